@@ -1,0 +1,159 @@
+"""ctypes binding of libgsd.so (include/gsd.h).  The product path: there is NO fallback.
+
+If the shared library is missing or fails to load, importing this module raises; nothing in
+gelslim_depth_amd/ ever routes to the oracle or to torch ops for the arithmetic of the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgsd.so")
+
+
+class GsdError(RuntimeError):
+    pass
+
+
+class gsd_src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("off_h", C.c_int32), ("off_w", C.c_int32), ("relu", C.c_int32),
+                ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
+
+
+class gsd_dst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("off_h", C.c_int32), ("off_w", C.c_int32),
+                ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_D = C.c_double
+_SRC = C.POINTER(gsd_src)
+_DST = C.POINTER(gsd_dst)
+
+# name -> (restype, argtypes); mirrors include/gsd.h one to one (tests check every symbol loads)
+SIGNATURES = {
+    "gsd_version": (C.c_char_p, []),
+    "gsd_last_error": (C.c_char_p, []),
+    "gsd_selftest_mfma": (_I, [_P, _P, _P, _P]),
+    "gsd_weight_layout_size": (_L, [_I, _I, _I]),
+    "gsd_weight_layout": (_I, [_I, _P, _I, _I, _P, _P]),
+    "gsd_conv3x3_partial_rows": (_I, [_I, _I, _I, _I]),
+    "gsd_conv3x3": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _I, _I, _I, _P]),
+    "gsd_convT2x2": (_I, [_SRC, _P, _P, _I, _I, _DST, _I, _I, _I, _P]),
+    "gsd_convT2x2_dgrad": (_I, [_SRC, _P, _I, _I, _DST, _I, _I, _I, _P]),
+    "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_wgrad": (_I, [_SRC, _I, _SRC, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "gsd_convT2x2_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "gsd_convT2x2_wgrad": (_I, [_SRC, _SRC, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "gsd_bn_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
+    "gsd_bn_finalize": (_I, [_P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gsd_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "gsd_bn_bwd_partial_rows": (_I, [_I, _I, _I, _I]),
+    "gsd_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _SRC, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "gsd_bn_bwd_reduce_partials": (_I, [_P, _I, _I, _P, _P]),
+    "gsd_bn_bwd_finalize": (_I, [_P, _P, _I, _D, _P, _P, _P, _P, _P, _P]),
+    "gsd_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "gsd_sum_planes": (_I, [_P, _I, _I, _L, _P, _P, _P]),
+    "gsd_maxpool2": (_I, [_SRC, _P, _I, _I, _I, _I, _P]),
+    "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _P]),
+    "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise GsdError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or python -m gelslim_depth_amd.build). There is no CPU/torch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.gsd_last_error().decode("utf-8", "replace")
+        raise GsdError(f"libgsd {what} failed (code {rc}): {msg}")
+
+
+def version() -> str:
+    return lib.gsd_version().decode()
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_f32(t: torch.Tensor) -> None:
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise GsdError(f"expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
+
+
+def make_src(t: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+             relu: bool = False, c_off: int = 0, c_len: Optional[int] = None,
+             off: Tuple[int, int] = (0, 0)) -> gsd_src:
+    """Describe channels [c_off, c_off+c_len) of a contiguous NCHW tensor as a gsd_src segment."""
+    _chk_f32(t)
+    assert t.dim() == 4 and t.is_contiguous()
+    n, ct, h, w = t.shape
+    cl = ct - c_off if c_len is None else c_len
+    s = gsd_src()
+    s.ptr = t.data_ptr() + 4 * c_off * h * w
+    s.scale = ptr(scale)
+    s.shift = ptr(shift)
+    s.C, s.H, s.W = cl, h, w
+    s.off_h, s.off_w = off
+    s.relu = 1 if relu else 0
+    s.n_stride = ct * h * w
+    s.c_stride = h * w
+    return s
+
+
+def make_dst(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None, off: Tuple[int, int] = (0, 0)) -> gsd_dst:
+    _chk_f32(t)
+    assert t.dim() == 4 and t.is_contiguous()
+    n, ct, h, w = t.shape
+    cl = ct - c_off if c_len is None else c_len
+    d = gsd_dst()
+    d.ptr = t.data_ptr() + 4 * c_off * h * w
+    d.C, d.H, d.W = cl, h, w
+    d.off_h, d.off_w = off
+    d.n_stride = ct * h * w
+    d.c_stride = h * w
+    return d
+
+
+def src_array(items: Sequence[gsd_src]):
+    arr = (gsd_src * len(items))()
+    for i, it in enumerate(items):
+        arr[i] = it
+    return arr
+
+
+def dst_array(items: Sequence[gsd_dst]):
+    arr = (gsd_dst * len(items))()
+    for i, it in enumerate(items):
+        arr[i] = it
+    return arr

@@ -1,0 +1,97 @@
+// gsd_common.h -- shared device helpers for libgsd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gsd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- host-side error plumbing (thread-local message, see gsd_api.hip) ----------------------
+void gsd_set_error(const char* fmt, ...);
+#define GSD_REQUIRE(cond, code, ...)                 \
+  do {                                               \
+    if (!(cond)) {                                   \
+      gsd_set_error(__VA_ARGS__);                    \
+      return (code);                                 \
+    }                                                \
+  } while (0)
+#define GSD_LAUNCH_CHECK(what)                                                       \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      gsd_set_error("%s: launch failed: %s", (what), hipGetErrorString(e_));         \
+      return GSD_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+// ---- device-side copies of the ABI descriptors (plain structs, passed by value in kernargs) --
+struct SrcD {
+  const float* p;
+  const float* scale;
+  const float* shift;
+  int C, H, W, oh, ow, relu;
+  long long ns, cs;
+};
+struct DstD {
+  float* p;
+  int C, H, W, oh, ow;
+  long long ns, cs;
+};
+
+static inline SrcD to_srcd(const gsd_src& s) {
+  SrcD d;
+  d.p = s.ptr; d.scale = s.scale; d.shift = s.shift;
+  d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w; d.relu = s.relu;
+  d.ns = s.n_stride; d.cs = s.c_stride;
+  return d;
+}
+static inline DstD to_dstd(const gsd_dst& s) {
+  DstD d;
+  d.p = s.ptr; d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w;
+  d.ns = s.n_stride; d.cs = s.c_stride;
+  return d;
+}
+static inline SrcD null_srcd() {
+  SrcD d;
+  d.p = nullptr; d.scale = nullptr; d.shift = nullptr;
+  d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.relu = 0; d.ns = 0; d.cs = 0;
+  return d;
+}
+static inline DstD null_dstd() {
+  DstD d;
+  d.p = nullptr; d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.ns = 0; d.cs = 0;
+  return d;
+}
+
+// Deferred BatchNorm + ReLU applied to a loaded raw value (channel c of segment s).
+__device__ __forceinline__ float apply_affine(float v, float sc, float sh, int relu) {
+  v = fmaf(v, sc, sh);
+  return relu ? fmaxf(v, 0.f) : v;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  // v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+  // D[row=(lane>>4)*4+reg][col=lane&15]  (cdna_hip_programming.md sec. 3)
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the 16 lanes that share lane>>4 (one MFMA column group)
+__device__ __forceinline__ float reduce16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

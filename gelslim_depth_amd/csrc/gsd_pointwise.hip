@@ -1,0 +1,535 @@
+// gsd_pointwise.hip -- the HBM-bound kernels of the U-Net train step (gfx950): BatchNorm statistics,
+// BatchNorm/ReLU/max-pool backward, max-pool forward, 1x1 output conv, loss, fused Adam+EMA, weight
+// re-layouts.  All of them are coalesced streaming passes along W (NCHW rows); reductions are
+// two-stage and ordered (bitwise reproducible), never float atomics.
+#include "gsd_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing / library info
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void gsd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* gsd_last_error(void) { return g_err; }
+extern "C" const char* gsd_version(void) { return "libgsd 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA lane-map self test
+// ---------------------------------------------------------------------------------------------
+__global__ void selftest_mfma_kernel(const float* a, const float* b, float* out) {
+  const int lane = threadIdx.x;
+  const float av = a[(lane & 15) * 4 + (lane >> 4)];   // A[i][k], row-major 16x4
+  const float bv = b[(lane >> 4) * 16 + (lane & 15)];  // B[k][j], row-major 4x16
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = mfma16(av, bv, c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = c[r];
+}
+extern "C" int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream) {
+  GSD_REQUIRE(a && b && out, GSD_ERR_BAD_ARG, "gsd_selftest_mfma: null argument");
+  hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);
+  GSD_LAUNCH_CHECK("gsd_selftest_mfma");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight re-layouts
+// ---------------------------------------------------------------------------------------------
+static void layout_dims(int mode, int Co, int Ci, int* rows, int* M) {
+  switch (mode) {
+    case 0: *rows = round_up(Ci, 4) * 9; *M = Co; break;        // k = ci*9+t        m = co
+    case 1: *rows = round_up(Co, 4) * 9; *M = Ci; break;        // k = co*9+t (flip) m = ci
+    case 2: *rows = round_up(Ci, 16); *M = Co * 4; break;       // k = ci            m = co*4+khkw
+    default: *rows = round_up(Co, 4) * 4; *M = Ci; break;       // k = co*4+khkw     m = ci
+  }
+}
+extern "C" int64_t gsd_weight_layout_size(int mode, int Co, int Ci) {
+  if (mode < 0 || mode > 3 || Co <= 0 || Ci <= 0) return 0;
+  int rows, M;
+  layout_dims(mode, Co, Ci, &rows, &M);
+  return (int64_t)rows * round_up(M, 64);
+}
+__global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int Co, int Ci, float* __restrict__ wt,
+                                     int rows, int M, int Mpad) {
+  const long long total = (long long)rows * Mpad;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(e % Mpad);
+    const int k = (int)(e / Mpad);
+    float v = 0.f;
+    if (m < M) {
+      if (mode == 0) {
+        const int ci = k / 9, t = k % 9;
+        if (ci < Ci) v = w[((size_t)m * Ci + ci) * 9 + t];
+      } else if (mode == 1) {
+        const int co = k / 9, t = k % 9;
+        if (co < Co) v = w[((size_t)co * Ci + m) * 9 + (8 - t)];
+      } else if (mode == 2) {
+        if (k < Ci) v = w[(size_t)k * M + m];  // (Ci, Co*4) is already [k][m]
+      } else {
+        const int co = k >> 2;
+        if (co < Co) v = w[(size_t)m * (Co * 4) + k];
+      }
+    }
+    wt[e] = v;
+  }
+}
+extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
+  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 3 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
+  int rows, M;
+  layout_dims(mode, Co, Ci, &rows, &M);
+  const int Mpad = round_up(M, 64);
+  const long long total = (long long)rows * Mpad;
+  const int grid = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+  hipLaunchKernelGGL(weight_layout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, rows, M,
+                     Mpad);
+  GSD_LAUNCH_CHECK("gsd_weight_layout");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums of a [rows][ncols] fp32 matrix into fp64 (two ordered stages)
+// ---------------------------------------------------------------------------------------------
+constexpr int RG = 64;  // row groups of stage 1
+__global__ void colsum_stage1(const float* __restrict__ part, int rows, int ld, int ncols, double* __restrict__ tmp) {
+  // block (64 cols x 4 row lanes); grid (ceil(ncols/64), RG)
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const int per = (rows + RG - 1) / RG;
+  const int rb = g * per, re = min(rb + per, rows);
+  double s = 0.0;
+  if (col < ncols)
+    for (int r = rb + rl; r < re; r += 4) s += (double)part[(size_t)r * ld + col];
+  __shared__ double red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncols)
+    tmp[(size_t)g * ncols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double* __restrict__ sums) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < ncols) {
+    double s = 0.0;
+    for (int g = 0; g < RG; ++g) s += tmp[(size_t)g * ncols + col];
+    sums[col] = s;
+  }
+}
+
+// sums layout: [0..C) sum, [C..2C) sum of squares.  tmp space lives right behind `sums`
+// (caller allocates (1+RG)*2*C doubles for `sums`).
+extern "C" int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad, int C, double* sums, void* stream) {
+  GSD_REQUIRE(partials && sums && rows > 0 && C > 0 && Mpad >= C, GSD_ERR_BAD_ARG, "gsd_bn_reduce_partials: bad argument");
+  double* tmp = sums + 2 * C;
+  // the two halves (sum | sumsq) are Mpad apart in a partial row; reduce them as two column ranges
+  for (int half = 0; half < 2; ++half) {
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(C, 64), RG), dim3(256), 0, (hipStream_t)stream,
+                       partials + (size_t)half * Mpad, rows, 2 * Mpad, C, tmp + (size_t)half * RG * C);
+    GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       tmp + (size_t)half * RG * C, C, sums + (size_t)half * C);
+    GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage2");
+  }
+  return GSD_OK;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / count;
+  double var = sums[C + c] / count - mu * mu;  // biased (normalisation) variance
+  if (var < 0.0) var = 0.0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[c] * is);
+  mean[c] = (float)mu;
+  invstd[c] = (float)is;
+  scale[c] = sc;
+  shift[c] = (float)((double)beta[c] - mu * (double)gamma[c] * is);
+  if (running_mean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+extern "C" int gsd_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, void* stream) {
+  GSD_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count > 0, GSD_ERR_BAD_ARG,
+              "gsd_bn_finalize: bad argument");
+  GSD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GSD_ERR_BAD_ARG,
+              "gsd_bn_finalize: running stats must come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  GSD_LAUNCH_CHECK("gsd_bn_finalize");
+  return GSD_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+extern "C" int gsd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  GSD_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, GSD_ERR_BAD_ARG,
+              "gsd_bn_eval_coeffs: bad argument");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  GSD_LAUNCH_CHECK("gsd_bn_eval_coeffs");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm + ReLU (+ max-pool / 1x1 output conv) backward, pass 1
+// ---------------------------------------------------------------------------------------------
+constexpr int BWD_CHUNK = 8192;  // elements of one (n, c) plane handled by one block
+
+struct BnBwdParams {
+  const float* raw;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  SrcD da;
+  const float* dpool;
+  const float* dout;
+  const float* wout;
+  int K;
+  float* dz;
+  float* partials;
+  int N, C, H, W, chunks;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P) {
+  // grid: (chunks, C, N)
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int HW = P.H * P.W;
+  const size_t plane = ((size_t)n * P.C + c) * HW;
+  const float sc = P.scale[c], sh = P.shift[c], mu = P.mean[c], is = P.invstd[c];
+  const int Hp = P.H >> 1, Wp = P.W >> 1;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int e_end = min((chunk + 1) * BWD_CHUNK, HW);
+  for (int e = chunk * BWD_CHUNK + threadIdx.x; e < e_end; e += 256) {
+    const float x = P.raw[plane + e];
+    const float y = fmaf(x, sc, sh);
+    float g;
+    if constexpr (MODE == 2) {
+      g = 0.f;
+      for (int k = 0; k < P.K; ++k) {
+        const float d = P.dout[((size_t)n * P.K + k) * HW + e];
+        g = fmaf(d, P.wout[(size_t)k * P.C + c], g);
+        if (k == 0) s3 = fmaf(d, fmaxf(y, 0.f), s3);  // dW_out[0][c] (K==1 fast path; K>1 handled on host side)
+      }
+    } else {
+      g = 0.f;
+      if (P.da.p != nullptr) {
+        const int h = e / P.W, w = e - h * P.W;
+        g = P.da.p[(size_t)n * P.da.ns + (size_t)c * P.da.cs + (size_t)h * P.da.W + w];
+      }
+      if constexpr (MODE == 1) {
+        const int h = e / P.W, w = e - h * P.W;
+        const int hp = h >> 1, wp = w >> 1;
+        if (hp < Hp && wp < Wp) {
+          // recompute the 2x2 arg-max of relu(bn(raw)); first maximum in (0,0),(0,1),(1,0),(1,1) order wins
+          const float* wbase = P.raw + plane + (size_t)(2 * hp) * P.W + 2 * wp;
+          float best = fmaxf(fmaf(wbase[0], sc, sh), 0.f);
+          int bi = 0;
+          float v = fmaxf(fmaf(wbase[1], sc, sh), 0.f);
+          if (v > best) { best = v; bi = 1; }
+          v = fmaxf(fmaf(wbase[P.W], sc, sh), 0.f);
+          if (v > best) { best = v; bi = 2; }
+          v = fmaxf(fmaf(wbase[P.W + 1], sc, sh), 0.f);
+          if (v > best) { best = v; bi = 3; }
+          if (bi == ((h & 1) << 1 | (w & 1))) g += P.dpool[(((size_t)n * P.C + c) * Hp + hp) * Wp + wp];
+        }
+      }
+    }
+    const float dzv = y > 0.f ? g : 0.f;
+    P.dz[plane + e] = dzv;
+    s1 += dzv;
+    s2 = fmaf(dzv, (x - mu) * is, s2);
+  }
+  __shared__ float red[3][4];
+  s1 = wave_sum_f(s1);
+  s2 = wave_sum_f(s2);
+  s3 = wave_sum_f(s3);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+    red[2][threadIdx.x >> 6] = s3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int row = n * P.chunks + chunk;
+    P.partials[(size_t)row * 3 * P.C + threadIdx.x * P.C + c] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
+extern "C" int gsd_bn_bwd_partial_rows(int N, int C, int H, int W) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return N * ceil_div(H * W, BWD_CHUNK);
+}
+
+extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, const gsd_src* da, const float* dpool, const float* dout,
+                                 const float* wout, int K, float* dz, float* partials, int N, int C, int H, int W,
+                                 void* stream) {
+  GSD_REQUIRE(raw && scale && shift && mean && invstd && dz && partials, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: null argument");
+  GSD_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 2, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: bad sizes");
+  GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_reduce: N, C must be <= 65535");
+  BnBwdParams P;
+  P.raw = raw; P.scale = scale; P.shift = shift; P.mean = mean; P.invstd = invstd;
+  P.da = null_srcd();
+  if (mode != 2 && da != nullptr && da->ptr != nullptr) {
+    GSD_REQUIRE(da->scale == nullptr && da->relu == 0 && da->off_h == 0 && da->off_w == 0 && da->H == H && da->W == W &&
+                    da->C >= C,
+                GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: da must be a plain (>=C,H,W) tensor");
+    P.da = to_srcd(*da);
+  }
+  if (mode == 0) GSD_REQUIRE(P.da.p != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode PLAIN needs da");
+  if (mode == 1) GSD_REQUIRE(dpool != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode POOL needs dpool");
+  if (mode == 2) {
+    GSD_REQUIRE(dout != nullptr && wout != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode OUTC needs dout, wout");
+    GSD_REQUIRE(K == 1, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_reduce: backward of the output conv supports n_classes == 1 only (got %d)", K);
+  }
+  P.dpool = dpool; P.dout = dout; P.wout = wout; P.K = K;
+  P.dz = dz; P.partials = partials;
+  P.N = N; P.C = C; P.H = H; P.W = W;
+  P.chunks = ceil_div(H * W, BWD_CHUNK);
+  dim3 grid(P.chunks, C, N);
+  if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  else if (mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce");
+  return GSD_OK;
+}
+
+// sums: 3*C doubles followed by RG*3*C doubles of scratch
+extern "C" int gsd_bn_bwd_reduce_partials(const float* partials, int rows, int C, double* sums, void* stream) {
+  GSD_REQUIRE(partials && sums && rows > 0 && C > 0, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce_partials: bad argument");
+  double* tmp = sums + 3 * C;
+  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(3 * C, 64), RG), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                     3 * C, 3 * C, tmp);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_partials stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(3 * C, 256)), dim3(256), 0, (hipStream_t)stream, tmp, 3 * C, sums);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_partials stage2");
+  return GSD_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* sl, const double* sg, int C, double count, float* dgamma,
+                                       float* dbeta, float* dwout, float* c1, float* c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)sl[c];
+  dgamma[c] = (float)sl[C + c];
+  if (dwout != nullptr) dwout[c] = (float)sl[2 * C + c];
+  c1[c] = (float)(sg[c] / count);
+  c2[c] = (float)(sg[C + c] / count);
+}
+extern "C" int gsd_bn_bwd_finalize(const double* sums_local, const double* sums_global, int C, double count,
+                                   float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream) {
+  GSD_REQUIRE(sums_local && dgamma && dbeta && c1 && c2 && C > 0 && count > 0, GSD_ERR_BAD_ARG,
+              "gsd_bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums_local,
+                     sums_global != nullptr ? sums_global : sums_local, C, count, dgamma, dbeta, dwout, c1, c2);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_finalize");
+  return GSD_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ raw,
+                                                           const float* scale, const float* mean, const float* invstd,
+                                                           const float* c1, const float* c2, int C, int HW, int chunks) {
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const size_t plane = ((size_t)n * C + c) * HW;
+  const float sc = scale[c], mu = mean[c], is = invstd[c], k1 = c1[c], k2 = c2[c];
+  const int e_end = min((chunk + 1) * BWD_CHUNK, HW);
+  for (int e = chunk * BWD_CHUNK + threadIdx.x; e < e_end; e += 256) {
+    const float xh = (raw[plane + e] - mu) * is;
+    dz[plane + e] = sc * (dz[plane + e] - k1 - xh * k2);
+  }
+}
+extern "C" int gsd_bn_bwd_apply(float* dz, const float* raw, const float* scale, const float* mean, const float* invstd,
+                                const float* c1, const float* c2, int N, int C, int H, int W, void* stream) {
+  GSD_REQUIRE(dz && raw && scale && mean && invstd && c1 && c2 && N > 0 && C > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG,
+              "gsd_bn_bwd_apply: bad argument");
+  GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_apply: N, C must be <= 65535");
+  const int chunks = ceil_div(H * W, BWD_CHUNK);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, dz, raw, scale, mean,
+                     invstd, c1, c2, C, H * W, chunks);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_apply");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2), floor mode, of relu(bn(raw))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const SrcD S, float* __restrict__ y, int C, int Hp, int Wp) {
+  // grid: (ceil(Hp*Wp/256), C, N)
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Hp * Wp) return;
+  const int hp = e / Wp, wp = e - hp * Wp;
+  const float* b = S.p + (size_t)n * S.ns + (size_t)c * S.cs + (size_t)(2 * hp) * S.W + 2 * wp;
+  float sc = 1.f, sh = 0.f;
+  if (S.scale != nullptr) { sc = S.scale[c]; sh = S.shift[c]; }
+  float v0 = fmaf(b[0], sc, sh), v1 = fmaf(b[1], sc, sh), v2 = fmaf(b[S.W], sc, sh), v3 = fmaf(b[S.W + 1], sc, sh);
+  float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+  if (S.relu) m = fmaxf(m, 0.f);
+  y[(((size_t)n * C + c) * Hp + hp) * Wp + wp] = m;
+}
+extern "C" int gsd_maxpool2(const gsd_src* src, float* y, int N, int C, int H, int W, void* stream) {
+  GSD_REQUIRE(src && src->ptr && y && N > 0 && C > 0 && H > 1 && W > 1, GSD_ERR_BAD_ARG, "gsd_maxpool2: bad argument");
+  GSD_REQUIRE(src->C == C && src->H == H && src->W == W && src->off_h == 0 && src->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_maxpool2: src must be the full (C,H,W) tensor");
+  GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_maxpool2: N, C must be <= 65535");
+  const int Hp = H / 2, Wp = W / 2;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(ceil_div(Hp * Wp, 256), C, N), dim3(256), 0, (hipStream_t)stream,
+                     to_srcd(*src), y, C, Hp, Wp);
+  GSD_LAUNCH_CHECK("gsd_maxpool2");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 output conv (+bias) of relu(bn(raw))
+// ---------------------------------------------------------------------------------------------
+constexpr int OUTC_MAXK = 8;
+__global__ __launch_bounds__(256) void conv1x1_out_kernel(const SrcD S, const float* __restrict__ w,
+                                                          const float* __restrict__ b, int C, int K,
+                                                          float* __restrict__ out, int HW) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float acc[OUTC_MAXK];
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k) acc[k] = 0.f;
+  const float* base = S.p + (size_t)n * S.ns + p;
+  for (int c = 0; c < C; ++c) {
+    float v = base[(size_t)c * S.cs];
+    if (S.scale != nullptr) v = fmaf(v, S.scale[c], S.shift[c]);
+    if (S.relu) v = fmaxf(v, 0.f);
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXK; ++k)
+      if (k < K) acc[k] = fmaf(w[k * C + c], v, acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k)
+    if (k < K) out[((size_t)n * K + k) * HW + p] = acc[k] + (b != nullptr ? b[k] : 0.f);
+}
+extern "C" int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* b, int C, int K, float* out, int N, int H,
+                               int W, void* stream) {
+  GSD_REQUIRE(src && src->ptr && w && out && N > 0 && C > 0 && K > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG,
+              "gsd_conv1x1_out: bad argument");
+  GSD_REQUIRE(K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out: n_classes %d > %d", K, OUTC_MAXK);
+  GSD_REQUIRE(src->C == C && src->H == H && src->W == W && src->off_h == 0 && src->off_w == 0 &&
+                  src->c_stride == (int64_t)H * W,
+              GSD_ERR_BAD_ARG, "gsd_conv1x1_out: src must be the full contiguous (C,H,W) tensor");
+  GSD_REQUIRE(N <= 65535, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out: N must be <= 65535");
+  hipLaunchKernelGGL(conv1x1_out_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, (hipStream_t)stream, to_srcd(*src),
+                     w, b, C, K, out, H * W);
+  GSD_LAUNCH_CHECK("gsd_conv1x1_out");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss (MSE / L1) forward + gradient
+// ---------------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 1024;
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_stage1(const float* __restrict__ o, const float* __restrict__ t,
+                                                   long long numel, float gscale, float* __restrict__ grad,
+                                                   float* __restrict__ ws) {
+  double s = 0.0;
+  const float inv = 1.0f / (float)numel;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
+    const float d = o[i] - t[i];
+    if (KIND == 0) {
+      s += (double)d * (double)d;
+      if (grad != nullptr) grad[i] = 2.f * d * inv * gscale;
+    } else {
+      s += (double)fabsf(d);
+      if (grad != nullptr) grad[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv * gscale;
+    }
+  }
+  __shared__ double red[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<double*>(ws)[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void loss_stage2(const float* ws, int nblocks, long long numel, float* loss_out) {
+  // single wave
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) s += reinterpret_cast<const double*>(ws)[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) loss_out[0] = (float)(s / (double)numel);
+}
+extern "C" int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_t numel, float grad_scale, float* loss_out,
+                                float* grad, float* workspace, void* stream) {
+  GSD_REQUIRE(o && t && loss_out && workspace && numel > 0 && (kind == 0 || kind == 1), GSD_ERR_BAD_ARG,
+              "gsd_loss_fwd_bwd: bad argument");
+  GSD_REQUIRE(((uintptr_t)workspace & 7) == 0, GSD_ERR_BAD_ARG, "gsd_loss_fwd_bwd: workspace must be 8-byte aligned");
+  int blocks = (int)(ceil_div64(numel, 256) < LOSS_BLOCKS ? ceil_div64(numel, 256) : LOSS_BLOCKS);
+  if (kind == 0)
+    hipLaunchKernelGGL((loss_stage1<0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, o, t, (long long)numel,
+                       grad_scale, grad, workspace);
+  else
+    hipLaunchKernelGGL((loss_stage1<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, o, t, (long long)numel,
+                       grad_scale, grad, workspace);
+  GSD_LAUNCH_CHECK("gsd_loss_fwd_bwd stage1");
+  hipLaunchKernelGGL(loss_stage2, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, blocks, (long long)numel, loss_out);
+  GSD_LAUNCH_CHECK("gsd_loss_fwd_bwd stage2");
+  return GSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused Adam (coupled L2) + EMA over a flat arena
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ ema, long long numel, float lr_over_bc1,
+                                                       float sqrt_bc2, float b1, float b2, float eps, float wd,
+                                                       float one_minus_d, float gscale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
+    float pv = p[i];
+    const float gv = fmaf(wd, pv, g[i] * gscale);   // g += wd*p            (torch _single_tensor_adam)
+    float mv = m[i];
+    mv = mv + (gv - mv) * (1.f - b1);               // exp_avg.lerp_(g, 1-b1)
+    const float vv = fmaf(1.f - b2, gv * gv, v[i] * b2);   // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    const float denom = sqrtf(vv) / sqrt_bc2 + eps;    // sqrt(v)/sqrt(bc2) + eps
+    pv = pv - lr_over_bc1 * (mv / denom);                  // p.addcdiv_(m, denom, -lr/bc1)
+    p[i] = pv;
+    m[i] = mv;
+    v[i] = vv;
+    if (ema != nullptr) {
+      const float s = ema[i];
+      ema[i] = s - one_minus_d * (s - pv);          // torch_ema: shadow.sub_((1-d)*(shadow-param))
+    }
+  }
+}
+extern "C" int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, int step, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
+                            void* stream) {
+  GSD_REQUIRE(p && g && m && v && numel > 0 && step >= 1, GSD_ERR_BAD_ARG, "gsd_adam_ema: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float lr_over_bc1 = (float)((double)lr / bc1);
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  const int blocks = (int)(ceil_div64(numel, 256) < 4096 ? ceil_div64(numel, 256) : 4096);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)numel,
+                     lr_over_bc1, sqrt_bc2, beta1, beta2, eps, weight_decay, 1.0f - ema_decay, grad_scale);
+  GSD_LAUNCH_CHECK("gsd_adam_ema");
+  return GSD_OK;
+}

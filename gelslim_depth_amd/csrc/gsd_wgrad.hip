@@ -1,0 +1,454 @@
+// gsd_wgrad.hip -- weight gradients as implicit GEMM over pixels on v_mfma_f32_16x16x4_f32 (gfx950).
+//
+//   MODE 0  conv3x3:  dW[co][ci][tap] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1]
+//           (the dW half of aten::convolution_backward for /root/reference/gelslim_depth/models/unet.py:11,14)
+//   MODE 1  convT2x2: dW[ci][co][kh][kw] = sum_{n,h,w} x[n,ci,h,w] * dy[n,co,2h+kh,2w+kw]   (unet.py:36)
+//
+// GEMM view: D[m][col] = sum_pixels A[m][pixel] * B[pixel][col] with the pixel index on the MFMA
+// k dimension (4 consecutive pixels of one row per instruction).  A = dy rows (MODE 1: space-to-depth
+// rows (co,kh,kw)), B = activation `a` with deferred BatchNorm+ReLU, zero padding and the two-segment
+// channel concat recomputed on load, so the tensors the reference saves for backward (relu outputs,
+// padded/concatenated inputs) are never stored.
+//
+// Wave tile: 64 m-rows x (16 input channels x 9 taps) [MODE 0] or 64 x 64 [MODE 1].
+// Reduction over pixels is split across blocks (split-K); every block writes a partial slab and a
+// second kernel sums the slabs in a fixed order => bitwise reproducible.
+#include "gsd_common.h"
+
+struct WgradParams {
+  SrcD a0, a1;  // B operand (activation)
+  SrcD dy;      // A operand (gradient, plain)
+  float* slabs;
+  int M, Ncols, Cact;  // M rows (Cout or Cout*4), Ncols = Cin, Cact = total channels of a0+a1
+  int N, H, W;
+  int TH, TW, tiles_y, tiles_x, WR, WC, PS;  // MODE 0
+  int tiles_flat;                            // MODE 1
+  int stages_total, splits, mblocks, nblocks;
+};
+
+template <int MODE, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
+  constexpr int MT = 4;
+  constexpr int NTB = MODE == 0 ? 9 : 4;
+  constexpr int BMw = WM * 64;
+  constexpr int BNw = MODE == 0 ? WN * 16 : WN * 64;
+  constexpr int DS = 66;  // == 2 (mod 32): 16 rows x 2 k-pixels of a half-wave hit 32 distinct banks
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Al = smem;             // [BMw][DS]
+  float* Xl = smem + BMw * DS;  // MODE 0: [BNw][PS]; MODE 1: [BNw][DS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane >> 4, l16 = lane & 15;
+  const int XS = MODE == 0 ? P.PS : DS;
+
+  const int per_split = P.mblocks * P.nblocks;
+  const int split = blockIdx.x / per_split;
+  const int rem = blockIdx.x - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BMw, n0 = nb * BNw;
+  const int s_begin = (int)((long long)split * P.stages_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
+  const int HW = P.H * P.W;
+
+  f32x4 acc[MT][NTB];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int q = tid & 63;   // loader pixel
+  const int lrow = tid >> 6;  // loader row phase 0..3
+
+  for (int stage = s_begin; stage < s_end; ++stage) {
+    int n, h0 = 0, w0 = 0, p0 = 0;
+    if constexpr (MODE == 0) {
+      const int tpi = P.tiles_y * P.tiles_x;
+      n = stage / tpi;
+      const int r = stage - n * tpi;
+      const int ty = r / P.tiles_x;
+      h0 = ty * P.TH;
+      w0 = (r - ty * P.tiles_x) * P.TW;
+    } else {
+      n = stage / P.tiles_flat;
+      p0 = (stage - n * P.tiles_flat) * 64;
+    }
+    __syncthreads();  // previous stage's MFMAs are done with LDS
+    // ---- A tile ------------------------------------------------------------------------------
+    if constexpr (MODE == 0) {
+      const bool qin = q < P.TH * P.TW;
+      const int r = qin ? q / P.TW : 0;
+      const int c = qin ? q - r * P.TW : 0;
+      const bool pix_ok = qin && (h0 + r) < P.H && (w0 + c) < P.W;
+      const float* base = P.dy.p + (long long)n * P.dy.ns + (long long)(h0 + r) * P.dy.W + (w0 + c);
+#pragma unroll 8
+      for (int i = 0; i < BMw / 4; ++i) {
+        const int row = lrow + 4 * i;
+        const int co = m0 + row;
+        float v = 0.f;
+        if (pix_ok && co < P.M) v = base[(long long)co * P.dy.cs];
+        Al[row * DS + q] = v;
+      }
+    } else {
+      const int p = p0 + q;
+      const bool pix_ok = p < HW;
+      const int h = pix_ok ? p / P.W : 0;
+      const int w = pix_ok ? p - h * P.W : 0;
+#pragma unroll 8
+      for (int i = 0; i < BMw / 8; ++i) {
+        const int rr = lrow + 4 * i;  // (co_i, kh)
+        const int co = (m0 >> 2) + (rr >> 1);
+        const int kh = rr & 1;
+        float2 v = make_float2(0.f, 0.f);
+        if (pix_ok && co < P.dy.C)
+          v = *reinterpret_cast<const float2*>(P.dy.p + (long long)n * P.dy.ns + (long long)co * P.dy.cs +
+                                               (long long)(2 * h + kh) * P.dy.W + 2 * w);
+        const int mrow = (rr >> 1) * 4 + kh * 2;
+        Al[mrow * DS + q] = v.x;
+        Al[(mrow + 1) * DS + q] = v.y;
+      }
+    }
+    // ---- B tile ------------------------------------------------------------------------------
+    if constexpr (MODE == 0) {
+      const bool pos_ok = tid < P.WR * P.WC;
+      const int rr = tid / P.WC;
+      const int gh = h0 - 1 + rr, gw = w0 - 1 + (tid - rr * P.WC);
+      if (pos_ok) {
+#pragma unroll 4
+        for (int ch = 0; ch < BNw; ++ch) {
+          const int c = n0 + ch;
+          const bool first = c < P.a0.C;
+          const SrcD& S = first ? P.a0 : P.a1;
+          const int cc = first ? c : c - P.a0.C;
+          const int hs = gh - S.oh, ws = gw - S.ow;
+          float v = 0.f;
+          if (c < P.Cact && cc < S.C && (unsigned)hs < (unsigned)S.H && (unsigned)ws < (unsigned)S.W) {
+            v = S.p[(long long)n * S.ns + (long long)cc * S.cs + hs * S.W + ws];
+            if (S.scale != nullptr) v = apply_affine(v, S.scale[cc], S.shift[cc], S.relu);
+            else if (S.relu) v = fmaxf(v, 0.f);
+          }
+          Xl[ch * XS + tid] = v;
+        }
+      }
+    } else {
+      const int p = p0 + q;
+      const bool pix_ok = p < HW;
+#pragma unroll 8
+      for (int i = 0; i < BNw / 4; ++i) {
+        const int ch = lrow + 4 * i;
+        const int c = n0 + ch;
+        float v = 0.f;
+        if (pix_ok && c < P.a0.C) {
+          v = P.a0.p[(long long)n * P.a0.ns + (long long)c * P.a0.cs + p];
+          if (P.a0.scale != nullptr) v = apply_affine(v, P.a0.scale[c], P.a0.shift[c], P.a0.relu);
+          else if (P.a0.relu) v = fmaxf(v, 0.f);
+        }
+        Xl[ch * XS + q] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the stage's pixels ----------------------------------------------------------
+    const int nk = MODE == 0 ? (P.TH * P.TW) / 4 : 16;
+    int r = 0, c = 0;
+    const int a_base = (wm * 64 + l16) * DS + j;
+    const int b_base = MODE == 0 ? (wn * 16 + l16) * XS + j : (wn * 64 + l16) * XS + j;
+    for (int s = 0; s < nk; ++s) {
+      float a[MT], b[NTB];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = Al[a_base + m * 16 * DS + 4 * s];
+      if constexpr (MODE == 0) {
+        const int xb = b_base + r * P.WC + c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = Xl[xb + (t / 3) * P.WC + (t % 3)];
+        c += 4;
+        if (c >= P.TW) {
+          c = 0;
+          ++r;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = Xl[b_base + t * 16 * XS + 4 * s];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+    }
+  }
+
+  // ---- slab store: D[row = m][col = l16] ---------------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int mr = m0 + wm * 64 + m * 16 + j * 4 + reg;
+      if (mr < P.M) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+          const int col = MODE == 0 ? (n0 + wn * 16 + l16) : (n0 + wn * 64 + t * 16 + l16);
+          if (col < P.Ncols) {
+            const size_t idx = MODE == 0 ? (((size_t)split * 9 + t) * P.M + mr) * P.Ncols + col
+                                         : ((size_t)split * P.M + mr) * P.Ncols + col;
+            P.slabs[idx] = acc[m][t][reg];
+          }
+        }
+      }
+    }
+}
+
+// Sum the slabs in split order and write the reference layout.
+//   MODE 0: slab[split][tap][co][ci] -> dW[co][ci][tap]
+//   MODE 1: slab[split][m][ci]       -> dW[ci][m]          (m = co*4+kh*2+kw)
+template <int MODE>
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int M,
+                                    int Ncols) {
+  const long long per = (long long)(MODE == 0 ? 9 : 1) * M * Ncols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * per + e];
+    const int col = (int)(e % Ncols);
+    const long long t2 = e / Ncols;
+    const int mr = (int)(t2 % M);
+    if (MODE == 0) {
+      const int tap = (int)(t2 / M);
+      dw[((size_t)mr * Ncols + col) * 9 + tap] = s;
+    } else {
+      dw[(size_t)col * M + mr] = s;
+    }
+  }
+}
+
+// out[k] = sum_{n, p} x[n][k][p]  -- two deterministic stages (G=64 groups per channel).
+__global__ void sum_planes_stage1(const float* __restrict__ x, int N, int K, long long HW, float* __restrict__ ws) {
+  const int k = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+  const long long total = (long long)N * HW;
+  const long long per = (total + G - 1) / G;
+  const long long b = (long long)g * per, e = b + per < total ? b + per : total;
+  double s = 0.0;
+  for (long long i = b + threadIdx.x; i < e; i += blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    s += (double)x[((size_t)n * K + k) * HW + p];
+  }
+  __shared__ double red[4];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[(size_t)k * G + g] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void sum_planes_stage2(const float* __restrict__ ws, int K, int G, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) {
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += (double)ws[(size_t)k * G + g];
+    out[k] = (float)s;
+  }
+}
+
+namespace {
+
+void choose_wgrad_tile(int H, int W, int* TH, int* TW) {
+  long best = -1;
+  int bh = 1, bw = 4;
+  for (int tw = 4; tw <= 64; tw += 4) {
+    int th = 64 / tw;
+    if (th > H) th = H;
+    while (th > 1 && (th + 2) * (tw + 2) > 256) --th;
+    if ((th + 2) * (tw + 2) > 256) continue;
+    const int ty = ceil_div(H, th);
+    th = ceil_div(H, ty);
+    const long stages = (long)ty * ceil_div(W, tw);
+    // cost: MFMA work ~ stages * th*tw (k-steps) ; prefer fewer wasted pixel slots, then wider rows
+    const long cost = stages * (long)(th * tw) * 1000 + stages * 10 - tw;
+    if (best < 0 || cost < best) {
+      best = cost;
+      bh = th;
+      bw = tw;
+    }
+  }
+  *TH = bh;
+  *TW = bw;
+}
+
+int plane_stride_2mod32(int n) {
+  int ps = (n / 32) * 32 + 2;
+  if (ps < n) ps += 32;
+  return ps;
+}
+
+struct WgradPlan {
+  bool wide;  // WM=1,WN=4 (M<=64) else WM=2,WN=2
+  int BMw, BNw, mblocks, nblocks, TH, TW, tiles_y, tiles_x, tiles_flat, stages_total, splits;
+  int64_t slab_elems;
+};
+
+WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
+  WgradPlan p;
+  p.wide = M <= 64;
+  p.BMw = p.wide ? 64 : 128;
+  const int WN = p.wide ? 4 : 2;
+  p.BNw = mode == 0 ? WN * 16 : WN * 64;
+  p.mblocks = ceil_div(M, p.BMw);
+  p.nblocks = ceil_div(Ncols, p.BNw);
+  p.TH = p.TW = p.tiles_y = p.tiles_x = p.tiles_flat = 0;
+  if (mode == 0) {
+    choose_wgrad_tile(H, W, &p.TH, &p.TW);
+    p.tiles_y = ceil_div(H, p.TH);
+    p.tiles_x = ceil_div(W, p.TW);
+    p.stages_total = N * p.tiles_y * p.tiles_x;
+  } else {
+    p.tiles_flat = ceil_div(H * W, 64);
+    p.stages_total = N * p.tiles_flat;
+  }
+  const int tiles = p.mblocks * p.nblocks;
+  int splits = ceil_div(1536, tiles);
+  if (splits > p.stages_total) splits = p.stages_total;
+  if (splits > 2048) splits = 2048;
+  if (splits < 1) splits = 1;
+  p.splits = splits;
+  p.slab_elems = (int64_t)splits * (mode == 0 ? 9 : 1) * M * Ncols;
+  return p;
+}
+
+int check_plain(const gsd_src& s, const char* what) {
+  GSD_REQUIRE(s.ptr != nullptr && s.scale == nullptr && s.shift == nullptr && s.relu == 0 && s.off_h == 0 &&
+                  s.off_w == 0,
+              GSD_ERR_BAD_ARG, "%s: gradient operand must be a plain tensor", what);
+  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
+              what);
+  return 0;
+}
+
+template <int MODE, int WM, int WN>
+int launch_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t st, const char* what) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MODE, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<MODE, WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK(what);
+  return GSD_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return plan_wgrad(0, N, H, W, Cout, Cin).slab_elems;
+}
+
+extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw,
+                                 float* workspace, int64_t workspace_elems, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(a && dy && dw && workspace, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: null argument");
+  GSD_REQUIRE(nsrc >= 1 && nsrc <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: nsrc must be 1 or 2");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: bad sizes");
+  int csum = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    GSD_REQUIRE(a[i].ptr != nullptr && a[i].C > 0 && a[i].H > 0 && a[i].W > 0, GSD_ERR_BAD_ARG,
+                "gsd_conv3x3_wgrad: bad activation segment %d", i);
+    GSD_REQUIRE((a[i].scale == nullptr) == (a[i].shift == nullptr), GSD_ERR_BAD_ARG,
+                "gsd_conv3x3_wgrad: scale/shift must come together");
+    csum += a[i].C;
+  }
+  GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: activation segments hold %d channels, Cin=%d", csum, Cin);
+  if (int e = check_plain(*dy, "gsd_conv3x3_wgrad dy")) return e;
+  GSD_REQUIRE(dy->C == Cout && dy->H == H && dy->W == W, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: dy must be (Cout,H,W)");
+  WgradPlan pl = plan_wgrad(0, N, H, W, Cout, Cin);
+  GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_conv3x3_wgrad: workspace %lld < %lld elements",
+              (long long)workspace_elems, (long long)pl.slab_elems);
+  WgradParams P;
+  P.a0 = to_srcd(a[0]);
+  P.a1 = nsrc > 1 ? to_srcd(a[1]) : null_srcd();
+  P.dy = to_srcd(*dy);
+  P.slabs = workspace;
+  P.M = Cout; P.Ncols = Cin; P.Cact = Cin;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.WR = pl.TH + 2; P.WC = pl.TW + 2;
+  P.PS = plane_stride_2mod32(P.WR * P.WC);
+  P.tiles_flat = 0;
+  P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
+  const int grid = pl.splits * pl.mblocks * pl.nblocks;
+  const size_t lds = (size_t)(pl.BMw * 66 + pl.BNw * P.PS) * sizeof(float);
+  int rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
+                   : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
+  if (rc) return rc;
+  const long long per = 9LL * Cout * Cin;
+  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+  hipLaunchKernelGGL((wgrad_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits,
+                     Cout, Cin);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad reduce");
+  return GSD_OK;
+}
+
+extern "C" int64_t gsd_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return plan_wgrad(1, N, H, W, Cout * 4, Cin).slab_elems + (int64_t)Cout * 64;
+}
+
+extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, int Cout, float* dw, float* dbias,
+                                  float* workspace, int64_t workspace_elems, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(x && dy && dw && workspace, GSD_ERR_BAD_ARG, "gsd_convT2x2_wgrad: null argument");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_wgrad: bad sizes");
+  GSD_REQUIRE(x->ptr != nullptr && x->C == Cin && x->H == H && x->W == W && x->off_h == 0 && x->off_w == 0,
+              GSD_ERR_BAD_ARG, "gsd_convT2x2_wgrad: x must be the full (Cin,H,W) tensor");
+  GSD_REQUIRE((x->scale == nullptr) == (x->shift == nullptr), GSD_ERR_BAD_ARG,
+              "gsd_convT2x2_wgrad: scale/shift must come together");
+  if (int e = check_plain(*dy, "gsd_convT2x2_wgrad dy")) return e;
+  GSD_REQUIRE(dy->C == Cout && dy->H == 2 * H && dy->W == 2 * W, GSD_ERR_BAD_ARG,
+              "gsd_convT2x2_wgrad: dy must be (Cout,2H,2W)");
+  GSD_REQUIRE(((uintptr_t)dy->ptr & 7) == 0 && (dy->c_stride & 1) == 0 && (dy->n_stride & 1) == 0, GSD_ERR_UNSUPPORTED,
+              "gsd_convT2x2_wgrad: dy must be 8-byte aligned with even strides");
+  const int M = Cout * 4;
+  WgradPlan pl = plan_wgrad(1, N, H, W, M, Cin);
+  const int64_t need = pl.slab_elems + (int64_t)Cout * 64;
+  GSD_REQUIRE(workspace_elems >= need, GSD_ERR_WORKSPACE, "gsd_convT2x2_wgrad: workspace %lld < %lld elements",
+              (long long)workspace_elems, (long long)need);
+  WgradParams P;
+  P.a0 = to_srcd(*x);
+  P.a1 = null_srcd();
+  P.dy = to_srcd(*dy);
+  P.slabs = workspace;
+  P.M = M; P.Ncols = Cin; P.Cact = Cin;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = P.TW = P.tiles_y = P.tiles_x = P.WR = P.WC = P.PS = 0;
+  P.tiles_flat = pl.tiles_flat;
+  P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
+  const int grid = pl.splits * pl.mblocks * pl.nblocks;
+  const size_t lds = (size_t)(pl.BMw * 66 + pl.BNw * 66) * sizeof(float);
+  int rc = pl.wide ? launch_wgrad<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_convT2x2_wgrad")
+                   : launch_wgrad<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_convT2x2_wgrad");
+  if (rc) return rc;
+  const long long per = (long long)M * Cin;
+  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+  hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits,
+                     M, Cin);
+  GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad reduce");
+  if (dbias != nullptr) {
+    GSD_REQUIRE(dy->c_stride == (int64_t)4 * H * W && dy->n_stride == (int64_t)Cout * 4 * H * W, GSD_ERR_UNSUPPORTED,
+                "gsd_convT2x2_wgrad: bias gradient needs a contiguous dy");
+    float* ws2 = workspace + pl.slab_elems;
+    hipLaunchKernelGGL(sum_planes_stage1, dim3(Cout, 64), dim3(256), 0, (hipStream_t)stream, dy->ptr, N, Cout,
+                       (long long)4 * H * W, ws2);
+    GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad bias stage1");
+    hipLaunchKernelGGL(sum_planes_stage2, dim3(ceil_div(Cout, 256)), dim3(256), 0, (hipStream_t)stream, ws2, Cout, 64,
+                       dbias);
+    GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad bias stage2");
+  }
+  return GSD_OK;
+}
+
+extern "C" int gsd_sum_planes(const float* x, int N, int K, int64_t HW, float* out, float* workspace, void* stream) {
+  GSD_REQUIRE(x && out && workspace && N > 0 && K > 0 && HW > 0, GSD_ERR_BAD_ARG, "gsd_sum_planes: bad argument");
+  hipLaunchKernelGGL(sum_planes_stage1, dim3(K, 64), dim3(256), 0, (hipStream_t)stream, x, N, K, (long long)HW, workspace);
+  GSD_LAUNCH_CHECK("gsd_sum_planes stage1");
+  hipLaunchKernelGGL(sum_planes_stage2, dim3(ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream, workspace, K, 64, out);
+  GSD_LAUNCH_CHECK("gsd_sum_planes stage2");
+  return GSD_OK;
+}

@@ -1,0 +1,326 @@
+"""Host-side schedule of the U-Net hot path over libgsd's C ABI.
+
+Mirrors the control flow of the reference model
+(/root/reference/gelslim_depth/models/unet.py:79-88 forward; autograd's reverse sweep for backward)
+but every arithmetic step is a libgsd kernel launch on torch's current HIP stream.  torch is used
+for device memory (buffers) and, in data-parallel runs, for the RCCL collectives; no torch op
+computes any part of the path.
+
+Data layout in HBM (all fp32 NCHW):
+  raw[u]    raw conv3x3 output of every conv unit (pre-BN); the normalised/activated tensor is
+            never stored, consumers apply (scale, shift, relu) on load            -- 18 tensors
+  g[u]      gradient buffer of the same shape: da -> dz -> d_raw in place         -- 18 tensors
+  pooled[l] max-pool output feeding encoder level l (l>=1);  dpooled[l] its gradient
+  up[j]     transposed-conv output (+bias) of decoder j at (2h,2w), unpadded;  dup[j] its gradient
+  wt_*      per-step re-laid-out weights (k-major, out-channel contiguous)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _r64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+class _Unit:
+    """conv3x3(no bias) + BatchNorm2d + ReLU (unet.py:11-13 / :14-16)."""
+
+    def __init__(self, prefix: str, conv_idx: int, bn_idx: int, cin: int, cout: int, level: int):
+        self.prefix, self.conv_idx, self.bn_idx = prefix, conv_idx, bn_idx
+        self.cin, self.cout, self.level = cin, cout, level
+        self.wname = f"{prefix}.double_conv.{conv_idx}.weight"
+        bn = f"{prefix}.double_conv.{bn_idx}."
+        self.gname, self.bname = bn + "weight", bn + "bias"
+        self.rmname, self.rvname, self.nbtname = bn + "running_mean", bn + "running_var", bn + "num_batches_tracked"
+        self.need_dgrad = True
+        # device buffers (filled by the engine)
+        self.wt_f = self.wt_d = None
+        self.scale = self.shift = self.mean = self.invstd = self.c1 = self.c2 = None
+        self.sums = None
+        self.raw = self.g = None
+        self.srcs = None  # gsd_src array kept for wgrad
+
+
+class _Up:
+    """ConvTranspose2d(cin, cin//2, 2, 2) (unet.py:36)."""
+
+    def __init__(self, j: int, cin: int, level_in: int):
+        self.j, self.cin, self.cout, self.level_in = j, cin, cin // 2, level_in
+        self.wname, self.bname = f"up.{j}.up.weight", f"up.{j}.up.bias"
+        self.wt_f = self.wt_d = None
+        self.out = self.dout = None
+
+
+class UNetEngine:
+    def __init__(self, n_channels: int, n_classes: int, layer_dimensions: Sequence[int]):
+        dims = list(layer_dimensions)
+        self.n_channels, self.n_classes, self.dims = n_channels, n_classes, dims
+        self.L = len(dims) - 1
+        self.enc: List[Tuple[_Unit, _Unit]] = []
+        self.dec: List[Tuple[_Unit, _Unit]] = []
+        self.ups: List[_Up] = []
+        self.enc.append((_Unit("inc", 0, 1, n_channels, dims[0], 0), _Unit("inc", 3, 4, dims[0], dims[0], 0)))
+        self.enc[0][0].need_dgrad = False
+        for i in range(self.L):
+            p = f"down.{i}.maxpool_conv.1"
+            self.enc.append((_Unit(p, 0, 1, dims[i], dims[i + 1], i + 1), _Unit(p, 3, 4, dims[i + 1], dims[i + 1], i + 1)))
+        for j, i in enumerate(range(self.L, 0, -1)):
+            cin, cout = dims[i], dims[i - 1]
+            # Up(cin, cout): ConvTranspose2d(cin, cin//2) then DoubleConv(cin, cout) on cat[skip, up] (unet.py:36-37,48):
+            # the reference only runs when skip channels + cin//2 == cin.
+            if dims[i - 1] + cin // 2 != cin:
+                raise ValueError(f"layer_dimensions {dims}: level {i} needs dims[i-1] + dims[i]//2 == dims[i] "
+                                 "(the reference model fails at torch.cat/conv otherwise)")
+            self.ups.append(_Up(j, cin, i))
+            p = f"up.{j}.conv"
+            # DoubleConv(in_channels=cin, out=cout): input = cat[skip (dims[i-1]), up (cin//2)]
+            self.dec.append((_Unit(p, 0, 1, cin, cout, i - 1), _Unit(p, 3, 4, cout, cout, i - 1)))
+        self.units: List[_Unit] = [u for pair in self.enc for u in pair] + [u for pair in self.dec for u in pair]
+        self._shape = None
+        self._dev = None
+        self.sync_fn: Optional[Callable[[torch.Tensor], None]] = None   # SyncBN hook: all-reduce fp64 sums in place
+        self.world = 1
+        self._saved_train = False
+        self.block_done_cb: Optional[Callable[[str], None]] = None   # data-parallel hook: a block's grads are final
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
+        key = (n, h, w, str(dev))
+        if self._shape == key and (not train or self.units[0].g is not None):
+            return
+        if self._shape != key:
+            for u in self.units:
+                u.raw = u.g = None
+            for up in self.ups:
+                up.out = up.dout = None
+        self._shape = key
+        self._dev = dev
+        hs, ws = [h], [w]
+        for _ in range(self.L):
+            hs.append(hs[-1] // 2)
+            ws.append(ws[-1] // 2)
+        assert hs[-1] >= 1 and ws[-1] >= 1, "input too small for this many max-pools"
+        self.hs, self.ws = hs, ws
+        f32 = dict(device=dev, dtype=torch.float32)
+        max_part = 1
+        max_ws = 1
+        for u in self.units:
+            lh, lw = hs[u.level], ws[u.level]
+            if u.raw is None:
+                u.raw = torch.empty((n, u.cout, lh, lw), **f32)
+            if train and u.g is None:
+                u.g = torch.empty((n, u.cout, lh, lw), **f32)
+            if u.scale is None or u.scale.device != dev:
+                for nm in ("scale", "shift", "mean", "invstd", "c1", "c2"):
+                    setattr(u, nm, torch.empty((u.cout,), **f32))
+                u.sums = torch.empty((65 * 3 * u.cout,), device=dev, dtype=torch.float64)
+                u.wt_f = torch.empty((lib.gsd_weight_layout_size(0, u.cout, u.cin),), **f32)
+                u.wt_d = torch.empty((lib.gsd_weight_layout_size(1, u.cout, u.cin),), **f32) if u.need_dgrad else None
+            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            max_part = max(max_part, rows * 2 * _r64(u.cout))
+            if train:
+                max_part = max(max_part, lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw) * 3 * u.cout)
+                max_ws = max(max_ws, lib.gsd_conv3x3_wgrad_workspace(n, lh, lw, u.cin, u.cout))
+        for up in self.ups:
+            li = up.level_in
+            if up.out is None:
+                up.out = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
+            if train and up.dout is None:
+                up.dout = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
+            if up.wt_f is None or up.wt_f.device != dev:
+                up.wt_f = torch.empty((lib.gsd_weight_layout_size(2, up.cout, up.cin),), **f32)
+                up.wt_d = torch.empty((lib.gsd_weight_layout_size(3, up.cout, up.cin),), **f32)
+            if train:
+                max_ws = max(max_ws, lib.gsd_convT2x2_wgrad_workspace(n, hs[li], ws[li], up.cin, up.cout))
+        self.pooled = [None] + [torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32) for l in range(1, self.L + 1)]
+        self.dpooled = [None] + ([torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32)
+                                 for l in range(1, self.L + 1)] if train else [None] * self.L)
+        self.partials = torch.empty((max_part,), **f32)
+        self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _act_src(u: _Unit) -> L.gsd_src:
+        return L.make_src(u.raw, u.scale, u.shift, relu=True)
+
+    def _run_unit(self, u: _Unit, srcs: List[L.gsd_src], P: Dict[str, torch.Tensor], train: bool, st: int) -> None:
+        n = u.raw.shape[0]
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        check(lib.gsd_weight_layout(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
+        arr = L.src_array(srcs)
+        u.srcs = arr
+        dst = L.dst_array([L.make_dst(u.raw)])
+        part = self.partials.data_ptr() if train else None
+        check(lib.gsd_conv3x3(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
+        if train:
+            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
+                  "bn_reduce_partials")
+            count = float(n * lh * lw)
+            if self.sync_fn is not None:
+                self.sync_fn(u.sums[:2 * u.cout])
+                count *= self.world
+            check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
+                                      BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
+                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_finalize")
+            P[u.nbtname].add_(1)   # int64 counter buffer (BatchNorm2d.num_batches_tracked)
+        else:
+            check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
+                                         P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_eval_coeffs")
+
+    def _pad_off(self, lvl: int) -> Tuple[int, int]:
+        # F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet.py:43-47)
+        dy = self.hs[lvl] - 2 * self.hs[lvl + 1]
+        dx = self.ws[lvl] - 2 * self.ws[lvl + 1]
+        return dy // 2, dx // 2
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], train: bool, out: Optional[torch.Tensor] = None
+                ) -> torch.Tensor:
+        """P: name -> tensor for every state_dict entry (reference names). Returns (N, n_classes, H, W)."""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise L.GsdError("UNetEngine.forward needs a float32 tensor on the GPU (no CPU fallback)")
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        assert c == self.n_channels, f"expected {self.n_channels} input channels, got {c}"
+        self._ensure(n, h, w, x.device, train)
+        st = L.stream_ptr()
+        self._x = x
+        self._saved_train = train
+        for lvl in range(self.L + 1):
+            u0, u1 = self.enc[lvl]
+            if lvl == 0:
+                srcs = [L.make_src(x)]
+            else:
+                prev = self.enc[lvl - 1][1]
+                s = self._act_src(prev)
+                check(lib.gsd_maxpool2(C.byref(s), self.pooled[lvl].data_ptr(), n, prev.cout, self.hs[lvl - 1],
+                                       self.ws[lvl - 1], st), "maxpool2")
+                srcs = [L.make_src(self.pooled[lvl])]
+            self._run_unit(u0, srcs, P, train, st)
+            self._run_unit(u1, [self._act_src(u0)], P, train, st)
+        cur = self.enc[self.L][1]
+        for j in range(self.L):
+            up = self.ups[j]
+            lvl = self.L - 1 - j
+            check(lib.gsd_weight_layout(2, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_layout")
+            s = self._act_src(cur)
+            d = L.make_dst(up.out)
+            check(lib.gsd_convT2x2(C.byref(s), up.wt_f.data_ptr(), P[up.bname].data_ptr(), up.cin, up.cout, C.byref(d), n,
+                                   self.hs[lvl + 1], self.ws[lvl + 1], st), "convT2x2")
+            skip = self.enc[lvl][1]
+            u0, u1 = self.dec[j]
+            self._run_unit(u0, [self._act_src(skip), L.make_src(up.out, off=self._pad_off(lvl))], P, train, st)
+            self._run_unit(u1, [self._act_src(u0)], P, train, st)
+            cur = u1
+        if out is None:
+            out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
+        s = self._act_src(cur)
+        check(lib.gsd_conv1x1_out(C.byref(s), P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(), cur.cout,
+                                  self.n_classes, out.data_ptr(), n, h, w, st), "conv1x1_out")
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd_tail(self, u: _Unit, P, G, st: int, dwout: Optional[torch.Tensor] = None) -> None:
+        """u.g holds dz and self.partials its per-block sums: finish BN backward, then dW."""
+        n = u.raw.shape[0]
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        rows = lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw)
+        check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
+              "bn_bwd_reduce_partials")
+        count = float(n * lh * lw)
+        gsum = None
+        if self.sync_fn is not None:
+            gsum = u.sums[:2 * u.cout].clone()
+            self.sync_fn(gsum)
+            count *= self.world
+        check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), L.ptr(gsum), u.cout, count, G[u.gname].data_ptr(),
+                                      G[u.bname].data_ptr(), None if dwout is None else dwout.data_ptr(),
+                                      u.c1.data_ptr(), u.c2.data_ptr(), st),
+              "bn_bwd_finalize")
+        check(lib.gsd_bn_bwd_apply(u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
+                                   u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), n, u.cout, lh, lw, st),
+              "bn_bwd_apply")
+        dy = L.make_src(u.g)
+        check(lib.gsd_conv3x3_wgrad(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, G[u.wname].data_ptr(),
+                                    self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, lh, lw, st), "conv3x3_wgrad")
+
+    def _reduce(self, mode: int, u: _Unit, st: int, dpool: Optional[torch.Tensor] = None,
+                dout: Optional[torch.Tensor] = None, wout: Optional[torch.Tensor] = None) -> None:
+        n = u.raw.shape[0]
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        da = L.make_src(u.g)
+        check(lib.gsd_bn_bwd_reduce(mode, u.raw.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(),
+                                    u.invstd.data_ptr(), C.byref(da), L.ptr(dpool), L.ptr(dout), L.ptr(wout),
+                                    self.n_classes, u.g.data_ptr(), self.partials.data_ptr(), n, u.cout, lh, lw, st),
+              "bn_bwd_reduce")
+
+    def _dgrad(self, u: _Unit, P, dsts: List[L.gsd_dst], st: int) -> None:
+        n = u.raw.shape[0]
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        check(lib.gsd_weight_layout(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        s = L.src_array([L.make_src(u.g)])
+        check(lib.gsd_conv3x3(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
+              "conv3x3 dgrad")
+
+    def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
+        """dout: (N, n_classes, H, W) gradient of the loss w.r.t. the output.
+        G: name -> tensor to receive every parameter's gradient (overwritten, not accumulated)."""
+        if not self._saved_train:
+            raise L.GsdError("backward() needs a preceding train-mode forward()")
+        dout = dout.contiguous()
+        st = L.stream_ptr()
+        n = dout.shape[0]
+        last = self.dec[-1][1] if self.L > 0 else self.enc[0][1]
+        self._reduce(2, last, st, dout=dout, wout=P["outc.conv.weight"])
+        check(lib.gsd_sum_planes(dout.data_ptr(), n, self.n_classes, dout.shape[2] * dout.shape[3],
+                                 G["outc.conv.bias"].data_ptr(), self.wgrad_ws.data_ptr(), st), "sum_planes")
+        dwout = G["outc.conv.weight"]
+        for j in reversed(range(self.L)):
+            u0, u1 = self.dec[j]
+            up = self.ups[j]
+            lvl = self.L - 1 - j
+            self._bn_bwd_tail(u1, P, G, st, dwout)
+            dwout = None
+            self._dgrad(u1, P, [L.make_dst(u0.g)], st)
+            self._reduce(0, u0, st)
+            self._bn_bwd_tail(u0, P, G, st)
+            skip = self.enc[lvl][1]
+            self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st)
+            prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
+            hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
+            xs = self._act_src(prev)
+            dys = L.make_src(up.dout)
+            check(lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
+                                         G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, hi, wi,
+                                         st), "convT2x2_wgrad")
+            check(lib.gsd_weight_layout(3, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
+            d = L.make_dst(prev.g)
+            check(lib.gsd_convT2x2_dgrad(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
+                  "convT2x2_dgrad")
+            self._reduce(0, prev, st)
+        for lvl in reversed(range(self.L + 1)):
+            u0, u1 = self.enc[lvl]
+            if lvl < self.L:
+                self._reduce(1, u1, st, dpool=self.dpooled[lvl + 1])
+            self._bn_bwd_tail(u1, P, G, st, dwout)
+            dwout = None
+            self._dgrad(u1, P, [L.make_dst(u0.g)], st)
+            self._reduce(0, u0, st)
+            self._bn_bwd_tail(u0, P, G, st)
+            if self.block_done_cb is not None:
+                self.block_done_cb(f"enc{lvl}")
+            if lvl > 0:
+                self._dgrad(u0, P, [L.make_dst(self.dpooled[lvl])], st)

@@ -1,0 +1,211 @@
+"""The reference's train-step body as one fused schedule of libgsd kernels.
+
+Reference (paths under /root/reference/):
+    optimizer.zero_grad(); output = unet(x=input_image)            train_utils/train_unet.py:346-347
+    pred_loss = MSE_loss(input=output, target=output_target)       :370  (def :51-52)
+    loss.backward(); optimizer.step(); ema.update()                :374-376
+    Adam(lr=1e-3, weight_decay=1e-6) :306, ExponentialMovingAverage(decay=0.995) :309
+
+Here: forward -> loss+grad kernel -> backward -> (RCCL all-reduce of the flat gradient arena, bucketed and
+overlapped with the rest of backward) -> one fused Adam+EMA kernel over the flat parameter arena.
+No autograd graph, no per-tensor optimiser launches, no host sync inside the step (the loss stays on the
+device; call .item() when you want it).
+
+Divergence from the reference, on purpose: its NaN guard (train_unet.py:371-372) replaces the loss by a
+constant without grad_fn, after which loss.backward() raises; it also costs a host sync per step.  The
+fused step does not test for NaN; `last_loss` can be inspected by the caller.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+from .models.unet import UNet
+
+LOSS_KINDS = {"mse": 0, "l1": 1}
+
+
+def loss_fwd_bwd(kind: str, out: torch.Tensor, target: torch.Tensor, grad: Optional[torch.Tensor],
+                 loss_buf: torch.Tensor, ws: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """loss_buf[0] = mean((o-t)^2) | mean(|o-t|); grad = d loss / d out * grad_scale (train_unet.py:51-52)."""
+    assert out.shape == target.shape and out.is_contiguous() and target.is_contiguous()
+    check(lib.gsd_loss_fwd_bwd(LOSS_KINDS[kind], out.data_ptr(), target.data_ptr(), out.numel(), grad_scale,
+                               loss_buf.data_ptr(), L.ptr(grad), ws.data_ptr(), L.stream_ptr()), "loss_fwd_bwd")
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, target, kind):
+        out_c, tgt_c = out.contiguous(), target.contiguous().float()
+        loss = torch.empty((1,), device=out.device, dtype=torch.float32)
+        grad = torch.empty_like(out_c)
+        ws = torch.empty((2048,), device=out.device, dtype=torch.float64)
+        loss_fwd_bwd(kind, out_c, tgt_c, grad, loss, ws)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def mse_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Drop-in for the reference's MSE_loss(input, target) (train_unet.py:51-52), libgsd kernel."""
+    return _LossFn.apply(input, target, "mse")
+
+
+def l1_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    return _LossFn.apply(input, target, "l1")
+
+
+class TrainStep:
+    """Fused fwd + loss + bwd + Adam + EMA step for a gelslim_depth_amd UNet.
+
+    Parameters live in one flat fp32 arena (the module's parameters become views of it, so state_dict(),
+    load_state_dict() and the reference's checkpoint layout keep working); gradients, Adam moments and the EMA
+    shadow are arenas of the same size.  With `process_group` set, gradients are summed across ranks with
+    RCCL all-reduce (torch.distributed backend "nccl") in per-block buckets launched as soon as a block's
+    backward is done, and scaled by 1/world inside the Adam kernel.
+    """
+
+    def __init__(self, model: UNet, lr: float = 1e-3, weight_decay: float = 1e-6, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, ema_decay: Optional[float] = 0.995, loss: str = "mse",
+                 process_group=None, sync_bn: bool = False, overlap_allreduce: bool = True):
+        self.model = model
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.ema_decay = ema_decay
+        self.loss_kind = loss
+        self.step_count = 0
+        self.ema_updates = 0
+        self.pg = process_group
+        self.world = 1
+        self.overlap = overlap_allreduce
+        if process_group is not None:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world = dist.get_world_size(process_group)
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise L.GsdError("TrainStep needs the model on the GPU")
+        names = [n for n, _ in model.named_parameters()]
+        sizes = [p.numel() for _, p in model.named_parameters()]
+        total = sum(sizes)
+        self.numel = total
+        self.p_flat = torch.empty((total,), device=dev, dtype=torch.float32)
+        self.g_flat = torch.zeros((total,), device=dev, dtype=torch.float32)
+        self.m_flat = torch.zeros((total,), device=dev, dtype=torch.float32)
+        self.v_flat = torch.zeros((total,), device=dev, dtype=torch.float32)
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        gviews: Dict[str, torch.Tensor] = {}
+        for (n, p), sz in zip(model.named_parameters(), sizes):
+            self.p_flat[off:off + sz].copy_(p.data.reshape(-1))
+            p.data = self.p_flat[off:off + sz].view(p.shape)
+            gviews[n] = self.g_flat[off:off + sz].view(p.shape)
+            self.offsets[n] = (off, sz)
+            off += sz
+        model._grad_views = gviews
+        self.ema_flat = self.p_flat.clone() if ema_decay is not None else None
+        self.loss_buf = torch.zeros((1,), device=dev, dtype=torch.float32)
+        self.loss_ws = torch.empty((2048,), device=dev, dtype=torch.float64)
+        self._dout = None
+        self._out = None
+        eng = model._engine
+        eng.world = self.world
+        if sync_bn and self.world > 1:
+            eng.sync_fn = lambda t: self.dist.all_reduce(t, group=self.pg)
+        if self.world > 1:
+            # rank 0's parameters and buffers are the truth (what DDP does at construction)
+            self.dist.broadcast(self.p_flat, src=0, group=self.pg)
+            for _, b in model.named_buffers():
+                self.dist.broadcast(b, src=0, group=self.pg)
+            if self.ema_flat is not None:
+                self.ema_flat.copy_(self.p_flat)
+        self._buckets = self._make_buckets(names)
+        self._works: List = []
+
+    # buckets: contiguous arena ranges in the order backward completes them (end of the arena first)
+    def _make_buckets(self, names: List[str]) -> List[Tuple[str, int, int]]:
+        blocks: List[Tuple[str, int, int]] = []
+
+        def rng(prefix_list):
+            sel = [self.offsets[n] for n in names if any(n.startswith(p) for p in prefix_list)]
+            lo = min(o for o, _ in sel)
+            hi = max(o + s for o, s in sel)
+            return lo, hi
+        Lv = self.model._engine.L
+        for j in reversed(range(Lv)):
+            pref = [f"up.{j}."] + (["outc."] if j == Lv - 1 else [])
+            lo, hi = rng(pref)
+            blocks.append((f"dec{j}", lo, hi))
+        for lvl in reversed(range(Lv + 1)):
+            pref = ["inc."] if lvl == 0 else [f"down.{lvl - 1}."]
+            if Lv == 0:
+                pref.append("outc.")
+            lo, hi = rng(pref)
+            blocks.append((f"enc{lvl}", lo, hi))
+        return blocks
+
+    def _on_block_done(self, tag: str) -> None:
+        if self.world == 1 or not self.overlap:
+            return
+        for name, lo, hi in self._buckets:
+            if name == tag:
+                self._works.append(self.dist.all_reduce(self.g_flat[lo:hi], group=self.pg, async_op=True))
+
+    def __call__(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        model = self.model
+        eng = model._engine
+        x = x.contiguous()
+        target = target.contiguous()
+        P = model._tensor_map()
+        if self._out is None or self._out.shape != (x.shape[0], model.n_classes, x.shape[2], x.shape[3]):
+            self._out = torch.empty((x.shape[0], model.n_classes, x.shape[2], x.shape[3]), device=x.device,
+                                    dtype=torch.float32)
+            self._dout = torch.empty_like(self._out)
+        out = eng.forward(x, P, train=True, out=self._out)
+        loss_fwd_bwd(self.loss_kind, out, target, self._dout, self.loss_buf, self.loss_ws)
+        eng.block_done_cb = self._on_block_done
+        eng.backward(self._dout, P, model._grad_views)
+        eng.block_done_cb = None
+        if self.world > 1:
+            if self.overlap:
+                for w in self._works:
+                    w.wait()
+                self._works = []
+            else:
+                self.dist.all_reduce(self.g_flat, group=self.pg)
+        self.step_count += 1
+        d = 0.0
+        if self.ema_flat is not None:
+            # torch_ema 0.3 (requirements.txt:6): decay = min(decay, (1+n)/(10+n)), n counted after increment
+            self.ema_updates += 1
+            d = min(self.ema_decay, (1.0 + self.ema_updates) / (10.0 + self.ema_updates))
+        check(lib.gsd_adam_ema(self.p_flat.data_ptr(), self.g_flat.data_ptr(), self.m_flat.data_ptr(),
+                               self.v_flat.data_ptr(), L.ptr(self.ema_flat), self.numel, self.step_count, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.wd, d, 1.0 / self.world, L.stream_ptr()),
+              "adam_ema")
+        return self.loss_buf
+
+    @property
+    def last_loss(self) -> torch.Tensor:
+        return self.loss_buf
+
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        """state_dict with the EMA shadow in place of the parameters -- what the reference saves at best-val
+        under `with ema.average_parameters()` (train_unet.py:480-483); BN buffers are the live ones."""
+        sd = self.model.state_dict()
+        if self.ema_flat is None:
+            return sd
+        out = {}
+        for k, v in sd.items():
+            if k in self.offsets:
+                o, s = self.offsets[k]
+                out[k] = self.ema_flat[o:o + s].view(v.shape).clone()
+            else:
+                out[k] = v.clone()
+        return out

@@ -1,0 +1,185 @@
+/*
+ * gsd.h -- C ABI of libgsd.so: MI355X (gfx950) kernels for the gelslim_depth U-Net train step.
+ *
+ * The reference (MMintLab/gelslim_depth) is pure Python and has NO FFI of its own: every device
+ * operation of its hot path is a torch (ATen) operator call.  Each entry point below therefore
+ * cites the reference call site whose ATen operator(s) it replaces (paths relative to
+ * /root/reference/).  A maintainer binds this library with ctypes; the
+ * shipped binding is gelslim_depth_amd/_lib.py.
+ *
+ * Conventions
+ *   - all tensors fp32, NCHW, allocated by the caller (PyTorch caching allocator); the library
+ *     never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void*; kernels are launched on it and nothing
+ *     synchronises (safe for hipGraph capture and for the autograd thread);
+ *   - return 0 on success, a negative gsd_status otherwise; gsd_last_error() returns a
+ *     thread-local message; no exceptions, no exit();
+ *   - no global mutable state: every call is re-entrant.
+ *
+ * "Deferred BatchNorm": a convolution never materialises relu(bn(raw)).  It writes the raw
+ * convolution output plus per-block partial sums; gsd_bn_finalize turns the partials into a
+ * per-channel (scale, shift); every consumer applies  max(0, raw*scale+shift)  while it loads
+ * the tensor (gsd_src.scale/shift/relu).  F.pad + torch.cat (unet.py:46-48) are likewise never
+ * materialised: a consumer takes up to two channel segments, each with its own extent/offset,
+ * and reads zeros outside a segment's extent.
+ */
+#ifndef GSD_H
+#define GSD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GSD_OK = 0,
+  GSD_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, inconsistent shapes          */
+  GSD_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels tile (message says which)      */
+  GSD_ERR_HIP = -3,           /* a HIP runtime call failed (message carries hipGetErrorString) */
+  GSD_ERR_WORKSPACE = -4      /* caller-provided workspace too small                           */
+} gsd_status;
+
+/* One channel segment of an input operand as a consumer sees it. */
+typedef struct {
+  const float* ptr;     /* element (n=0, c=0, h=0, w=0) of the stored tensor                    */
+  const float* scale;   /* per-channel affine applied on load, or NULL for identity             */
+  const float* shift;
+  int32_t C;            /* channels in this segment                                             */
+  int32_t H, W;         /* stored extent; row stride is W                                       */
+  int32_t off_h, off_w; /* where stored (0,0) sits in the consumer's grid (F.pad top/left)      */
+  int32_t relu;         /* max(0, .) after the affine                                           */
+  int64_t n_stride;     /* elements between images                                              */
+  int64_t c_stride;     /* elements between channels                                            */
+} gsd_src;
+
+/* One channel segment of an output operand. Positions outside (H, W) after subtracting the
+ * offset are dropped (this is the backward of F.pad: a crop). */
+typedef struct {
+  float* ptr;
+  int32_t C;
+  int32_t H, W;
+  int32_t off_h, off_w;
+  int64_t n_stride;
+  int64_t c_stride;
+} gsd_dst;
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* gsd_version(void);
+const char* gsd_last_error(void);
+/* MFMA fragment-layout self test (v_mfma_f32_16x16x4_f32 A/B/D lane maps used by every conv
+ * kernel); writes 16x16 D = A*B for asymmetric integer A (16x4), B (4x16) to `out`. */
+int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
+
+/* ---- weight re-layouts (cheap, once per optimiser step) ----------------------------------- */
+/* mode 0: conv3x3 forward   W[Co][Ci][3][3]      -> Wt[(ci*9+t)][Mpad]       (k-major, co contiguous)
+ * mode 1: conv3x3 dgrad     W[Co][Ci][3][3]      -> Wt[(co*9+t)][Mpad]  with tap flipped, m = ci
+ * mode 2: convT   forward   W[Ci][Co][2][2]      -> Wt[ci][Mpad]            m = co*4+kh*2+kw
+ * mode 3: convT   dgrad     W[Ci][Co][2][2]      -> Wt[(co*4+kh*2+kw)][Mpad]  m = ci
+ * Rows are padded with zeros to a multiple of 4 channels (mode 0/1: 4*9 rows), Mpad is M rounded
+ * up to 64.  gsd_weight_layout_size returns rows*Mpad (elements). */
+int64_t gsd_weight_layout_size(int mode, int Co, int Ci);
+int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream);
+
+/* ---- convolution family (implicit GEMM on v_mfma_f32_16x16x4_f32) -------------------------- */
+/* conv3x3, stride 1, pad 1, no bias.  Replaces aten::convolution at unet.py:11,14 (forward,
+ * weights from mode 0) and the dX half of aten::convolution_backward (weights from mode 1,
+ * src = gradient w.r.t. the raw output).  `partials` (optional) receives per-block
+ * (sum, sum of squares) of the raw output per output channel for BatchNorm:
+ * layout [n_partial_rows][2*Mpad]; gsd_conv3x3_partial_rows gives n_partial_rows. */
+int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout);
+int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout,
+                const gsd_dst* dst, int ndst, float* partials, int N, int H, int W, void* stream);
+
+/* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
+ * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 2. */
+int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin, int Cout,
+                 const gsd_dst* dst, int N, int H, int W, void* stream);
+/* dX of the above: src = gradient w.r.t. the (2h,2w) output (plain), dst (h,w). weights: mode 3. */
+int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout,
+                       const gsd_dst* dst, int N, int H, int W, void* stream);
+
+/* dW of conv3x3: dW[co][ci][kh][kw] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1].
+ * `a` is given as up to two segments with deferred BN (recomputed on load), `dy` plain.
+ * Deterministic split-K: partial slabs in `workspace` (gsd_conv3x3_wgrad_workspace elements),
+ * then an ordered reduction writes dW in the reference's (Co,Ci,3,3) layout. */
+int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout,
+                      float* dw, float* workspace, int64_t workspace_elems,
+                      int N, int H, int W, void* stream);
+/* dW and db of ConvTranspose2d(k2,s2): x (h,w) with deferred BN, dy (2h,2w) plain;
+ * dW in the reference's (Ci,Co,2,2) layout. */
+int64_t gsd_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, int Cout,
+                       float* dw, float* dbias, float* workspace, int64_t workspace_elems,
+                       int N, int H, int W, void* stream);
+
+/* ---- BatchNorm2d (unet.py:12,15; aten::native_batch_norm / _backward) ---------------------- */
+/* Reduce conv partials -> sums[0..2*C) (fp64: sum, sum of squares), two ordered stages. Separate from
+ * finalize so a data-parallel run can all-reduce sums[0..2C) (SyncBN) in between.
+ * `sums` must hold 65*2*C doubles: the result followed by 64*2*C doubles of stage-1 scratch. */
+int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad, int C, double* sums, void* stream);
+/* sums -> mean, invstd, (scale, shift) = (gamma*invstd, beta - mean*scale); updates running stats
+ * (momentum 0.1, unbiased variance) when running_mean != NULL. count = N*H*W (global if synced). */
+int gsd_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: (scale, shift) from running stats. */
+int gsd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+
+/* Backward of relu(bn(raw)), pass 1.  dz = da * [raw*scale+shift > 0]; writes dz and per-block
+ * partials of (sum dz, sum dz*xhat) [+ sum dout*a for mode OUTC].
+ *   mode 0 PLAIN: da given by `da` (gsd_src, plain).
+ *   mode 1 POOL : da = da (may be NULL ptr => 0) + max-pool routed `dpool` (N,C,H/2,W/2):
+ *                 the 2x2 arg-max is recomputed from raw (first maximum wins, like aten).
+ *   mode 2 OUTC : da[c] = dout*wout[c]   (1x1 output conv unet.py:54 with n_classes K == 1), extra
+ *                 partial dWout[c] = sum dout*a[c]  (a = relu(bn(raw))).
+ * partial layout: [rows][3*C] (third block only meaningful in mode 2), rows from
+ * gsd_bn_bwd_partial_rows. */
+int gsd_bn_bwd_partial_rows(int N, int C, int H, int W);
+int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale, const float* shift,
+                      const float* mean, const float* invstd,
+                      const gsd_src* da, const float* dpool, const float* dout, const float* wout,
+                      int K, float* dz, float* partials, int N, int C, int H, int W, void* stream);
+/* pass 2: reduce partials -> sums[0..3*C) (fp64; exposed for the SyncBN all-reduce), then
+ * dgamma, dbeta (+ dWout), and the coefficient vectors c1 = sum_dz/n, c2 = sum_dz_xhat/n.
+ * `sums` must hold 65*3*C doubles (result + stage-1 scratch). dwout may be NULL.
+ * finalize: dgamma/dbeta/dwout come from sums_local (this rank's batch: data-parallel averaging of
+ * parameter gradients happens later), c1/c2 from sums_global/count (sums_global == NULL: local). */
+int gsd_bn_bwd_reduce_partials(const float* partials, int rows, int C, double* sums, void* stream);
+int gsd_bn_bwd_finalize(const double* sums_local, const double* sums_global, int C, double count,
+                        float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream);
+/* pass 3: d_raw = scale_g * (dz - c1 - xhat*c2), in place on dz; scale_g = gamma*invstd = scale. */
+int gsd_bn_bwd_apply(float* dz, const float* raw, const float* scale, const float* mean,
+                     const float* invstd, const float* c1, const float* c2,
+                     int N, int C, int H, int W, void* stream);
+/* out[k] = sum over n, p of x[n][k][p] (contiguous [N][K][HW]); deterministic two-stage.
+ * workspace >= 64*K floats. Used for dbias of the output conv / transposed conv. */
+int gsd_sum_planes(const float* x, int N, int K, int64_t HW, float* out, float* workspace, void* stream);
+
+/* ---- MaxPool2d(2) floor mode (unet.py:26; aten::max_pool2d_with_indices) -------------------- */
+/* y = maxpool(max(0, raw*scale+shift)) materialised at (H/2, W/2). No index tensor is kept. */
+int gsd_maxpool2(const gsd_src* src, float* y, int N, int C, int H, int W, void* stream);
+
+/* ---- output conv + loss (unet.py:54; train_unet.py:51-52) ----------------------------------- */
+/* out[n,k,p] = b[k] + sum_c w[k][c] * max(0, raw[c]*scale[c]+shift[c]). */
+int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* b, int C, int K,
+                    float* out, int N, int H, int W, void* stream);
+/* loss = mean((o-t)^2) (kind 0) or mean(|o-t|) (kind 1); grad = d loss/d o * grad_scale.
+ * loss_out: 1 float (device). workspace >= 2048 floats. grad may be NULL. */
+int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_t numel, float grad_scale,
+                     float* loss_out, float* grad, float* workspace, void* stream);
+
+/* ---- optimiser (train_unet.py:306,375-376) -------------------------------------------------- */
+/* Fused torch.optim.Adam(lr, betas, eps, weight_decay: coupled L2) + torch_ema update over a flat
+ * parameter arena. step is the 1-based Adam step; ema may be NULL; ema_decay already resolved
+ * (min(decay,(1+n)/(10+n))). grad_scale multiplies g first (1/world_size after all-reduce). */
+int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel,
+                 int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float ema_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSD_H */

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads here (no GPU) and exports every symbol include/gsd.h declares; the ctypes
+binding lists exactly those symbols.  No compute call is made."""
+import ctypes
+import os
+import re
+
+from conftest import REPO
+
+
+def header_functions():
+    src = open(os.path.join(REPO, "include", "gsd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsd_[a-z0-9_A-Z]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from gelslim_depth_amd import _lib
+    names = header_functions()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in gsd.h but not exported by libgsd.so"
+    assert sorted(_lib.SIGNATURES.keys()) == names
+    assert "gfx950" in _lib.version()
+
+
+def test_struct_layout_matches_header():
+    from gelslim_depth_amd import _lib
+    # gsd_src: 3 pointers, 6 int32, 2 int64 ; gsd_dst: 1 pointer, 5 int32 (+pad), 2 int64
+    assert ctypes.sizeof(_lib.gsd_src) == 3 * 8 + 6 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.gsd_dst) == 8 + 5 * 4 + 4 + 2 * 8
+    assert _lib.gsd_src.n_stride.offset == 48 and _lib.gsd_dst.n_stride.offset == 32
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "gelslim_depth_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_module_refuses_cpu_tensors():
+    import pytest
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    m = UNet(3, 1, layer_dimensions=[4, 8])
+    with pytest.raises(RuntimeError):
+        m(x=torch.zeros(1, 3, 8, 8))
+    with pytest.raises(NotImplementedError):
+        UNet(3, 1, kernel_size=5)
+    with pytest.raises(ValueError):
+        UNet(3, 1, layer_dimensions=[4, 12])

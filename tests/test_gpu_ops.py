@@ -1,0 +1,346 @@
+"""GPU parity, op level: every libgsd entry point against the oracle (oracle/unet_numpy.py) on seeded
+inputs with odd shapes.  All calls go through the C ABI (gelslim_depth_amd._lib).
+
+Tolerances: fp32 MFMA accumulates products in k order, the oracle uses BLAS / fp64; the bound for a
+K-term dot product is ~K*eps relative to sum|a*b|, far below the 1e-3 relative-L1 north-star tolerance.
+TOL = 2e-5 relative L1 everywhere an op is compared on identical inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l1
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def gsd():
+    from gelslim_depth_amd import _lib
+    return _lib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def layout(gsd, mode, w, co, ci):
+    wt = torch.zeros(gsd.lib.gsd_weight_layout_size(mode, co, ci), device="cuda")
+    gsd.check(gsd.lib.gsd_weight_layout(mode, w.data_ptr(), co, ci, wt.data_ptr(), gsd.stream_ptr()))
+    return wt
+
+
+def test_mfma_lane_maps(gsd):
+    rng = np.random.default_rng(0)
+    a = rng.integers(-8, 9, (16, 4)).astype(np.float32)       # asymmetric integer operands: exact in fp32
+    b = rng.integers(-8, 9, (4, 16)).astype(np.float32)
+    out = torch.zeros(16, 16, device="cuda")
+    gsd.check(gsd.lib.gsd_selftest_mfma(dev(a).data_ptr(), dev(b).data_ptr(), out.data_ptr(), gsd.stream_ptr()))
+    assert np.array_equal(out.cpu().numpy(), a @ b)
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 3, 64, 20, 33), (2, 8, 130, 13, 17), (1, 64, 64, 40, 53),
+                                         (3, 16, 200, 5, 4)])
+def test_conv3x3_plain(gsd, n, ci, co, h, w):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(n * 1000 + ci)
+    x, wt_ = rnd(rng, n, ci, h, w), rnd(rng, co, ci, 3, 3, scale=0.2)
+    xd, wd = dev(x), dev(wt_)
+    y = torch.full((n, co, h, w), float("nan"), device="cuda")
+    rows = gsd.lib.gsd_conv3x3_partial_rows(n, h, w, co)
+    mpad = (co + 63) // 64 * 64
+    part = torch.zeros(rows * 2 * mpad, device="cuda")
+    src = gsd.src_array([gsd.make_src(xd)])
+    dst = gsd.dst_array([gsd.make_dst(y)])
+    gsd.check(gsd.lib.gsd_conv3x3(src, 1, layout(gsd, 0, wd, co, ci).data_ptr(), ci, co, dst, 1, part.data_ptr(), n, h, w,
+                                  gsd.stream_ptr()))
+    ref = on.conv3x3_fwd(x, wt_)
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all(), "every output element must be written"
+    assert rel_l1(got, ref) < TOL
+    # BatchNorm partial sums -> (sum, sumsq) per channel
+    sums = torch.zeros(65 * 2 * co, device="cuda", dtype=torch.float64)
+    gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, co, sums.data_ptr(), gsd.stream_ptr()))
+    s = sums[:2 * co].cpu().numpy()
+    r64 = ref.astype(np.float64)
+    np.testing.assert_allclose(s[:co], r64.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[co:], (r64 * r64).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_conv3x3_deferred_bn_two_segments_and_crop(gsd):
+    """Consumer-side fusion: relu(bn(.)) on load, channel concat of two segments, F.pad offsets (unet.py:46-48);
+    producer-side: two destinations with the crop that is F.pad's backward."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(7)
+    n, c0, c1, co, h, w = 2, 6, 5, 9, 9, 11
+    skip_raw = rnd(rng, n, c0, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, c0).astype(np.float32), rnd(rng, c0, scale=0.3)
+    up = rnd(rng, n, c1, 6, 8)          # diffY=3, diffX=3 -> top=1,left=1
+    wt_ = rnd(rng, co, c0 + c1, 3, 3, scale=0.2)
+    a0 = np.maximum(skip_raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    upp, (top, left) = on.pad_to(up, h, w)
+    assert (top, left) == (1, 1)
+    ref = on.conv3x3_fwd(np.concatenate([a0, upp], 1), wt_)
+    srd, upd = dev(skip_raw), dev(up)
+    scd, shd = dev(sc), dev(sh)
+    y = torch.zeros((n, co, h, w), device="cuda")
+    src = gsd.src_array([gsd.make_src(srd, scd, shd, relu=True), gsd.make_src(upd, off=(top, left))])
+    gsd.check(gsd.lib.gsd_conv3x3(src, 2, layout(gsd, 0, dev(wt_), co, c0 + c1).data_ptr(), c0 + c1, co,
+                                  gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
+    assert rel_l1(y.cpu().numpy(), ref) < TOL
+    # dgrad with split destinations: dX of the same conv, routed to (skip grad | cropped up grad)
+    dy = rnd(rng, n, co, h, w)
+    dxr, _ = on.conv3x3_bwd(np.concatenate([a0, upp], 1), wt_, dy)
+    g_skip = torch.zeros((n, c0, h, w), device="cuda")
+    g_up = torch.full((n, c1, 6, 8), float("nan"), device="cuda")
+    dyd = dev(dy)
+    gsd.check(gsd.lib.gsd_conv3x3(gsd.src_array([gsd.make_src(dyd)]), 1, layout(gsd, 1, dev(wt_), co, c0 + c1).data_ptr(),
+                                  co, c0 + c1, gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))]), 2,
+                                  None, n, h, w, gsd.stream_ptr()))
+    assert rel_l1(g_skip.cpu().numpy(), dxr[:, :c0]) < TOL
+    assert rel_l1(g_up.cpu().numpy(), dxr[:, c0:, top:top + 6, left:left + 8]) < TOL
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 64, 64, 21, 29), (2, 20, 130, 6, 70), (1, 3, 16, 40, 53)])
+def test_conv3x3_wgrad(gsd, n, ci, co, h, w):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(ci * 31 + co)
+    raw = rnd(rng, n, ci, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, ci).astype(np.float32), rnd(rng, ci, scale=0.3)
+    a = np.maximum(raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    dy = rnd(rng, n, co, h, w)
+    wdummy = np.zeros((co, ci, 3, 3), np.float32)
+    _, dwr = on.conv3x3_bwd(a, wdummy, dy, need_dx=False)
+    rawd, scd, shd, dyd = dev(raw), dev(sc), dev(sh), dev(dy)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+    need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    a_src = gsd.src_array([gsd.make_src(rawd, scd, shd, relu=True)])
+    dy_src = gsd.make_src(dyd)
+    gsd.check(gsd.lib.gsd_conv3x3_wgrad(a_src, 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need, n, h, w,
+                                        gsd.stream_ptr()))
+    assert rel_l1(dw.cpu().numpy(), dwr) < 5e-5
+    # too-small workspace is refused, not overrun
+    rc = gsd.lib.gsd_conv3x3_wgrad(a_src, 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need - 1, n, h, w,
+                                   gsd.stream_ptr())
+    assert rc == -4 and b"workspace" in gsd.lib.gsd_last_error()
+
+
+@pytest.mark.parametrize("n,ci,h,w", [(2, 8, 4, 5), (1, 128, 20, 26), (2, 36, 7, 9)])
+def test_convT_fwd_bwd(gsd, n, ci, h, w):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(ci)
+    co = ci // 2
+    raw = rnd(rng, n, ci, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, ci).astype(np.float32), rnd(rng, ci, scale=0.3)
+    x = np.maximum(raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    wt_, b = rnd(rng, ci, co, 2, 2, scale=0.2), rnd(rng, co)
+    ref = on.convT_fwd(x, wt_, b)
+    rawd, scd, shd, wd, bd = dev(raw), dev(sc), dev(sh), dev(wt_), dev(b)
+    y = torch.full((n, co, 2 * h, 2 * w), float("nan"), device="cuda")
+    s = gsd.make_src(rawd, scd, shd, relu=True)
+    d = gsd.make_dst(y)
+    gsd.check(gsd.lib.gsd_convT2x2(C.byref(s), layout(gsd, 2, wd, co, ci).data_ptr(), bd.data_ptr(), ci, co, C.byref(d), n, h,
+                                   w, gsd.stream_ptr()))
+    assert rel_l1(y.cpu().numpy(), ref) < TOL
+    dy = rnd(rng, n, co, 2 * h, 2 * w)
+    dxr, dwr, dbr = on.convT_bwd(x, wt_, dy)
+    dyd = dev(dy)
+    dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
+    sdy = gsd.make_src(dyd)
+    ddx = gsd.make_dst(dx)
+    gsd.check(gsd.lib.gsd_convT2x2_dgrad(C.byref(sdy), layout(gsd, 3, wd, co, ci).data_ptr(), ci, co, C.byref(ddx), n, h, w,
+                                         gsd.stream_ptr()))
+    assert rel_l1(dx.cpu().numpy(), dxr) < TOL
+    need = gsd.lib.gsd_convT2x2_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    dw = torch.full((ci, co, 2, 2), float("nan"), device="cuda")
+    db = torch.full((co,), float("nan"), device="cuda")
+    gsd.check(gsd.lib.gsd_convT2x2_wgrad(C.byref(s), C.byref(sdy), ci, co, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), need,
+                                         n, h, w, gsd.stream_ptr()))
+    assert rel_l1(dw.cpu().numpy(), dwr) < 5e-5
+    assert rel_l1(db.cpu().numpy(), dbr) < TOL
+
+
+def test_bn_finalize_and_eval_coeffs(gsd):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(3)
+    n, c, h, w = 3, 5, 7, 9
+    x = rnd(rng, n, c, h, w) * 2 + 1
+    g, b = rng.uniform(0.5, 1.5, c).astype(np.float32), rnd(rng, c)
+    rm, rv = rnd(rng, c, scale=0.1), rng.uniform(0.5, 1.5, c).astype(np.float32)
+    yr, (mr, ir), (nrm, nrv) = on.bn_train_fwd(x, g, b, rm, rv)
+    x64 = x.astype(np.float64)
+    sums = torch.zeros(65 * 2 * c, dtype=torch.float64, device="cuda")
+    sums[:c] = torch.from_numpy(x64.sum(axis=(0, 2, 3))).cuda()
+    sums[c:2 * c] = torch.from_numpy((x64 * x64).sum(axis=(0, 2, 3))).cuda()
+    gd, bd, rmd, rvd = dev(g), dev(b), dev(rm), dev(rv)
+    outs = [torch.zeros(c, device="cuda") for _ in range(4)]
+    gsd.check(gsd.lib.gsd_bn_finalize(sums.data_ptr(), c, float(n * h * w), gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1,
+                                      rmd.data_ptr(), rvd.data_ptr(), *[o.data_ptr() for o in outs], gsd.stream_ptr()))
+    mean, invstd, scale, shift = [o.cpu().numpy() for o in outs]
+    assert rel_l1(mean, mr) < 1e-6 and rel_l1(invstd, ir) < 1e-6
+    assert rel_l1(rmd.cpu().numpy(), nrm) < 1e-6 and rel_l1(rvd.cpu().numpy(), nrv) < 1e-6
+    y = x * scale[None, :, None, None] + shift[None, :, None, None]
+    assert rel_l1(y, yr) < 1e-6
+    sc2, sh2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    gsd.check(gsd.lib.gsd_bn_eval_coeffs(gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, c,
+                                         sc2.data_ptr(), sh2.data_ptr(), gsd.stream_ptr()))
+    ye = x * sc2.cpu().numpy()[None, :, None, None] + sh2.cpu().numpy()[None, :, None, None]
+    assert rel_l1(ye, on.bn_eval_fwd(x, g, b, nrm, nrv)) < 1e-6
+
+
+def _bn_setup(rng, n, c, h, w):
+    from oracle import unet_numpy as on
+    raw = rnd(rng, n, c, h, w) + 0.3
+    g, b = rng.uniform(0.5, 1.5, c).astype(np.float32), rnd(rng, c, scale=0.3)
+    y, (mean, invstd), _ = on.bn_train_fwd(raw, g, b, np.zeros(c, np.float32), np.ones(c, np.float32))
+    scale = (g * invstd).astype(np.float32)
+    shift = (b - mean * scale).astype(np.float32)
+    return raw, g, b, mean, invstd, scale, shift, np.maximum(y, 0)
+
+
+def _bn_bwd_run(gsd, mode, raw, scale, shift, mean, invstd, n, c, h, w, da=None, dpool=None, dout=None, wout=None):
+    rawd = dev(raw)
+    vecs = [dev(v) for v in (scale, shift, mean, invstd)]
+    g = dev(da) if da is not None else torch.zeros((n, c, h, w), device="cuda")
+    rows = gsd.lib.gsd_bn_bwd_partial_rows(n, c, h, w)
+    part = torch.zeros(rows * 3 * c, device="cuda")
+    das = gsd.make_src(g)
+    dp = dev(dpool) if dpool is not None else None
+    do = dev(dout) if dout is not None else None
+    wo = dev(wout) if wout is not None else None
+    gsd.check(gsd.lib.gsd_bn_bwd_reduce(mode, rawd.data_ptr(), *[v.data_ptr() for v in vecs], C.byref(das), gsd.ptr(dp),
+                                        gsd.ptr(do), gsd.ptr(wo), 1, g.data_ptr(), part.data_ptr(), n, c, h, w,
+                                        gsd.stream_ptr()))
+    sums = torch.zeros(65 * 3 * c, dtype=torch.float64, device="cuda")
+    gsd.check(gsd.lib.gsd_bn_bwd_reduce_partials(part.data_ptr(), rows, c, sums.data_ptr(), gsd.stream_ptr()))
+    outs = [torch.zeros(c, device="cuda") for _ in range(5)]   # dgamma dbeta dwout c1 c2
+    gsd.check(gsd.lib.gsd_bn_bwd_finalize(sums.data_ptr(), None, c, float(n * h * w), *[o.data_ptr() for o in outs],
+                                          gsd.stream_ptr()))
+    gsd.check(gsd.lib.gsd_bn_bwd_apply(g.data_ptr(), rawd.data_ptr(), vecs[0].data_ptr(), vecs[2].data_ptr(),
+                                       vecs[3].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), n, c, h, w,
+                                       gsd.stream_ptr()))
+    return g.cpu().numpy(), [o.cpu().numpy() for o in outs]
+
+
+def test_bn_relu_backward_plain(gsd):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(5)
+    n, c, h, w = 3, 5, 7, 9
+    raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, c, h, w)
+    da = rnd(rng, n, c, h, w)
+    dxr, dgr, dbr = on.bn_train_bwd(raw, g, mean, invstd, da * (a > 0))
+    dx, (dg, db, _, _, _) = _bn_bwd_run(gsd, 0, raw, scale, shift, mean, invstd, n, c, h, w, da=da)
+    assert rel_l1(dx, dxr) < TOL and rel_l1(dg, dgr) < TOL and rel_l1(db, dbr) < TOL
+
+
+def test_bn_relu_maxpool_backward(gsd):
+    """mode POOL: skip gradient + max-pool routed gradient, arg-max recomputed (first max wins), odd H/W."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(6)
+    n, c, h, w = 2, 4, 9, 11
+    raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, c, h, w)
+    a_gpu_like = np.maximum(raw * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    _, idx = on.maxpool2_fwd(a_gpu_like)
+    dpool = rnd(rng, n, c, h // 2, w // 2)
+    dskip = rnd(rng, n, c, h, w)
+    da = dskip + on.maxpool2_bwd(dpool, idx, raw.shape)
+    dxr, dgr, dbr = on.bn_train_bwd(raw, g, mean, invstd, da * (a > 0))
+    dx, (dg, db, _, _, _) = _bn_bwd_run(gsd, 1, raw, scale, shift, mean, invstd, n, c, h, w, da=dskip, dpool=dpool)
+    assert rel_l1(dx, dxr) < TOL and rel_l1(dg, dgr) < TOL and rel_l1(db, dbr) < TOL
+
+
+def test_outconv_forward_loss_and_backward(gsd):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(8)
+    n, c, h, w = 2, 6, 7, 9
+    raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, c, h, w)
+    wout, bout = rnd(rng, 1, c, 1, 1, scale=0.4), rnd(rng, 1)
+    tgt = rnd(rng, n, 1, h, w)
+    yr = on.conv1x1_fwd(a, wout, bout)
+    rawd, scd, shd = dev(raw), dev(scale), dev(shift)
+    y = torch.zeros((n, 1, h, w), device="cuda")
+    s = gsd.make_src(rawd, scd, shd, relu=True)
+    gsd.check(gsd.lib.gsd_conv1x1_out(C.byref(s), dev(wout).data_ptr(), dev(bout).data_ptr(), c, 1, y.data_ptr(), n, h, w,
+                                      gsd.stream_ptr()))
+    assert rel_l1(y.cpu().numpy(), yr) < TOL
+    for kind, fn in ((0, on.mse_loss), (1, on.l1_loss)):
+        lr, gr = fn(yr, tgt)
+        loss = torch.zeros(1, device="cuda")
+        grad = torch.zeros((n, 1, h, w), device="cuda")
+        ws = torch.zeros(2048, dtype=torch.float64, device="cuda")
+        gsd.check(gsd.lib.gsd_loss_fwd_bwd(kind, dev(yr).data_ptr(), dev(tgt).data_ptr(), yr.size, 1.0, loss.data_ptr(),
+                                           grad.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
+        assert abs(loss.item() - lr) < 1e-6 * abs(lr)
+        assert rel_l1(grad.cpu().numpy(), gr) < 1e-6
+    _, dout = on.mse_loss(yr, tgt)
+    dar, dwr, dbr = on.conv1x1_bwd(a, wout, dout)
+    dxr, dgr, dbtr = on.bn_train_bwd(raw, g, mean, invstd, dar * (a > 0))
+    dx, (dg, db, dwo, _, _) = _bn_bwd_run(gsd, 2, raw, scale, shift, mean, invstd, n, c, h, w, dout=dout,
+                                          wout=wout.reshape(1, c))
+    assert rel_l1(dx, dxr) < TOL and rel_l1(dg, dgr) < TOL and rel_l1(db, dbtr) < TOL
+    assert rel_l1(dwo, dwr.reshape(-1)) < TOL
+    out = torch.zeros(1, device="cuda")
+    ws = torch.zeros(64, device="cuda")
+    gsd.check(gsd.lib.gsd_sum_planes(dev(dout).data_ptr(), n, 1, h * w, out.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
+    assert rel_l1(out.cpu().numpy(), dbr) < TOL
+
+
+def test_maxpool_floor(gsd):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(9)
+    n, c, h, w = 2, 4, 9, 11
+    raw = rnd(rng, n, c, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, c).astype(np.float32), rnd(rng, c, scale=0.3)
+    a = np.maximum(raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    yr, _ = on.maxpool2_fwd(a)
+    rawd, scd, shd = dev(raw), dev(sc), dev(sh)
+    y = torch.zeros((n, c, h // 2, w // 2), device="cuda")
+    s = gsd.make_src(rawd, scd, shd, relu=True)
+    gsd.check(gsd.lib.gsd_maxpool2(C.byref(s), y.data_ptr(), n, c, h, w, gsd.stream_ptr()))
+    assert np.allclose(y.cpu().numpy(), yr, rtol=1e-6, atol=1e-6)
+
+
+def test_adam_ema_matches_torch_and_oracle(gsd):
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(10)
+    numel = 10007
+    p0 = rnd(rng, numel)
+    p, m, v = p0.copy(), np.zeros(numel, np.float32), np.zeros(numel, np.float32)
+    shadow = p0.copy()
+    pd, md, vd, ed = dev(p0), torch.zeros(numel, device="cuda"), torch.zeros(numel, device="cuda"), dev(p0)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, weight_decay=1e-6)
+    for step in range(1, 4):
+        g = rnd(rng, numel, scale=0.1)
+        on.adam_step(p, g, m, v, step)
+        on.ema_update(shadow, p, step)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        d = on.ema_decay(step)
+        gsd.check(gsd.lib.gsd_adam_ema(pd.data_ptr(), dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(), numel,
+                                       step, 1e-3, 0.9, 0.999, 1e-8, 1e-6, d, 1.0, gsd.stream_ptr()))
+    assert rel_l1(pd.cpu().numpy(), pt.detach().numpy()) < 1e-6
+    assert rel_l1(pd.cpu().numpy(), p) < 1e-6
+    assert rel_l1(ed.cpu().numpy(), shadow) < 1e-6
+
+
+def test_bad_arguments_are_refused(gsd):
+    x = torch.zeros((1, 4, 8, 8), device="cuda")
+    y = torch.zeros((1, 4, 8, 8), device="cuda")
+    src = gsd.src_array([gsd.make_src(x)])
+    dst = gsd.dst_array([gsd.make_dst(y)])
+    wt = torch.zeros(gsd.lib.gsd_weight_layout_size(0, 4, 4), device="cuda")
+    assert gsd.lib.gsd_conv3x3(src, 1, wt.data_ptr(), 5, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1   # Cin mismatch
+    assert gsd.lib.gsd_conv3x3(src, 1, None, 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
+    assert gsd.lib.gsd_conv3x3(src, 3, wt.data_ptr(), 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
+    with pytest.raises(gsd.GsdError):
+        gsd.check(gsd.lib.gsd_weight_layout(7, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
