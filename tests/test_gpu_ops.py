@@ -42,7 +42,8 @@ def test_mfma_lane_maps(gsd):
     a = rng.integers(-8, 9, (16, 4)).astype(np.float32)       # asymmetric integer operands: exact in fp32
     b = rng.integers(-8, 9, (4, 16)).astype(np.float32)
     out = torch.zeros(16, 16, device="cuda")
-    gsd.check(gsd.lib.gsd_selftest_mfma(dev(a).data_ptr(), dev(b).data_ptr(), out.data_ptr(), gsd.stream_ptr()))
+    ad, bd = dev(a), dev(b)      # keep the device tensors alive across the launch
+    gsd.check(gsd.lib.gsd_selftest_mfma(ad.data_ptr(), bd.data_ptr(), out.data_ptr(), gsd.stream_ptr()))
     assert np.array_equal(out.cpu().numpy(), a @ b)
 
 
@@ -269,7 +270,8 @@ def test_outconv_forward_loss_and_backward(gsd):
     rawd, scd, shd = dev(raw), dev(scale), dev(shift)
     y = torch.zeros((n, 1, h, w), device="cuda")
     s = gsd.make_src(rawd, scd, shd, relu=True)
-    gsd.check(gsd.lib.gsd_conv1x1_out(C.byref(s), dev(wout).data_ptr(), dev(bout).data_ptr(), c, 1, y.data_ptr(), n, h, w,
+    woutd, boutd = dev(wout), dev(bout)
+    gsd.check(gsd.lib.gsd_conv1x1_out(C.byref(s), woutd.data_ptr(), boutd.data_ptr(), c, 1, y.data_ptr(), n, h, w,
                                       gsd.stream_ptr()))
     assert rel_l1(y.cpu().numpy(), yr) < TOL
     for kind, fn in ((0, on.mse_loss), (1, on.l1_loss)):
@@ -277,7 +279,8 @@ def test_outconv_forward_loss_and_backward(gsd):
         loss = torch.zeros(1, device="cuda")
         grad = torch.zeros((n, 1, h, w), device="cuda")
         ws = torch.zeros(2048, dtype=torch.float64, device="cuda")
-        gsd.check(gsd.lib.gsd_loss_fwd_bwd(kind, dev(yr).data_ptr(), dev(tgt).data_ptr(), yr.size, 1.0, loss.data_ptr(),
+        yrd, tgtd = dev(yr), dev(tgt)
+        gsd.check(gsd.lib.gsd_loss_fwd_bwd(kind, yrd.data_ptr(), tgtd.data_ptr(), yr.size, 1.0, loss.data_ptr(),
                                            grad.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
         assert abs(loss.item() - lr) < 1e-6 * abs(lr)
         assert rel_l1(grad.cpu().numpy(), gr) < 1e-6
@@ -290,7 +293,8 @@ def test_outconv_forward_loss_and_backward(gsd):
     assert rel_l1(dwo, dwr.reshape(-1)) < TOL
     out = torch.zeros(1, device="cuda")
     ws = torch.zeros(64, device="cuda")
-    gsd.check(gsd.lib.gsd_sum_planes(dev(dout).data_ptr(), n, 1, h * w, out.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
+    doutd = dev(dout)
+    gsd.check(gsd.lib.gsd_sum_planes(doutd.data_ptr(), n, 1, h * w, out.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
     assert rel_l1(out.cpu().numpy(), dbr) < TOL
 
 
@@ -326,7 +330,8 @@ def test_adam_ema_matches_torch_and_oracle(gsd):
         pt.grad = torch.from_numpy(g.copy())
         opt.step()
         d = on.ema_decay(step)
-        gsd.check(gsd.lib.gsd_adam_ema(pd.data_ptr(), dev(g).data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(), numel,
+        gd = dev(g)
+        gsd.check(gsd.lib.gsd_adam_ema(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(), numel,
                                        step, 1e-3, 0.9, 0.999, 1e-8, 1e-6, d, 1.0, gsd.stream_ptr()))
     assert rel_l1(pd.cpu().numpy(), pt.detach().numpy()) < 1e-6
     assert rel_l1(pd.cpu().numpy(), p) < 1e-6
