@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config: train frames/s at 3x320x427, batch 32 per GPU,
+fp32, full train step (forward + MSE + backward + Adam + EMA), every device operation a libgsd HIP kernel.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Data parallel,
+weak scaling: every rank processes its own batch of 32; gradients are all-reduced over RCCL.
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how each field is obtained).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+DIMS = [64, 128, 256, 512, 1024]
+H, W = 320, 427
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The reference's CPU path (its torch-operator sequence, oracle/torch_cpu_path.py) timed on this box's host
+    cores on a bounded sample of the same workload: full train steps at 320x427, batch 2."""
+    from gelslim_depth_amd import synth
+    from oracle import torch_cpu_path as ot      # cpu_baseline leg only
+    cores = torch.get_num_threads()
+    st = synth.make_state(3, 1, DIMS, 0, "conditioned")
+    b = 2
+    x, t = synth.make_batch(b, H, W, 1)
+    tr = ot.CpuTrainer(st)
+    xt, tt = torch.from_numpy(x), torch.from_numpy(t)
+    tr.step(xt, tt)                               # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 3 or (time.time() - t_start < seconds_budget and len(times) < 5):
+        t0 = time.time()
+        tr.step(xt, tt)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": round(b / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full train steps (fwd+MSE+bwd+Adam) of batch {b} at 3x{H}x{W} fp32, "
+                      f"torch CPU operators as the reference executes them, median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from gelslim_depth_amd import synth
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+
+    model = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS)
+    st = synth.make_state(3, 1, DIMS, 0, "conditioned")            # random-init weights of the named architecture
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    model = model.to(dev).train()
+    step = TrainStep(model, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse", process_group=pg,
+                     sync_bn=args.sync_bn)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.rand((B, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
+    tgt = -0.9 * torch.rand((B, 1, H, W), device=dev, generator=g)         # U(-0.9,0] (normalised depth)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(x, tgt)
+    barrier()
+    eng = model._engine
+    eng.kernel_log = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(x, tgt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    klog = eng.kernel_log
+    eng.kernel_log = None
+    loss = float(step.last_loss.item())
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # dominant kernel: the 128x128-tile conv3x3 implicit GEMM (forward + dgrad of every layer with >64 out channels)
+        dom = "igemm_kernel<0,2,2>"
+        flops = sum(f for v, f, _, _ in klog if v == dom)
+        ms = sum(a.elapsed_time(b) for v, _, a, b in klog if v == dom)
+        launches = sum(1 for v, _, _, _ in klog if v == dom)
+        all_flops = sum(f for _, f, _, _ in klog)
+        all_ms = sum(a.elapsed_time(b) for _, _, a, b in klog)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "train frames/sec (320x427) at batch 32",
+            "value": round(B * world * args.steps / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch-32 full train step (fwd+MSE+bwd+Adam+EMA) fp32, "
+                                   "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6)},
+            "roofline": {"bound": "mfma", "kernel": dom,
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                         "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
+                         "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+                         "conv3x3_share_of_step": round(all_ms / args.steps / ms_per_step, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,8 @@ class UNetEngine:
         self.world = 1
         self._saved_train = False
         self.block_done_cb: Optional[Callable[[str], None]] = None   # data-parallel hook: a block's grads are final
+        # bench hook: when a list, every conv3x3 launch appends (variant, flops, start_event, end_event)
+        self.kernel_log: Optional[list] = None
 
     # ------------------------------------------------------------------ buffers
     def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
@@ -161,7 +163,9 @@ class UNetEngine:
         u.srcs = arr
         dst = L.dst_array([L.make_dst(u.raw)])
         part = self.partials.data_ptr() if train else None
+        ev = self._log_begin()
         check(lib.gsd_conv3x3(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
+        self._log_end(ev, u.cout, u.cin, n, lh, lw)
         if train:
             rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
@@ -179,6 +183,21 @@ class UNetEngine:
             check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
                                          P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
                   "bn_eval_coeffs")
+
+    def _log_begin(self):
+        if self.kernel_log is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _log_end(self, ev, m: int, k_ch: int, n: int, lh: int, lw: int) -> None:
+        if ev is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        variant = "igemm_kernel<0,1,4>" if m <= 64 else "igemm_kernel<0,2,2>"
+        self.kernel_log.append((variant, 2.0 * m * k_ch * 9 * n * lh * lw, ev, e))
 
     def _pad_off(self, lvl: int) -> Tuple[int, int]:
         # F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet.py:43-47)
@@ -272,8 +291,10 @@ class UNetEngine:
         lh, lw = self.hs[u.level], self.ws[u.level]
         check(lib.gsd_weight_layout(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.src_array([L.make_src(u.g)])
+        ev = self._log_begin()
         check(lib.gsd_conv3x3(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
               "conv3x3 dgrad")
+        self._log_end(ev, u.cin, u.cout, n, lh, lw)
 
     def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
         """dout: (N, n_classes, H, W) gradient of the loss w.r.t. the output.
