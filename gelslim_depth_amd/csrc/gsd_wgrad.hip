@@ -15,6 +15,8 @@
 // second kernel sums the slabs in a fixed order => bitwise reproducible.
 #include "gsd_common.h"
 
+#include <cstdlib>
+
 struct WgradParams {
   SrcD a0, a1;  // B operand (activation)
   SrcD dy;      // A operand (gradient, plain)
@@ -197,6 +199,170 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// conv3x3 dW, LDS-DMA form.  Both operand tiles go HBM/L2 -> LDS with global_load_lds_dword (no VGPR
+// staging), double-buffered: the DMA of stage s+1 is in flight while stage s is multiplied.  The
+// deferred BatchNorm+ReLU of the activation operand is applied after the ds_read, per lane (a lane's
+// input channel is fixed): b = max(fma(raw, scale, shift), lo).  Zero padding / out-of-segment
+// positions are DMA'd from a sentinel: quiet NaN for relu'd segments (max(NaN,0) = 0), 0 otherwise.
+// -------------------------------------------------------------------------------------------------
+__device__ const float gsd_pad[2] = {0.f, __builtin_nanf("")};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad3x3_dma_kernel(const WgradParams P) {
+  constexpr int MT = 4, NW = WM * WN;
+  constexpr int BMw = WM * 64, BNw = WN * 16, DS = 66;
+  static_assert(NW == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XS = P.PS;
+  const int BUF = BMw * DS + BNw * XS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int per_split = P.mblocks * P.nblocks;
+  const int split = blockIdx.x / per_split;
+  const int rem = blockIdx.x - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BMw, n0 = nb * BNw;
+  const int s_begin = (int)((long long)split * P.stages_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
+
+  // lane geometry of the DMA
+  const bool a_qin = lane < P.TH * P.TW;
+  const int a_r = a_qin ? lane / P.TW : 0;
+  const int a_c = a_qin ? lane - a_r * P.TW : 0;
+  int b_rr[4], b_cc[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int pos = p * 64 + lane;
+    b_ok[p] = pos < P.WR * P.WC;
+    b_rr[p] = pos / P.WC;
+    b_cc[p] = pos - b_rr[p] * P.WC;
+  }
+
+  // per-lane transform of the B operand (lane's input channel is fixed)
+  float sc = 1.f, sh = 0.f, lo = -__builtin_inff();
+  {
+    const int c = n0 + wn * 16 + l16;
+    const bool first = c < P.a0.C;
+    const SrcD& S = first ? P.a0 : P.a1;
+    const int cc = first ? c : c - P.a0.C;
+    if (c < P.Cact && cc < S.C) {
+      if (S.scale != nullptr) {
+        sc = S.scale[cc];
+        sh = S.shift[cc];
+      }
+      if (S.relu) lo = 0.f;
+    }
+  }
+
+  auto issue_dma = [&](int stage, int buf) {
+    const int tpi = P.tiles_y * P.tiles_x;
+    const int n = stage / tpi;
+    const int rs = stage - n * tpi;
+    const int ty = rs / P.tiles_x;
+    const int h0 = ty * P.TH, w0 = (rs - ty * P.tiles_x) * P.TW;
+    float* Ab = smem + buf * BUF;
+    float* Bb = Ab + BMw * DS;
+    const bool pix_ok = a_qin && (h0 + a_r) < P.H && (w0 + a_c) < P.W;
+    const float* abase = P.dy.p + (long long)n * P.dy.ns + (long long)(h0 + a_r) * P.dy.W + (w0 + a_c);
+#pragma unroll 4
+    for (int i = 0; i < BMw / 4; ++i) {
+      const int row = wave + 4 * i;
+      const int co = m0 + row;
+      const float* g = (pix_ok && co < P.M) ? abase + (long long)co * P.dy.cs : &gsd_pad[0];
+      __builtin_amdgcn_global_load_lds(g, Ab + row * DS, 4, 0, 0);
+    }
+#pragma unroll 2
+    for (int i = 0; i < BNw / 4; ++i) {
+      const int ch = wave + 4 * i;
+      const int c = n0 + ch;
+      const bool first = c < P.a0.C;
+      const SrcD& S = first ? P.a0 : P.a1;
+      const int cc = first ? c : c - P.a0.C;
+      const bool c_ok = c < P.Cact && cc < S.C;
+      const float* sentinel = (c_ok && S.relu) ? &gsd_pad[1] : &gsd_pad[0];
+      const float* cbase = S.p + (long long)n * S.ns + (long long)cc * S.cs;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (b_ok[p]) {
+          const int hs = h0 - 1 + b_rr[p] - S.oh, ws = w0 - 1 + b_cc[p] - S.ow;
+          const bool ok = c_ok && (unsigned)hs < (unsigned)S.H && (unsigned)ws < (unsigned)S.W;
+          const float* g = ok ? cbase + hs * S.W + ws : sentinel;
+          __builtin_amdgcn_global_load_lds(g, Bb + ch * XS + p * 64, 4, 0, 0);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MT][9];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (P.TH * P.TW) / 4;
+  const int a_off = (wm * 64 + l16) * DS + j;
+  const int b_off = BMw * DS + (wn * 16 + l16) * XS + j;
+
+  if (s_begin < s_end) issue_dma(s_begin, 0);
+  for (int stage = s_begin; stage < s_end; ++stage) {
+    const int cur = (stage - s_begin) & 1;
+    __syncthreads();  // this stage's DMA has landed (vmcnt(0) + barrier); everyone left the other buffer
+    if (stage + 1 < s_end) issue_dma(stage + 1, cur ^ 1);
+    const float* Ab = smem + cur * BUF + a_off;
+    const float* Bb = smem + cur * BUF + b_off;
+    int r = 0, c = 0;
+    float an[MT], bn[9];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) an[m] = Ab[m * 16 * DS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bn[t] = Bb[(t / 3) * P.WC + (t % 3)];
+    for (int s = 0; s < nk; ++s) {
+      float a[MT], b[9];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) b[t] = fmaxf(fmaf(bn[t], sc, sh), lo);
+      c += 4;
+      if (c >= P.TW) {
+        c = 0;
+        ++r;
+      }
+      if (s + 1 < nk) {
+        const int xb = r * P.WC + c;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) an[m] = Ab[m * 16 * DS + 4 * (s + 1)];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bn[t] = Bb[xb + (t / 3) * P.WC + (t % 3)];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+    }
+  }
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int mr = m0 + wm * 64 + m * 16 + j * 4 + reg;
+      if (mr < P.M) {
+        const int col = n0 + wn * 16 + l16;
+        if (col < P.Ncols) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            P.slabs[(((size_t)split * 9 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
+        }
+      }
+    }
+}
+
 // Sum the slabs in split order and write the reference layout.
 //   MODE 0: slab[split][tap][co][ci] -> dW[co][ci][tap]
 //   MODE 1: slab[split][m][ci]       -> dW[ci][m]          (m = co*4+kh*2+kw)
@@ -336,6 +502,24 @@ int launch_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t st, con
   return GSD_OK;
 }
 
+template <int WM, int WN>
+int launch_dma(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma_kernel<WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: LDS tile %zu B too large", lds);
+  hipLaunchKernelGGL((wgrad3x3_dma_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad");
+  return GSD_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
@@ -376,8 +560,18 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   const size_t lds = (size_t)(pl.BMw * 66 + pl.BNw * P.PS) * sizeof(float);
-  int rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
-                   : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
+  for (int i = 0; i < nsrc; ++i)
+    GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
+                "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
+  static const bool use_old = getenv("GSD_WGRAD_OLD") != nullptr;
+  int rc;
+  if (use_old) {
+    rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
+                 : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
+  } else {
+    const size_t lds2 = 2 * lds;
+    rc = pl.wide ? launch_dma<1, 4>(P, grid, lds2, (hipStream_t)stream) : launch_dma<2, 2>(P, grid, lds2, (hipStream_t)stream);
+  }
   if (rc) return rc;
   const long long per = 9LL * Cout * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
