@@ -118,44 +118,14 @@ class TrainStep:
         eng.world = self.world
         if sync_bn and self.world > 1:
             eng.sync_fn = lambda t: self.dist.all_reduce(t, group=self.pg)
+        self.sync = None
         if self.world > 1:
-            # rank 0's parameters and buffers are the truth (what DDP does at construction)
-            self.dist.broadcast(self.p_flat, src=0, group=self.pg)
-            for _, b in model.named_buffers():
-                self.dist.broadcast(b, src=0, group=self.pg)
+            from .distributed import GradSync, broadcast_state, make_buckets
+            broadcast_state(self.p_flat, [b for _, b in model.named_buffers()], group=self.pg)
             if self.ema_flat is not None:
                 self.ema_flat.copy_(self.p_flat)
-        self._buckets = self._make_buckets(names)
-        self._works: List = []
-
-    # buckets: contiguous arena ranges in the order backward completes them (end of the arena first)
-    def _make_buckets(self, names: List[str]) -> List[Tuple[str, int, int]]:
-        blocks: List[Tuple[str, int, int]] = []
-
-        def rng(prefix_list):
-            sel = [self.offsets[n] for n in names if any(n.startswith(p) for p in prefix_list)]
-            lo = min(o for o, _ in sel)
-            hi = max(o + s for o, s in sel)
-            return lo, hi
-        Lv = self.model._engine.L
-        for j in reversed(range(Lv)):
-            pref = [f"up.{j}."] + (["outc."] if j == Lv - 1 else [])
-            lo, hi = rng(pref)
-            blocks.append((f"dec{j}", lo, hi))
-        for lvl in reversed(range(Lv + 1)):
-            pref = ["inc."] if lvl == 0 else [f"down.{lvl - 1}."]
-            if Lv == 0:
-                pref.append("outc.")
-            lo, hi = rng(pref)
-            blocks.append((f"enc{lvl}", lo, hi))
-        return blocks
-
-    def _on_block_done(self, tag: str) -> None:
-        if self.world == 1 or not self.overlap:
-            return
-        for name, lo, hi in self._buckets:
-            if name == tag:
-                self._works.append(self.dist.all_reduce(self.g_flat[lo:hi], group=self.pg, async_op=True))
+            self.sync = GradSync(self.g_flat, make_buckets(names, self.offsets, eng.L), group=self.pg,
+                                 overlap=overlap_allreduce)
 
     def __call__(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         model = self.model
@@ -169,16 +139,11 @@ class TrainStep:
             self._dout = torch.empty_like(self._out)
         out = eng.forward(x, P, train=True, out=self._out)
         loss_fwd_bwd(self.loss_kind, out, target, self._dout, self.loss_buf, self.loss_ws)
-        eng.block_done_cb = self._on_block_done
+        eng.block_done_cb = self.sync.on_block_done if self.sync is not None else None
         eng.backward(self._dout, P, model._grad_views)
         eng.block_done_cb = None
-        if self.world > 1:
-            if self.overlap:
-                for w in self._works:
-                    w.wait()
-                self._works = []
-            else:
-                self.dist.all_reduce(self.g_flat, group=self.pg)
+        if self.sync is not None:
+            self.sync.finish()
         self.step_count += 1
         d = 0.0
         if self.ema_flat is not None:

@@ -1,0 +1,65 @@
+"""GPU: the 2-rank data-parallel fused train step (bucketed gradient all-reduce overlapped with backward,
+rank-0 broadcast, optional SyncBN) against the oracle.
+
+  * local BN (what torch DDP does): summed gradient arena / 2 == mean of the oracle's per-shard gradients;
+  * SyncBN: equals the oracle's SINGLE-process step on the whole global batch;
+both ranks end with identical parameters."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, rel_l1
+from gelslim_depth_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_two_ranks(tmp_path, mode):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
+
+
+def oracle_flat(grads, names):
+    return np.concatenate([grads[n].reshape(-1) for n in names])
+
+
+@pytest.mark.parametrize("mode", ["local_bn", "sync_bn"])
+def test_two_rank_step_matches_oracle(tmp_path, mode):
+    from oracle import unet_numpy as on
+    res = run_two_ranks(tmp_path, mode)
+    dims = [16, 32, 64]
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")          # rank 0's weights are the truth
+    names = synth.param_names(list(st0.keys()))
+    p0 = oracle_flat(st0, names)
+    for r in res:
+        assert np.array_equal(r["p0"], p0), "rank-0 broadcast"
+    assert np.array_equal(res[0]["g_sum"], res[1]["g_sum"]), "all ranks hold the same summed gradients"
+    assert np.array_equal(res[0]["p1"], res[1]["p1"]), "replicas stay in lock-step"
+    x, t = synth.make_batch(4, 37, 53, 6)
+    if mode == "local_bn":
+        gs, ls = [], []
+        for r in range(2):
+            net, losses, first, _ = on.train_steps(st0, x[2 * r:2 * r + 2], t[2 * r:2 * r + 2], 1)
+            gs.append(oracle_flat(first["grads"], names))
+            ls.append(losses[0])
+        g_exp = (gs[0] + gs[1]) / 2
+        for r in range(2):
+            assert abs(res[r]["loss"] - ls[r]) < 1e-4 * ls[r]
+        p_exp = None
+    else:
+        net, losses, first, _ = on.train_steps(st0, x, t, 1)
+        g_exp = oracle_flat(first["grads"], names)
+        p_exp = oracle_flat(net.s, names)
+        for k, v in first["buf"].items():
+            if not k.endswith("num_batches_tracked"):
+                assert rel_l1(res[0]["buf/" + k], v) < 1e-4, k      # running stats from GLOBAL batch statistics
+    assert rel_l1(res[0]["g_sum"] / 2, g_exp) < 2e-2
+    if p_exp is not None:
+        assert rel_l1(res[0]["p1"], p_exp) < 1e-3
