@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +118,22 @@ def main():
     if rank == 0:
         # dominant kernel: the 128x128-tile conv3x3 implicit GEMM (forward + dgrad of every layer with >64 out channels)
         dom = "igemm_kernel<0,2,2>"
-        flops = sum(f for v, f, _, _ in klog if v == dom)
-        ms = sum(a.elapsed_time(b) for v, _, a, b in klog if v == dom)
-        launches = sum(1 for v, _, _, _ in klog if v == dom)
-        all_flops = sum(f for _, f, _, _ in klog)
-        all_ms = sum(a.elapsed_time(b) for _, _, a, b in klog)
+        flops = sum(f for v, f, _, _, _ in klog if v == dom)
+        ms = sum(a.elapsed_time(b) for v, _, a, b, _ in klog if v == dom)
+        launches = sum(1 for v, _, _, _, _ in klog if v == dom)
+        all_flops = sum(f for _, f, _, _, _ in klog)
+        all_ms = sum(a.elapsed_time(b) for _, _, a, b, _ in klog)
+        if args.per_layer:
+            import collections
+            agg = collections.OrderedDict()
+            for v, f, a, b, sig in klog:
+                d = agg.setdefault(sig, [0.0, 0.0, 0])
+                d[0] += f
+                d[1] += a.elapsed_time(b)
+                d[2] += 1
+            for sig, (f, t, c) in agg.items():
+                print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
+                      (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         out = {

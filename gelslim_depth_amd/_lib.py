@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgsd.so")
+LIB_PATH = os.environ.get("GSD_LIB_PATH") or os.path.join(_HERE, "csrc", "libgsd.so")   # override: A/B builds while tuning
 
 
 class GsdError(RuntimeError):

@@ -92,6 +92,22 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
+static inline int gsd_check_src(const gsd_src& s, const char* what) {
+  GSD_REQUIRE(s.ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null ptr", what);
+  GSD_REQUIRE(s.C > 0 && s.H > 0 && s.W > 0, GSD_ERR_BAD_ARG, "%s: bad dims C=%d H=%d W=%d", what, s.C, s.H, s.W);
+  GSD_REQUIRE((s.scale == nullptr) == (s.shift == nullptr), GSD_ERR_BAD_ARG, "%s: scale/shift must come together", what);
+  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
+              what);
+  return 0;
+}
+static inline int gsd_check_dst(const gsd_dst& s, const char* what) {
+  GSD_REQUIRE(s.ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null ptr", what);
+  GSD_REQUIRE(s.C > 0 && s.H > 0 && s.W > 0, GSD_ERR_BAD_ARG, "%s: bad dims", what);
+  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
+              what);
+  return 0;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -1,0 +1,369 @@
+// gsd_conv3x3.hip -- conv3x3 (pad 1, stride 1, no bias) forward and dX as implicit GEMM on
+// v_mfma_f32_16x16x4_f32, LDS-DMA form (gfx950).
+//
+//   D[m = out channel][n = pixel] = sum_{ci,tap} Wt[(ci,tap)][m] * B[(ci,tap)][pixel]
+//
+// Replaces aten::convolution at /root/reference/gelslim_depth/models/unet.py:11,14 (forward) and, with the
+// dgrad weight layout (taps flipped, channels swapped), the dX half of aten::convolution_backward.
+//
+// Data movement: both operand tiles go HBM/L2 -> LDS with global_load_lds (weights 16 B/lane from a
+// pre-tiled, pre-padded layout; the zero-padded (TH+2)x(TW+2) input halo 4 B/lane along NCHW rows), double
+// buffered, one barrier per K-chunk of 4 input channels (36 k-rows, 9 MFMA k-steps): the DMA of chunk c+1 is
+// in flight while chunk c is multiplied, no VGPR staging, no ds_write.  Deferred BatchNorm+ReLU of the
+// producer is applied after the ds_read (b = max(fma(raw, scale[ci], shift[ci]), lo)), i.e. inside the MFMA
+// loop where VALU work is free; zero padding / channel padding / F.pad offsets of the second (concat)
+// segment are DMA'd from a sentinel (quiet NaN under a ReLU: max(NaN, 0) = 0; else 0).
+//
+// Pixels sit on the MFMA column (lane&15): one accumulator register = 16 consecutive floats of an NCHW row.
+// Wave tile 64 (m) x 64 (pixels) = 4x4 MFMA tiles; block = 4 waves: 64x256 for M <= 64, 128x128 otherwise.
+#include "gsd_common.h"
+
+
+__device__ const float gsd_pad_c3[2] = {0.f, __builtin_nanf("")};
+
+struct Conv3Params {
+  SrcD src0, src1;
+  DstD dst0, dst1;
+  const float* wt;   // [mblocks][nchunks*36][BM+16]
+  float* partials;
+  int Cin, Cout, Mpad, nchunks, mblocks;
+  int N, H, W;
+  int TH, TW, tiles_y, tiles_x, WR, WC, PS, NPV;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
+  constexpr int MT = 4, NT = 4;
+  constexpr int BM = WM * 64;
+  constexpr int WS = BM + 16;        // == 16 (mod 32): the 4 k-rows of one ds_read_b32 hit disjoint banks
+  constexpr int WTILE = 36 * WS;     // floats per chunk
+  constexpr int W4 = WTILE / 4;      // float4s per chunk
+  constexpr int NWI = (W4 + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PS = P.PS;
+  const int BUF = WTILE + 4 * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int mb = blockIdx.x % P.mblocks;
+  const int pt = blockIdx.x / P.mblocks;
+  const int m0 = mb * BM;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = pt / tpi;
+  const int rt = pt - n * tpi;
+  const int ty = rt / P.tiles_x;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+
+  // ---- per-lane pixel bookkeeping for the MFMA B operand / epilogue ------------------------------
+  int baddr[NT], opix[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int q = (wn * NT + t) * 16 + l16;
+    const bool ok = q < P.TH * P.TW;
+    const int r = ok ? q / P.TW : 0;
+    const int c = ok ? q - r * P.TW : 0;
+    baddr[t] = WTILE + j * PS + r * P.WC + c;
+    opix[t] = (ok && (h0 + r) < P.H && (w0 + c) < P.W) ? ((r << 16) | c) : -1;
+  }
+
+  // ---- DMA lane geometry: this wave owns window position chunks p = wave and wave+4 ------------------
+  // offset of the position inside a channel plane of segment 0 / 1; -1: zero padding; -2: beyond the window
+  int xo0[2], xo1[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int pos = (wave + 4 * pp) * 64 + lane;
+    xo0[pp] = xo1[pp] = -2;
+    if (pos < P.WR * P.WC) {
+      const int rr = pos / P.WC;
+      const int gh = h0 - 1 + rr, gw = w0 - 1 + (pos - rr * P.WC);
+      int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.W + ws : -1;
+      hs = gh - P.src1.oh;
+      ws = gw - P.src1.ow;
+      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.W + ws : -1;
+    }
+  }
+  const float* wsrc0 = P.wt + (size_t)mb * P.nchunks * WTILE;
+  const bool p_on[2] = {wave < P.NPV, wave + 4 < P.NPV};
+
+  // DMA-side running state over the channel sequence (wave-uniform except d_xo): which segment the next
+  // channel comes from, its plane pointer, the padding sentinel, how many channels the segment has left.
+  int d_seg = 0, d_left = P.src0.C;
+  const float* d_base = P.src0.p + (long long)n * P.src0.ns;
+  long long d_cs = P.src0.cs;
+  const float* d_sent = P.src0.relu ? &gsd_pad_c3[1] : &gsd_pad_c3[0];
+  int d_xo[2] = {xo0[0], xo0[1]};
+
+  auto issue_dma = [&](int chunk, int buf) {
+    float* Wb = smem + buf * BUF;
+    float* Xb = Wb + WTILE;
+    const float* wsrc = wsrc0 + (size_t)chunk * WTILE + tid * 4;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      if (tid + i * 256 < W4) __builtin_amdgcn_global_load_lds(wsrc + i * 1024, Wb + (i * 256 + wave * 64) * 4, 16, 0, 0);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (d_left == 0 && d_seg == 0) {  // first segment exhausted: continue in the concatenated second one
+        d_seg = 1;
+        d_left = P.src1.C;
+        d_base = P.src1.p + (long long)n * P.src1.ns;
+        d_cs = P.src1.cs;
+        d_sent = P.src1.relu ? &gsd_pad_c3[1] : &gsd_pad_c3[0];
+        d_xo[0] = xo1[0];
+        d_xo[1] = xo1[1];
+      }
+      const bool c_ok = d_left > 0;
+      const float* sentinel = c_ok ? d_sent : &gsd_pad_c3[0];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        if (p_on[pp] && d_xo[pp] != -2) {
+          const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : sentinel;
+          __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave + 4 * pp) * 64, 4, 0, 0);
+        }
+      }
+      if (c_ok) {
+        d_base += d_cs;
+        --d_left;
+      }
+    }
+  };
+
+  // per-lane transform of the B operand for one chunk (lane's k row = channel chunk*4 + j)
+  auto load_affine = [&](int chunk, float& sc, float& sh, float& lo) {
+    const int c = chunk * 4 + j;
+    const bool first = c < P.src0.C;
+    const SrcD& S = first ? P.src0 : P.src1;
+    const int cc = first ? c : c - P.src0.C;
+    sc = 1.f;
+    sh = 0.f;
+    lo = -__builtin_inff();
+    if (c < P.Cin && cc < S.C) {
+      if (S.scale != nullptr) {
+        sc = S.scale[cc];
+        sh = S.shift[cc];
+      }
+      if (S.relu) lo = 0.f;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_lane = wm * 64 + l16;
+  float sc_n, sh_n, lo_n;
+  issue_dma(0, 0);
+  load_affine(0, sc_n, sh_n, lo_n);
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    __syncthreads();  // this chunk's DMA has landed (vmcnt(0) + barrier); everyone has left the other buffer
+    const float sc = sc_n, sh = sh_n, lo = lo_n;
+    if (chunk + 1 < P.nchunks) {
+      issue_dma(chunk + 1, cur ^ 1);
+      load_affine(chunk + 1, sc_n, sh_n, lo_n);
+    }
+    const float* Wc = smem + cur * BUF;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      const int koff = (s / 3) * P.WC + (s % 3);
+      const int arow = j * 9 + s;
+      float a[MT], b[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = Wc[arow * WS + a_lane + m * 16];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = fmaxf(fmaf(Wc[baddr[t] + koff], sc, sh), lo);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+    }
+  }
+
+  // ---- epilogue: NCHW store (two destination segments with crop) + BatchNorm partial sums ---------
+  int ooff0[NT], ooff1[NT];  // element offset of the lane's pixel inside a plane of dst0 / dst1, -1: cropped
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    ooff0[t] = ooff1[t] = -1;
+    if (opix[t] >= 0) {
+      const int h = h0 + (opix[t] >> 16), w = w0 + (opix[t] & 0xffff);
+      int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
+      if ((unsigned)hd < (unsigned)P.dst0.H && (unsigned)wd < (unsigned)P.dst0.W) ooff0[t] = hd * P.dst0.W + wd;
+      hd = h - P.dst1.oh;
+      wd = w - P.dst1.ow;
+      if ((unsigned)hd < (unsigned)P.dst1.H && (unsigned)wd < (unsigned)P.dst1.W) ooff1[t] = hd * P.dst1.W + wd;
+    }
+  }
+  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
+  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int co = m0 + wm * 64 + m * 16 + j * 4 + reg;
+      const bool first = co < P.dst0.C;
+      const int cd = first ? co : co - P.dst0.C;
+      const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+      float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (opix[t] >= 0) {
+          const float v = acc[m][t][reg];
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+          const int off = first ? ooff0[t] : ooff1[t];
+          if (co_ok && off >= 0) plane[off] = v;
+        }
+      }
+      if (P.partials != nullptr) {
+        s1 = reduce16(s1);
+        s2 = reduce16(s2);
+        if (l16 == 0 && co < P.Mpad) {
+          float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
+          row[co] = s1;
+          row[P.Mpad + co] = s2;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+// Pick a TH x TW output tile with TH*TW <= BN and (TH+2)*(TW+2) <= 512.  First the minimum number of
+// tiles (= wasted MFMA columns) over all shapes; then, among shapes within 5 % of that minimum, the one
+// that is best for memory: rows that are multiples of 16 pixels (one accumulator register = one 64-B row
+// segment), then the widest rows (long coalesced halo rows, few row wraps per wave).
+void choose_tile(int H, int W, int BN, int* TH, int* TW) {
+  long min_tiles = -1;
+  for (int pass = 0; pass < 2; ++pass) {
+    long best_score = -1;
+    for (int tw = 1; tw <= W + 15 && tw <= BN; ++tw) {
+      int th = BN / tw;
+      if (th > H) th = H;
+      while (th > 1 && (th + 2) * (tw + 2) > 512) --th;
+      if ((th + 2) * (tw + 2) > 512) continue;
+      const int ty = ceil_div(H, th);
+      th = ceil_div(H, ty);  // smallest th giving the same number of row tiles
+      const long tiles = (long)ty * ceil_div(W, tw);
+      if (pass == 0) {
+        if (min_tiles < 0 || tiles < min_tiles) min_tiles = tiles;
+      } else if (tiles * 100 <= min_tiles * 105) {
+        const long score = (tw % 16 == 0 ? 1000000L : 0L) + (long)(tw > W ? W : tw) * 1000 - tiles;
+        if (score > best_score) {
+          best_score = score;
+          *TH = th;
+          *TW = tw;
+        }
+      }
+    }
+  }
+}
+
+int plane_stride_16mod32(int n) {  // smallest PS >= n with PS % 32 == 16
+  int ps = (n / 32) * 32 + 16;
+  if (ps < n) ps += 32;
+  return ps;
+}
+
+struct ConvPlan {
+  bool wide;  // true: 64x256 block tile (M<=64), false: 128x128
+  int BM, BN, WN, TH, TW, tiles_y, tiles_x, mblocks;
+};
+
+ConvPlan plan_conv3x3(int H, int W, int M) {
+  ConvPlan p;
+  p.wide = M <= 64;
+  p.BM = p.wide ? 64 : 128;
+  p.BN = p.wide ? 256 : 128;
+  p.WN = p.wide ? 4 : 2;
+  choose_tile(H, W, p.BN, &p.TH, &p.TW);
+  p.tiles_y = ceil_div(H, p.TH);
+  p.tiles_x = ceil_div(W, p.TW);
+  p.mblocks = ceil_div(M, p.BM);
+  return p;
+}
+
+template <int WM, int WN>
+int launch(const Conv3Params& P, int grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("gsd_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_dma_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3");
+  return GSD_OK;
+}
+
+}  // namespace
+
+extern "C" int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  ConvPlan p = plan_conv3x3(H, W, Cout);
+  return N * p.tiles_y * p.tiles_x * p.WN;
+}
+
+extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                           int ndst, float* partials, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3: null argument");
+  GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3: nsrc/ndst must be 1 or 2");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3: bad sizes");
+  GSD_REQUIRE(H < 32768 && W < 32768, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: H, W must be < 32768");
+  GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3: weight layout must be 16-byte aligned");
+  int csum = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (int e = gsd_check_src(src[i], "gsd_conv3x3 src")) return e;
+    GSD_REQUIRE(src[i].scale == nullptr || src[i].relu != 0, GSD_ERR_UNSUPPORTED,
+                "gsd_conv3x3: an affine source segment must also have relu (zero padding uses a NaN sentinel)");
+    GSD_REQUIRE((int64_t)src[i].H * src[i].W < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3: plane too large");
+    csum += src[i].C;
+  }
+  GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3: source segments hold %d channels, Cin=%d", csum, Cin);
+  csum = 0;
+  for (int i = 0; i < ndst; ++i) {
+    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3 dst")) return e;
+    csum += dst[i].C;
+  }
+  GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3: destination segments hold %d channels, Cout=%d", csum, Cout);
+
+  ConvPlan pl = plan_conv3x3(H, W, Cout);
+  Conv3Params P;
+  P.src0 = to_srcd(src[0]);
+  P.src1 = nsrc > 1 ? to_srcd(src[1]) : null_srcd();
+  P.dst0 = to_dstd(dst[0]);
+  P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
+  P.wt = wt;
+  P.partials = partials;
+  P.Cin = Cin;
+  P.Cout = Cout;
+  P.Mpad = round_up(Cout, 64);
+  P.nchunks = ceil_div(Cin, 4);
+  P.mblocks = pl.mblocks;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.WR = pl.TH + 2; P.WC = pl.TW + 2;
+  P.PS = plane_stride_16mod32(P.WR * P.WC);
+  P.NPV = ceil_div(P.WR * P.WC, 64);
+  GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: halo window too large");
+  const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
+  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
+  const size_t lds = (size_t)2 * (36 * (pl.BM + 16) + 4 * P.PS) * sizeof(float);
+  if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);
+  return launch<2, 2>(P, (int)grid, lds, (hipStream_t)stream);
+}

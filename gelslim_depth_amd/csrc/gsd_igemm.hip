@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
   //         4 channels of a chunk.  flat modes: thread owns pixel q = tid % BN for NXE rows.
   int gh[2] = {0, 0}, gw[2] = {0, 0};
   bool pos_ok[2] = {false, false};
+  // chunk-invariant per-thread offsets (MODE 0): element offset of each window position inside a channel
+  // plane of segment 0 / 1 (-1: outside the segment => zero padding), and of each weight float4 inside a chunk
+  int xo0[2] = {-1, -1}, xo1[2] = {-1, -1};
+  int wv_off[NW4], wl_off[NW4];
   int fq = 0, frow0 = 0, fh = 0, fw = 0;
   bool f_ok = false;
   if constexpr (MODE == 0) {
@@ -103,6 +107,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
       const int rr = pos / P.WC;
       gh[i] = h0 - 1 + rr;
       gw[i] = w0 - 1 + (pos - rr * P.WC);
+      if (pos_ok[i]) {
+        int hs = gh[i] - P.src0.oh, ws = gw[i] - P.src0.ow;
+        if ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) xo0[i] = hs * P.src0.W + ws;
+        hs = gh[i] - P.src1.oh;
+        ws = gw[i] - P.src1.ow;
+        if ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) xo1[i] = hs * P.src1.W + ws;
+      }
     }
   } else {
     fq = tid % BN;
@@ -114,21 +125,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
     }
   }
 
+#pragma unroll
+  for (int i = 0; i < NW4; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx / (BM / 4);
+    const int c4 = idx % (BM / 4);
+    wv_off[i] = (idx < W4 && m0 + c4 * 4 < P.Mpad) ? r * P.Mpad + m0 + c4 * 4 : -1;
+    wl_off[i] = r * WS + c4 * 4;
+  }
+  float xsc[4] = {1.f, 1.f, 1.f, 1.f}, xsh[4] = {0.f, 0.f, 0.f, 0.f};  // per-chunk channel affine (wave-uniform)
+
   float xr[NXE];   // raw prefetched values (MODE 2: NXE float2 halves stored as 2*NXE floats below)
   float xr2[MODE == 2 ? NXE : 1];
   unsigned xvalid = 0;
   f32x4 wr[NW4];
 
   auto prefetch = [&](int chunk) {
-    // weights
+    // weights: uniform chunk base + chunk-invariant per-thread offset
+    const float* wbase = P.wt + (size_t)chunk * WROWS * P.Mpad;
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx / (BM / 4);
-      const int col = m0 + (idx % (BM / 4)) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < W4 && col < P.Mpad)
-        v = *reinterpret_cast<const f32x4*>(P.wt + (size_t)(chunk * WROWS + r) * P.Mpad + col);
+      if (wv_off[i] >= 0) v = *reinterpret_cast<const f32x4*>(wbase + wv_off[i]);
       wr[i] = v;
     }
     xvalid = 0;
@@ -140,13 +158,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
         const SrcD& S = first ? P.src0 : P.src1;
         const int cc = first ? c : c - P.src0.C;
         const bool c_ok = c < P.Cin && cc < S.C;
-        const float* base = S.p + (long long)n * S.ns + (long long)cc * S.cs;
+        const float* base = S.p + (long long)n * S.ns + (long long)cc * S.cs;   // wave-uniform
+        float sc = 1.f, sh = 0.f;
+        if (c_ok && S.scale != nullptr) {
+          sc = S.scale[cc];
+          sh = S.shift[cc];
+        }
+        xsc[ch] = sc;
+        xsh[ch] = sh;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int hs = gh[i] - S.oh, ws = gw[i] - S.ow;
-          const bool ok = c_ok && pos_ok[i] && (unsigned)hs < (unsigned)S.H && (unsigned)ws < (unsigned)S.W;
+          const int off = first ? xo0[i] : xo1[i];
+          const bool ok = c_ok && off >= 0;
           float v = 0.f;
-          if (ok) v = base[hs * S.W + ws];
+          if (ok) v = base[off];
           xr[i * 4 + ch] = v;
           xvalid |= ok ? (1u << (i * 4 + ch)) : 0u;
         }
@@ -182,30 +207,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
   auto stage = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < W4) {
-        const int r = idx / (BM / 4);
-        const int c4 = idx % (BM / 4);
-        *reinterpret_cast<f32x4*>(&Wl[r * WS + c4 * 4]) = wr[i];
-      }
+      if (tid + i * 256 < W4) *reinterpret_cast<f32x4*>(&Wl[wl_off[i]]) = wr[i];
     }
     if constexpr (MODE == 0) {
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         const int c = chunk * 4 + ch;
-        const bool first = c < P.src0.C;
-        const SrcD& S = first ? P.src0 : P.src1;
-        const int cc = first ? c : c - P.src0.C;
-        float sc = 1.f, sh = 0.f;
-        if (S.scale != nullptr && c < P.Cin && cc < S.C) {
-          sc = S.scale[cc];
-          sh = S.shift[cc];
-        }
+        const int relu = c < P.src0.C ? P.src0.relu : P.src1.relu;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (pos_ok[i]) {
             const bool ok = (xvalid >> (i * 4 + ch)) & 1u;
-            const float v = ok ? apply_affine(xr[i * 4 + ch], sc, sh, S.relu) : 0.f;
+            const float v = ok ? apply_affine(xr[i * 4 + ch], xsc[ch], xsh[ch], relu) : 0.f;
             Xl[ch * PS + tid + i * 256] = v;
           }
         }
@@ -341,57 +354,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams P) {
 // -------------------------------------------------------------------------------------------------
 namespace {
 
-// Pick a TH x TW output tile with TH*TW <= BN and (TH+2)*(TW+2) <= 512 minimising the number of
-// tiles (i.e. wasted MFMA columns), then the halo area.
-void choose_tile(int H, int W, int BN, int* TH, int* TW) {
-  long best_cost = -1;
-  int bh = 1, bw = 1;
-  for (int tw = 1; tw <= W && tw <= BN; ++tw) {
-    int th = BN / tw;
-    if (th > H) th = H;
-    while (th > 1 && (th + 2) * (tw + 2) > 512) --th;
-    if ((th + 2) * (tw + 2) > 512) continue;
-    // smallest th giving the same number of row tiles
-    const int ty = ceil_div(H, th);
-    th = ceil_div(H, ty);
-    const int tx = ceil_div(W, tw);
-    const long tiles = (long)ty * tx;
-    const long halo = (long)(th + 2) * (tw + 2);
-    const long cost = tiles * 100000L + halo * 10 - (tw >= 16 ? 5 : 0);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      bh = th;
-      bw = tw;
-    }
-  }
-  *TH = bh;
-  *TW = bw;
-}
-
-int plane_stride_16mod32(int n) {  // smallest PS >= n with PS % 32 == 16
-  int ps = (n / 32) * 32 + 16;
-  if (ps < n) ps += 32;
-  return ps;
-}
-
-struct ConvPlan {
-  bool wide;  // true: 64x256 block tile (Cout<=64), false: 128x128
-  int BM, BN, WN, TH, TW, tiles_y, tiles_x, mblocks;
-};
-
-ConvPlan plan_conv3x3(int H, int W, int Cout) {
-  ConvPlan p;
-  p.wide = Cout <= 64;
-  p.BM = p.wide ? 64 : 128;
-  p.BN = p.wide ? 256 : 128;
-  p.WN = p.wide ? 4 : 2;
-  choose_tile(H, W, p.BN, &p.TH, &p.TW);
-  p.tiles_y = ceil_div(H, p.TH);
-  p.tiles_x = ceil_div(W, p.TW);
-  p.mblocks = ceil_div(Cout, p.BM);
-  return p;
-}
-
 int check_src(const gsd_src& s, const char* what) {
   GSD_REQUIRE(s.ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null ptr", what);
   GSD_REQUIRE(s.C > 0 && s.H > 0 && s.W > 0, GSD_ERR_BAD_ARG, "%s: bad dims C=%d H=%d W=%d", what, s.C, s.H, s.W);
@@ -426,57 +388,6 @@ int launch(const IgemmParams& P, int grid, size_t lds, hipStream_t st, const cha
 }
 
 }  // namespace
-
-extern "C" int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout) {
-  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-  ConvPlan p = plan_conv3x3(H, W, Cout);
-  return N * p.tiles_y * p.tiles_x * p.WN;
-}
-
-extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst,
-                           int ndst, float* partials, int N, int H, int W, void* stream) {
-  GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3: null argument");
-  GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3: nsrc/ndst must be 1 or 2");
-  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3: bad sizes");
-  GSD_REQUIRE(H < 32768 && W < 32768, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: H, W must be < 32768");
-  int csum = 0;
-  for (int i = 0; i < nsrc; ++i) {
-    if (int e = check_src(src[i], "gsd_conv3x3 src")) return e;
-    csum += src[i].C;
-  }
-  GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3: source segments hold %d channels, Cin=%d", csum, Cin);
-  csum = 0;
-  for (int i = 0; i < ndst; ++i) {
-    if (int e = check_dst(dst[i], "gsd_conv3x3 dst")) return e;
-    csum += dst[i].C;
-  }
-  GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3: destination segments hold %d channels, Cout=%d", csum, Cout);
-
-  ConvPlan pl = plan_conv3x3(H, W, Cout);
-  IgemmParams P;
-  P.src0 = to_srcd(src[0]);
-  P.src1 = nsrc > 1 ? to_srcd(src[1]) : null_srcd();
-  P.dst0 = to_dstd(dst[0]);
-  P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
-  P.wt = wt;
-  P.bias = nullptr;
-  P.partials = partials;
-  P.Cin = Cin;
-  P.Cout = Cout;
-  P.Mpad = round_up(Cout, 64);
-  P.nchunks = ceil_div(Cin, 4);
-  P.mblocks = pl.mblocks;
-  P.N = N; P.H = H; P.W = W;
-  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
-  P.WR = pl.TH + 2; P.WC = pl.TW + 2;
-  P.PS = plane_stride_16mod32(P.WR * P.WC);
-  P.tiles_flat = 0;
-  const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
-  const size_t lds = (size_t)(36 * (pl.BM + 16) + 4 * P.PS) * sizeof(float);
-  if (pl.wide) return launch<0, 1, 4>(P, (int)grid, lds, (hipStream_t)stream, "gsd_conv3x3");
-  return launch<0, 2, 2>(P, (int)grid, lds, (hipStream_t)stream, "gsd_conv3x3");
-}
 
 extern "C" int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin, int Cout,
                             const gsd_dst* dst, int N, int H, int W, void* stream) {

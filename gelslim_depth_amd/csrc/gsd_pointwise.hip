@@ -42,34 +42,49 @@ extern "C" int gsd_selftest_mfma(const float* a, const float* b, float* out, voi
 // ---------------------------------------------------------------------------------------------
 // weight re-layouts
 // ---------------------------------------------------------------------------------------------
-static void layout_dims(int mode, int Co, int Ci, int* rows, int* M) {
+// modes 0/1 (conv3x3): tiled for the LDS-DMA kernel: [mblock][k row][BM+16], BM = 64 if M <= 64 else 128, so that
+//   one K-chunk of one m-block is ONE contiguous, already bank-padded LDS image (36 x (BM+16) floats).
+// modes 2/3 (convT): plain [k row][Mpad].
+static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, int* pitch, int* mblocks) {
   switch (mode) {
     case 0: *rows = round_up(Ci, 4) * 9; *M = Co; break;        // k = ci*9+t        m = co
     case 1: *rows = round_up(Co, 4) * 9; *M = Ci; break;        // k = co*9+t (flip) m = ci
     case 2: *rows = round_up(Ci, 16); *M = Co * 4; break;       // k = ci            m = co*4+khkw
     default: *rows = round_up(Co, 4) * 4; *M = Ci; break;       // k = co*4+khkw     m = ci
   }
+  if (mode <= 1) {
+    *BM = *M <= 64 ? 64 : 128;
+    *pitch = *BM + 16;
+    *mblocks = ceil_div(*M, *BM);
+  } else {
+    *BM = round_up(*M, 64);
+    *pitch = *BM;
+    *mblocks = 1;
+  }
 }
 extern "C" int64_t gsd_weight_layout_size(int mode, int Co, int Ci) {
   if (mode < 0 || mode > 3 || Co <= 0 || Ci <= 0) return 0;
-  int rows, M;
-  layout_dims(mode, Co, Ci, &rows, &M);
-  return (int64_t)rows * round_up(M, 64);
+  int rows, M, BM, pitch, mblocks;
+  layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
+  return (int64_t)mblocks * rows * pitch;
 }
 __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int Co, int Ci, float* __restrict__ wt,
-                                     int rows, int M, int Mpad) {
-  const long long total = (long long)rows * Mpad;
+                                     int rows, int M, int BM, int pitch, int mblocks) {
+  const long long total = (long long)mblocks * rows * pitch;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(e % Mpad);
-    const int k = (int)(e / Mpad);
+    const int col = (int)(e % pitch);
+    const long long t = e / pitch;
+    const int k = (int)(t % rows);
+    const int mb = (int)(t / rows);
+    const int m = mb * BM + col;
     float v = 0.f;
-    if (m < M) {
+    if (col < BM && m < M) {
       if (mode == 0) {
-        const int ci = k / 9, t = k % 9;
-        if (ci < Ci) v = w[((size_t)m * Ci + ci) * 9 + t];
+        const int ci = k / 9, tp = k % 9;
+        if (ci < Ci) v = w[((size_t)m * Ci + ci) * 9 + tp];
       } else if (mode == 1) {
-        const int co = k / 9, t = k % 9;
-        if (co < Co) v = w[((size_t)co * Ci + m) * 9 + (8 - t)];
+        const int co = k / 9, tp = k % 9;
+        if (co < Co) v = w[((size_t)co * Ci + m) * 9 + (8 - tp)];
       } else if (mode == 2) {
         if (k < Ci) v = w[(size_t)k * M + m];  // (Ci, Co*4) is already [k][m]
       } else {
@@ -82,13 +97,12 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
 }
 extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
   GSD_REQUIRE(w && wt && mode >= 0 && mode <= 3 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
-  int rows, M;
-  layout_dims(mode, Co, Ci, &rows, &M);
-  const int Mpad = round_up(M, 64);
-  const long long total = (long long)rows * Mpad;
+  int rows, M, BM, pitch, mblocks;
+  layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
+  const long long total = (long long)mblocks * rows * pitch;
   const int grid = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
-  hipLaunchKernelGGL(weight_layout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, rows, M,
-                     Mpad);
+  hipLaunchKernelGGL(weight_layout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, rows, M, BM,
+                     pitch, mblocks);
   GSD_LAUNCH_CHECK("gsd_weight_layout");
   return GSD_OK;
 }

@@ -333,17 +333,23 @@ __global__ __launch_bounds__(256) void wgrad3x3_dma_kernel(const WgradParams P) 
         c = 0;
         ++r;
       }
-      if (s + 1 < nk) {
+      {
+        // next k-step's operands: issued before this k-step's MFMAs so their LDS latency hides behind them
+        // (one wave per SIMD here: nobody else covers it).  Reading one step past the stage's last is harmless:
+        // the addresses stay inside this buffer's LDS image and the values are never used.
         const int xb = r * P.WC + c;
+        const int sn = (s + 1 < nk) ? s + 1 : s;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) an[m] = Ab[m * 16 * DS + 4 * (s + 1)];
+        for (int m = 0; m < MT; ++m) an[m] = Ab[m * 16 * DS + 4 * sn];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) bn[t] = Bb[xb + (t / 3) * P.WC + (t % 3)];
+        for (int t = 0; t < 9; ++t) bn[t] = Bb[((s + 1 < nk) ? xb : 0) + (t / 3) * P.WC + (t % 3)];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -197,7 +197,7 @@ class UNetEngine:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         variant = "igemm_kernel<0,1,4>" if m <= 64 else "igemm_kernel<0,2,2>"
-        self.kernel_log.append((variant, 2.0 * m * k_ch * 9 * n * lh * lw, ev, e))
+        self.kernel_log.append((variant, 2.0 * m * k_ch * 9 * n * lh * lw, ev, e, (m, k_ch, lh, lw)))
 
     def _pad_off(self, lvl: int) -> Tuple[int, int]:
         # F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet.py:43-47)

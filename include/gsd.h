@@ -72,12 +72,14 @@ const char* gsd_last_error(void);
 int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
 
 /* ---- weight re-layouts (cheap, once per optimiser step) ----------------------------------- */
-/* mode 0: conv3x3 forward   W[Co][Ci][3][3]      -> Wt[(ci*9+t)][Mpad]       (k-major, co contiguous)
- * mode 1: conv3x3 dgrad     W[Co][Ci][3][3]      -> Wt[(co*9+t)][Mpad]  with tap flipped, m = ci
- * mode 2: convT   forward   W[Ci][Co][2][2]      -> Wt[ci][Mpad]            m = co*4+kh*2+kw
- * mode 3: convT   dgrad     W[Ci][Co][2][2]      -> Wt[(co*4+kh*2+kw)][Mpad]  m = ci
- * Rows are padded with zeros to a multiple of 4 channels (mode 0/1: 4*9 rows), Mpad is M rounded
- * up to 64.  gsd_weight_layout_size returns rows*Mpad (elements). */
+/* mode 0: conv3x3 forward   W[Co][Ci][3][3]  -> k = ci*9+t,           m = co
+ * mode 1: conv3x3 dgrad     W[Co][Ci][3][3]  -> k = co*9+(8-t) flipped, m = ci
+ * mode 2: convT   forward   W[Ci][Co][2][2]  -> k = ci,               m = co*4+kh*2+kw
+ * mode 3: convT   dgrad     W[Ci][Co][2][2]  -> k = co*4+kh*2+kw,     m = ci
+ * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM+16] with BM = 64 (M <= 64) or 128, so one
+ * K-chunk of one m-block is a contiguous, bank-padded LDS image; modes 2/3 are [k row][M rounded up to 64].
+ * k rows are zero-padded to whole K-chunks. gsd_weight_layout_size returns the element count; the buffer
+ * must be 16-byte aligned. */
 int64_t gsd_weight_layout_size(int mode, int Co, int Ci);
 int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream);
 
