@@ -117,7 +117,7 @@ def main():
 
     if rank == 0:
         # dominant kernel: the 128x128-tile conv3x3 implicit GEMM (forward + dgrad of every layer with >64 out channels)
-        dom = "igemm_kernel<0,2,2>"
+        dom = "conv3x3_dma_kernel<2,2>"
         flops = sum(f for v, f, _, _, _ in klog if v == dom)
         ms = sum(a.elapsed_time(b) for v, _, a, b, _ in klog if v == dom)
         launches = sum(1 for v, _, _, _, _ in klog if v == dom)

@@ -24,7 +24,7 @@ __device__ const float gsd_pad_c3[2] = {0.f, __builtin_nanf("")};
 struct Conv3Params {
   SrcD src0, src1;
   DstD dst0, dst1;
-  const float* wt;   // [mblocks][nchunks*36][BM+16]
+  const float* wt;   // [mblocks][nchunks*36][BM], columns permuted so a lane's 4 m-tiles are one float4
   float* partials;
   int Cin, Cout, Mpad, nchunks, mblocks;
   int N, H, W;
@@ -35,7 +35,7 @@ template <int WM, int WN>
 __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
   constexpr int MT = 4, NT = 4;
   constexpr int BM = WM * 64;
-  constexpr int WS = BM + 16;        // == 16 (mod 32): the 4 k-rows of one ds_read_b32 hit disjoint banks
+  constexpr int WS = BM;             // unpadded rows: conflict-free for the ds_read_b128 A fetch (9*WS == 0 mod 64 banks)
   constexpr int WTILE = 36 * WS;     // floats per chunk
   constexpr int W4 = WTILE / 4;      // float4s per chunk
   constexpr int NWI = (W4 + 255) / 256;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int a_lane = wm * 64 + l16;
+  const int a_lane = wm * 64 + l16 * 4;
   float sc_n, sh_n, lo_n;
   issue_dma(0, 0);
   load_affine(0, sc_n, sh_n, lo_n);
@@ -175,8 +175,9 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
       const int koff = (s / 3) * P.WC + (s % 3);
       const int arow = j * 9 + s;
       float a[MT], b[NT];
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&Wc[arow * WS + a_lane]);   // out channels m*16+l16, m = 0..3
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = Wc[arow * WS + a_lane + m * 16];
+      for (int m = 0; m < MT; ++m) a[m] = av[m];
 #pragma unroll
       for (int t = 0; t < NT; ++t) b[t] = fmaxf(fmaf(Wc[baddr[t] + koff], sc, sh), lo);
 #pragma unroll
@@ -363,7 +364,7 @@ extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Ci
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: halo window too large");
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
-  const size_t lds = (size_t)2 * (36 * (pl.BM + 16) + 4 * P.PS) * sizeof(float);
+  const size_t lds = (size_t)2 * (36 * pl.BM + 4 * P.PS) * sizeof(float);
   if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);
   return launch<2, 2>(P, (int)grid, lds, (hipStream_t)stream);
 }

@@ -42,8 +42,10 @@ extern "C" int gsd_selftest_mfma(const float* a, const float* b, float* out, voi
 // ---------------------------------------------------------------------------------------------
 // weight re-layouts
 // ---------------------------------------------------------------------------------------------
-// modes 0/1 (conv3x3): tiled for the LDS-DMA kernel: [mblock][k row][BM+16], BM = 64 if M <= 64 else 128, so that
-//   one K-chunk of one m-block is ONE contiguous, already bank-padded LDS image (36 x (BM+16) floats).
+// modes 0/1 (conv3x3): tiled for the LDS-DMA kernel: [mblock][k row][BM], BM = 64 if M <= 64 else 128, so that
+//   one K-chunk of one m-block is ONE contiguous LDS image (36 x BM floats).  Inside every group of 64 columns
+//   (one wave's output channels) the order is permuted: storage slot l*4+m holds column m*16+l, so the four
+//   MFMA A operands of a lane (its 4 m-tiles) are one aligned float4 in LDS.
 // modes 2/3 (convT): plain [k row][Mpad].
 static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, int* pitch, int* mblocks) {
   switch (mode) {
@@ -54,7 +56,7 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
   }
   if (mode <= 1) {
     *BM = *M <= 64 ? 64 : 128;
-    *pitch = *BM + 16;
+    *pitch = *BM;
     *mblocks = ceil_div(*M, *BM);
   } else {
     *BM = round_up(*M, 64);
@@ -76,7 +78,11 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
     const long long t = e / pitch;
     const int k = (int)(t % rows);
     const int mb = (int)(t / rows);
-    const int m = mb * BM + col;
+    int m = mb * BM + col;
+    if (mode <= 1) {  // un-permute: slot (l*4 + t) of a 64-column group holds column t*16 + l
+      const int slot = col & 63;
+      m = mb * BM + (col & ~63) + (slot & 3) * 16 + (slot >> 2);
+    }
     float v = 0.f;
     if (col < BM && m < M) {
       if (mode == 0) {

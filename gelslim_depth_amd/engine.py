@@ -196,7 +196,7 @@ class UNetEngine:
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        variant = "igemm_kernel<0,1,4>" if m <= 64 else "igemm_kernel<0,2,2>"
+        variant = "conv3x3_dma_kernel<1,4>" if m <= 64 else "conv3x3_dma_kernel<2,2>"
         self.kernel_log.append((variant, 2.0 * m * k_ch * 9 * n * lh * lw, ev, e, (m, k_ch, lh, lw)))
 
     def _pad_off(self, lvl: int) -> Tuple[int, int]:

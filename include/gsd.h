@@ -76,8 +76,9 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * mode 1: conv3x3 dgrad     W[Co][Ci][3][3]  -> k = co*9+(8-t) flipped, m = ci
  * mode 2: convT   forward   W[Ci][Co][2][2]  -> k = ci,               m = co*4+kh*2+kw
  * mode 3: convT   dgrad     W[Ci][Co][2][2]  -> k = co*4+kh*2+kw,     m = ci
- * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM+16] with BM = 64 (M <= 64) or 128, so one
- * K-chunk of one m-block is a contiguous, bank-padded LDS image; modes 2/3 are [k row][M rounded up to 64].
+ * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM] with BM = 64 (M <= 64) or 128, columns
+ * permuted inside each 64-group (slot l*4+t = column t*16+l), so one K-chunk of one m-block is a contiguous LDS
+ * image whose A operands are aligned float4s; modes 2/3 are [k row][M rounded up to 64].
  * k rows are zero-padded to whole K-chunks. gsd_weight_layout_size returns the element count; the buffer
  * must be 16-byte aligned. */
 int64_t gsd_weight_layout_size(int mode, int Co, int Ci);
