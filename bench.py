@@ -27,12 +27,29 @@ H, W = 320, 427
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: min(affinity mask, cgroup quota, logical CPUs)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     """The reference's CPU path (its torch-operator sequence, oracle/torch_cpu_path.py) timed on this box's host
     cores on a bounded sample of the same workload: full train steps at 320x427, batch 2."""
     from gelslim_depth_amd import synth
     from oracle import torch_cpu_path as ot      # cpu_baseline leg only
-    cores = torch.get_num_threads()
+    cores = host_cores()
+    torch.set_num_threads(cores)
     st = synth.make_state(3, 1, DIMS, 0, "conditioned")
     b = 2
     x, t = synth.make_batch(b, H, W, 1)
@@ -135,6 +152,13 @@ def main():
                 print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
                       (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json)
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            if tj.get("kernel") == dom and B == 32:
+                traffic = round(float(tj["hbm_bytes_per_launch"]))
+        except (OSError, ValueError, KeyError):
+            pass
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "train frames/sec (320x427) at batch 32",
@@ -155,7 +179,7 @@ def main():
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6)},
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
                          "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
