@@ -87,9 +87,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("GSD_FORCE_SYNC"):
         import torch.distributed as dist
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"      # keep stdout to the ONE JSON line (RCCL prints its version banner there)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
 
@@ -110,7 +115,7 @@ def main():
     tgt = -0.9 * torch.rand((B, 1, H, W), device=dev, generator=g)         # U(-0.9,0] (normalised depth)
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -188,7 +193,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -10,6 +10,7 @@ all-reduced as soon as the block is done, overlapping the rest of backward.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -44,18 +45,19 @@ class GradSync:
         self.group = group
         self.overlap = overlap
         self.world = dist.get_world_size(group)
+        self.force = bool(os.environ.get("GSD_FORCE_SYNC"))   # exercise the collectives with one rank
         self._works: List = []
         self._done: List[str] = []
 
     def on_block_done(self, tag: str) -> None:
         self._done.append(tag)
-        if self.world > 1 and self.overlap and tag in self.buckets:
+        if (self.world > 1 or self.force) and self.overlap and tag in self.buckets:
             lo, hi = self.buckets[tag]
             self._works.append(self.dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True))
 
     def finish(self) -> None:
         """After backward: every bucket has been summed when this returns (stream-ordered for NCCL)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             if self.overlap:
                 missing = [t for t in self.buckets if t not in self._done]
                 for t in missing:          # a block the schedule did not announce: reduce it now

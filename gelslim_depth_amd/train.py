@@ -17,6 +17,7 @@ fused step does not test for NaN; `last_loss` can be inspected by the caller.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -119,7 +120,7 @@ class TrainStep:
         if sync_bn and self.world > 1:
             eng.sync_fn = lambda t: self.dist.all_reduce(t, group=self.pg)
         self.sync = None
-        if self.world > 1:
+        if self.world > 1 or (process_group is not None and os.environ.get("GSD_FORCE_SYNC")):   # 2nd: 1-rank rehearsal
             from .distributed import GradSync, broadcast_state, make_buckets
             broadcast_state(self.p_flat, [b for _, b in model.named_buffers()], group=self.pg)
             if self.ema_flat is not None:
