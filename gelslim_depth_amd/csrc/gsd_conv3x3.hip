@@ -18,6 +18,8 @@
 // Wave tile 64 (m) x 64 (pixels) = 4x4 MFMA tiles; block = 4 waves: 64x256 for M <= 64, 128x128 otherwise.
 #include "gsd_common.h"
 
+#include <cstdlib>
+
 
 __device__ const float gsd_pad_c3[2] = {0.f, __builtin_nanf("")};
 
@@ -364,7 +366,9 @@ extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Ci
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: halo window too large");
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
-  const size_t lds = (size_t)2 * (36 * pl.BM + 4 * P.PS) * sizeof(float);
+  size_t lds = (size_t)2 * (36 * pl.BM + 4 * P.PS) * sizeof(float);
+  static const int lds_min = getenv("GSD_CONV_LDS_MIN") ? atoi(getenv("GSD_CONV_LDS_MIN")) : 0;   // tuning: cap blocks/CU
+  if ((size_t)lds_min > lds) lds = lds_min;
   if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);
   return launch<2, 2>(P, (int)grid, lds, (hipStream_t)stream);
 }
