@@ -75,6 +75,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Logical block id such that every XCD (blocks b, b+8, b+16, ... share one) owns a contiguous id range.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // sum over the 16 lanes that share lane>>4 (one MFMA column group)
 __device__ __forceinline__ float reduce16(float v) {
   v += __shfl_xor(v, 1, 64);

@@ -17,6 +17,10 @@
 
 #include <cstdlib>
 
+#ifndef GSD_WG_SCHED
+#define GSD_WG_SCHED 2   // 0: sched_barrier fences around the MFMA burst, 1: sched_group_barrier interleave, 2: hipcc's own order (fastest at 2 waves/SIMD)
+#endif
+
 struct WgradParams {
   SrcD a0, a1;  // B operand (activation)
   SrcD dy;      // A operand (gradient, plain)
@@ -210,23 +214,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
 // -------------------------------------------------------------------------------------------------
 __device__ const float gsd_pad[2] = {0.f, __builtin_nanf("")};
 
+// NBUF 1: one LDS image, 4 waves, two blocks per CU.   NBUF 2: two images, 4 waves, one block per CU.
+// NBUF 3: two images, 8 waves in two groups that SWAP ROLES every stage: one group multiplies stage s out of image
+//         s&1 while the other issues the DMA of stage s+1 into the other image and waits for it; the barrier at
+//         the end of the stage swaps them.  Loads never interrupt a multiplying wave, and the alternation is
+//         enforced instead of being left to how two independent blocks happen to drift (NBUF 1).  Each group
+//         accumulates the stages of its parity and writes its own slab.
 template <int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void wgrad3x3_dma_kernel(const WgradParams P) {
+__global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgrad3x3_dma_kernel(const WgradParams P) {
   constexpr int MT = 4, NW = WM * WN;
   constexpr int BMw = WM * 64, BNw = WN * 16, DS = 66;
-  static_assert(NW == 4, "4 waves");
+  constexpr bool SWAP = NBUF == 3;
+  static_assert(NW == 4, "4 waves per group");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.PS;
   const int BUF = BMw * DS + BNw * XS;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3;        // role inside the group: MFMA sub-tile and share of the DMA work
+  const int grp = wave8 >> 2;        // 0 / 1 (always 0 unless SWAP)
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane >> 4, l16 = lane & 15;
 
+  // XCD-aware block order: the blocks of one split (same pixel range, different (m,n) tiles) read the same dy /
+  // activation tiles, so they should share an L2.  Hardware deals blocks round-robin over the 8 XCDs (b and b+8
+  // share one): give each XCD a contiguous range of logical ids (bijective for any grid size).  Speed only.
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int per_split = P.mblocks * P.nblocks;
-  const int split = blockIdx.x / per_split;
-  const int rem = blockIdx.x - split * per_split;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
   const int mb = rem % P.mblocks, nb = rem / P.mblocks;
   const int m0 = mb * BMw, n0 = nb * BNw;
   const int s_begin = (int)((long long)split * P.stages_total / P.splits);
@@ -311,19 +328,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void wgrad3x3_dma_kernel(co
   const int a_off = (wm * 64 + l16) * DS + j;
   const int b_off = BMw * DS + (wn * 16 + l16) * XS + j;
 
-  // NBUF == 2: the DMA of stage s+1 flies while stage s is multiplied (one block per CU).
-  // NBUF == 1: one LDS image per block, two blocks per CU: a block's DMA issue + flight is covered by the
-  //            other block's MFMAs (block-level ping-pong), which also hides the DMA *issue* cost.
-  if (NBUF == 2 && s_begin < s_end) issue_dma(s_begin, 0);
-  for (int stage = s_begin; stage < s_end; ++stage) {
-    const int cur = NBUF == 2 ? (stage - s_begin) & 1 : 0;
-    __syncthreads();  // NBUF 2: this stage's DMA has landed, everyone left the other buffer; NBUF 1: everyone left the buffer
-    if (NBUF == 2) {
-      if (stage + 1 < s_end) issue_dma(stage + 1, cur ^ 1);
-    } else {
-      issue_dma(stage, 0);
-      __syncthreads();  // vmcnt(0) + barrier: the image is complete
-    }
+  auto compute = [&](int cur) {
     const float* Ab = smem + cur * BUF + a_off;
     const float* Bb = smem + cur * BUF + b_off;
     int r = 0, c = 0;
@@ -354,15 +359,58 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void wgrad3x3_dma_kernel(co
 #pragma unroll
         for (int t = 0; t < 9; ++t) bn[t] = Bb[((s + 1 < nk) ? xb : 0) + (t / 3) * P.WC + (t % 3)];
       }
+#if GSD_WG_SCHED == 0
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+#if GSD_WG_SCHED == 0
       __builtin_amdgcn_sched_barrier(0);
+#elif GSD_WG_SCHED == 1
+      // one MFMA, then a little of everything else: VALU / LDS reads issue in the shadow of the 32-cycle MFMAs
+#pragma unroll
+      for (int g = 0; g < 13; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      }
+#pragma unroll
+      for (int g = 0; g < 23; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+#endif
+    }
+  };
+
+  const int nst = s_end - s_begin;
+  if constexpr (SWAP) {
+    if (grp == 1 && nst > 0) issue_dma(s_begin, 0);
+    __syncthreads();
+    for (int it = 0; it < nst; ++it) {
+      const int cur = it & 1;
+      if (grp == cur) compute(cur);
+      else if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+      __syncthreads();  // the loaders' vmcnt(0) + barrier: image cur^1 is complete, image cur is free; roles swap
+    }
+  } else {
+    if (NBUF == 2 && nst > 0) issue_dma(s_begin, 0);
+    for (int it = 0; it < nst; ++it) {
+      const int cur = NBUF == 2 ? it & 1 : 0;
+      __syncthreads();  // NBUF 2: this stage's DMA has landed, everyone left the other image; NBUF 1: everyone left the image
+      if (NBUF == 2) {
+        if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+      } else {
+        issue_dma(s_begin + it, 0);
+        __syncthreads();  // vmcnt(0) + barrier: the image is complete
+      }
+      compute(cur);
     }
   }
 
+  const int slab = SWAP ? split * 2 + grp : split;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 2 : 1) void wgrad3x3_dma_kernel(co
         if (col < P.Ncols) {
 #pragma unroll
           for (int t = 0; t < 9; ++t)
-            P.slabs[(((size_t)split * 9 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
+            P.slabs[(((size_t)slab * 9 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
         }
       }
     }
@@ -488,7 +536,8 @@ WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
   if (splits > 2048) splits = 2048;
   if (splits < 1) splits = 1;
   p.splits = splits;
-  p.slab_elems = (int64_t)splits * (mode == 0 ? 9 : 1) * M * Ncols;
+  // conv3x3: the role-swap kernel writes two slabs per split (one per wave group)
+  p.slab_elems = (int64_t)splits * (mode == 0 ? 18 : 1) * M * Ncols;
   return p;
 }
 
@@ -531,7 +580,7 @@ int launch_dma(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
     attr_done = true;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: LDS tile %zu B too large", lds);
-  hipLaunchKernelGGL((wgrad3x3_dma_kernel<WM, WN, NBUF>), dim3(grid), dim3(256), lds, st, P);
+  hipLaunchKernelGGL((wgrad3x3_dma_kernel<WM, WN, NBUF>), dim3(grid), dim3(NBUF == 3 ? 512 : 256), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad");
   return GSD_OK;
 }
@@ -580,22 +629,26 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
     GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
                 "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
   static const bool use_old = getenv("GSD_WGRAD_OLD") != nullptr;
+  static const int wmode = getenv("GSD_WGRAD_MODE") ? atoi(getenv("GSD_WGRAD_MODE")) : 1;   // 1 (default, fastest) / 2 / 3: see kernel
+  const int nslabs = (!use_old && wmode == 3) ? 2 * pl.splits : pl.splits;
   int rc;
   if (use_old) {
     rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
                  : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
   } else {
-    static const bool one_buf = getenv("GSD_WGRAD_NBUF2") == nullptr;   // default: one LDS image, two blocks per CU
-    if (one_buf)
+    if (wmode == 1)
       rc = pl.wide ? launch_dma<1, 4, 1>(P, grid, lds, (hipStream_t)stream) : launch_dma<2, 2, 1>(P, grid, lds, (hipStream_t)stream);
-    else
+    else if (wmode == 2)
       rc = pl.wide ? launch_dma<1, 4, 2>(P, grid, 2 * lds, (hipStream_t)stream)
                    : launch_dma<2, 2, 2>(P, grid, 2 * lds, (hipStream_t)stream);
+    else
+      rc = pl.wide ? launch_dma<1, 4, 3>(P, grid, 2 * lds, (hipStream_t)stream)
+                   : launch_dma<2, 2, 3>(P, grid, 2 * lds, (hipStream_t)stream);
   }
   if (rc) return rc;
   const long long per = 9LL * Cout * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-  hipLaunchKernelGGL((wgrad_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits,
+  hipLaunchKernelGGL((wgrad_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, nslabs,
                      Cout, Cin);
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad reduce");
   return GSD_OK;
