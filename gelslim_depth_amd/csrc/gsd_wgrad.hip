@@ -478,26 +478,38 @@ __global__ void sum_planes_stage2(const float* __restrict__ ws, int K, int G, fl
 namespace {
 
 void choose_wgrad_tile(int H, int W, int* TH, int* TW) {
-  long best = -1;
-  int bh = 1, bw = 4;
-  for (int tw = 4; tw <= 64; tw += 4) {
-    int th = 64 / tw;
-    if (th > H) th = H;
-    while (th > 1 && (th + 2) * (tw + 2) > 256) --th;
-    if ((th + 2) * (tw + 2) > 256) continue;
-    const int ty = ceil_div(H, th);
-    th = ceil_div(H, ty);
-    const long stages = (long)ty * ceil_div(W, tw);
-    // cost: MFMA work ~ stages * th*tw (k-steps) ; prefer fewer wasted pixel slots, then wider rows
-    const long cost = stages * (long)(th * tw) * 1000 + stages * 10 - tw;
-    if (best < 0 || cost < best) {
-      best = cost;
-      bh = th;
-      bw = tw;
+  // Stage = TH x TW pixels, TH*TW <= 64, TW % 4 == 0, halo window <= 256 positions.  First the least MFMA work
+  // (stages * pixels per stage); then the WIDEST rows: a DMA instruction that covers one 256-byte row segment is
+  // measurably faster than one that covers two 128-byte segments (TH 2 x TW 32 was 13 % slower than 1 x 64 although
+  // its halo traffic is a third lower) -- the cost is per cache line touched, not per byte.
+  static const bool halo_first = getenv("GSD_WGRAD_HALO") != nullptr;
+  long min_work = -1;
+  for (int pass = 0; pass < 2; ++pass) {
+    long best = -1;
+    for (int tw = 4; tw <= 64; tw += 4) {
+      int th = 64 / tw;
+      if (th > H) th = H;
+      while (th > 1 && (th + 2) * (tw + 2) > 256) --th;
+      if ((th + 2) * (tw + 2) > 256) continue;
+      const int ty = ceil_div(H, th);
+      th = ceil_div(H, ty);
+      const long stages = (long)ty * ceil_div(W, tw);
+      const long work = stages * (long)(th * tw);
+      if (pass == 0) {
+        if (min_work < 0 || work < min_work) min_work = work;
+        continue;
+      }
+      if (work * 100 > min_work * 103) continue;
+      long cost;
+      if (halo_first) cost = stages * (long)((th + 2) * (tw + 2)) + ((tw < 32 && W >= 32) ? (1L << 40) : 0);
+      else cost = work * 1000 + stages * 10 - tw;
+      if (best < 0 || cost < best) {
+        best = cost;
+        *TH = th;
+        *TW = tw;
+      }
     }
   }
-  *TH = bh;
-  *TW = bw;
 }
 
 int plane_stride_2mod32(int n) {
