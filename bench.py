@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
+    ap.add_argument("--workload", choices=["train", "infer"], default="train",
+                    help="train: BASELINE configs[2] (the metric, default); infer: configs[1], eval-mode forward only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,14 +121,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.workload == "infer":
+        model.eval()
+
+        def one_step():
+            with torch.no_grad():
+                model(x=x)
+    else:
+        def one_step():
+            step(x, tgt)
     for _ in range(args.warmup):
-        step(x, tgt)
+        one_step()
     barrier()
     eng = model._engine
     eng.kernel_log = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(x, tgt)
+        one_step()
     barrier()
     elapsed = time.perf_counter() - t0
     klog = eng.kernel_log
@@ -166,7 +177,8 @@ def main():
             pass
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "train frames/sec (320x427) at batch 32",
+            "metric": "train frames/sec (320x427) at batch 32" if args.workload == "train"
+                      else "inference frames/sec (320x427), eval-mode forward",
             "value": round(B * world * args.steps / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -178,8 +190,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: batch-32 full train step (fwd+MSE+bwd+Adam+EMA) fp32, "
-                                   "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels",
+            "config": {"workload": ("BASELINE.json configs[2]: batch-32 full train step (fwd+MSE+bwd+Adam+EMA) fp32, "
+                                    "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels")
+                                   if args.workload == "train" else
+                                   ("BASELINE.json configs[1]: eval-mode forward fp32, 3x320x427 -> 1x320x427, "
+                                    "U-Net [64,128,256,512,1024], HIP kernels"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6)},
             "roofline": {"bound": "mfma", "kernel": dom,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
     "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _P]),
     "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "gsd_area_resize_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _F, _F, _P]),
 }
 
 

@@ -553,3 +553,43 @@ extern "C" int gsd_adam_ema(float* p, const float* g, float* m, float* v, float*
   GSD_LAUNCH_CHECK("gsd_adam_ema");
   return GSD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// inference pre/post-processing: F.interpolate(mode='area') == adaptive average pooling,
+// fused with the difference image ((a - base + 255) / 2, image_utils.py:6-10) and the per-channel affine of
+// normalize_tactile_image / denormalize_depth_image (normalization_utils.py:4-35,101-129).
+//   out[n,c,oh,ow] = A[c'] * mean_{window(oh,ow)} pre(in[n,c,h,w]) + B[c'],  c' = min(c, nab-1)
+//   window rows [floor(oh*H/OH), ceil((oh+1)*H/OH)), same for columns (ATen adaptive_avg_pool2d)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void area_resize_affine_kernel(const float* __restrict__ in, const float* __restrict__ base,
+                                                                 int C, int H, int W, float* __restrict__ out, int OH, int OW,
+                                                                 const float* __restrict__ A, const float* __restrict__ B, int nab,
+                                                                 float pre_add, float pre_mul) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= OH * OW) return;
+  const int oh = e / OW, ow = e - oh * OW;
+  const int h0 = (int)(((long long)oh * H) / OH), h1 = (int)(((long long)(oh + 1) * H + OH - 1) / OH);
+  const int w0 = (int)(((long long)ow * W) / OW), w1 = (int)(((long long)(ow + 1) * W + OW - 1) / OW);
+  const size_t plane = ((size_t)n * C + c) * H * W;
+  float s = 0.f;
+  for (int h = h0; h < h1; ++h)
+    for (int w = w0; w < w1; ++w) {
+      float v = in[plane + (size_t)h * W + w];
+      if (base != nullptr) v = (v - base[plane + (size_t)h * W + w] + pre_add) * pre_mul;
+      s += v;
+    }
+  s /= (float)((h1 - h0) * (w1 - w0));
+  const int cc = c < nab ? c : nab - 1;
+  out[((size_t)n * C + c) * OH * OW + e] = fmaf(s, A[cc], B[cc]);
+}
+extern "C" int gsd_area_resize_affine(const float* in, const float* base, int N, int C, int H, int W, float* out, int OH, int OW,
+                                      const float* A, const float* B, int nab, float pre_add, float pre_mul, void* stream) {
+  GSD_REQUIRE(in && out && A && B && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && nab > 0, GSD_ERR_BAD_ARG,
+              "gsd_area_resize_affine: bad argument");
+  GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_area_resize_affine: N, C must be <= 65535");
+  hipLaunchKernelGGL(area_resize_affine_kernel, dim3(ceil_div(OH * OW, 256), C, N), dim3(256), 0, (hipStream_t)stream, in, base,
+                     C, H, W, out, OH, OW, A, B, nab, pre_add, pre_mul);
+  GSD_LAUNCH_CHECK("gsd_area_resize_affine");
+  return GSD_OK;
+}

@@ -157,6 +157,24 @@ class TrainStep:
               "adam_ema")
         return self.loss_buf
 
+    def evaluate(self, x: torch.Tensor, use_ema: bool = True) -> torch.Tensor:
+        """Eval-mode forward under the EMA weights WITHOUT the store / copy-in / restore the reference pays per batch
+        (`with ema.average_parameters(): unet(x=...)`, train_unet.py:389-390,428-429): the kernels
+        are simply pointed at the shadow arena.  BatchNorm buffers are the live ones, as in the reference."""
+        model = self.model
+        P = model._tensor_map()
+        if use_ema and self.ema_flat is not None:
+            for k, (o, sz) in self.offsets.items():
+                P[k] = self.ema_flat[o:o + sz].view(P[k].shape)
+        with torch.no_grad():
+            return model._engine.forward(x.float().contiguous(), P, train=False)
+
+    def save_checkpoint(self, path: str, use_ema: bool = True) -> None:
+        """torch.save of the reference-layout state_dict (118 keys), EMA weights swapped in like the reference's
+        best-validation save (train_unet.py:480-483); loads into the reference's UNet with strict=True."""
+        sd = self.ema_state_dict() if use_ema else self.model.state_dict()
+        torch.save({k: v.detach().cpu() for k, v in sd.items()}, path)
+
     @property
     def last_loss(self) -> torch.Tensor:
         return self.loss_buf

@@ -182,6 +182,14 @@ int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64
                  int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float ema_decay, float grad_scale, void* stream);
 
+/* ---- inference pre/post-processing (test_utils/test_depth_estimation.py:14-20, complete_prediction.py:4-10) ---- */
+/* F.interpolate(mode='area') (image_utils.py:12-15; == adaptive_avg_pool2d) fused with the difference image
+ * (image_utils.py:6-10, when base != NULL: pre(x) = (x - base + pre_add) * pre_mul) and a per-channel affine
+ * (normalize_tactile_image / denormalize_depth_image, normalization_utils.py:4-35,101-129):
+ *   out[n,c,oh,ow] = A[min(c,nab-1)] * mean_window(pre(in)) + B[min(c,nab-1)]. */
+int gsd_area_resize_affine(const float* in, const float* base, int N, int C, int H, int W, float* out, int OH, int OW,
+                           const float* A, const float* B, int nab, float pre_add, float pre_mul, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

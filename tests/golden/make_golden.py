@@ -267,7 +267,38 @@ def g_full():
     save("gfull_b1.npz", **out)
 
 
+def g_proc():
+    """Inference pre/post-processing (test_depth_estimation.py:14-20): the reference's normalisers are imported
+    (normalization_utils.py); image_utils.py needs torchvision (absent), so its two one-liners are restated here:
+    difference image (image_utils.py:6-10) and F.interpolate(..., mode='area') (image_utils.py:12-15)."""
+    import torch.nn.functional as F
+    from gelslim_depth.processing_utils import normalization_utils as nu       # reference
+    rng = np.random.Generator(np.random.PCG64(77))
+    img = rng.uniform(0, 255, (2, 3, 41, 55)).astype(np.float32)
+    base = rng.uniform(0, 255, (2, 3, 41, 55)).astype(np.float32)
+    diff = (t(img) - t(base) + 255.0) / 2.0
+    small = F.interpolate(diff, size=(20, 27), mode="area")
+    out = {"img": img, "base": base, "diff": diff.numpy(), "small": small.numpy()}
+    out["norm_0_255_to_0_1"] = nu.normalize_tactile_image(small, "0_255_to_0_1", 0.9, None).numpy()
+    out["norm_0_255_to_-1_1"] = nu.normalize_tactile_image(small, "0_255_to_-1_1", 0.9, None).numpy()
+    params = ([10.0, 20.0, 5.0], [240.0, 200.0, 250.0], [120.0, 110.0, 130.0], [40.0, 50.0, 60.0])
+    out["norm_mean_std"] = nu.normalize_tactile_image(small, "mean_std", 0.9, params).numpy()
+    # ("min_max_to_-1_1" raises TypeError inside the reference itself: list * float at normalization_utils.py:9)
+    depth = -0.9 * rng.random((2, 1, 20, 27), dtype=np.float32)
+    out["depth_norm"] = depth
+    den = nu.denormalize_depth_image(t(depth), "min_max_to_0_-1", 0.9, (-1.9180814027786255, 0.0))
+    out["depth_denorm"] = den.numpy()
+    out["depth_full"] = F.interpolate(den, size=(41, 55), mode="area").numpy()
+    den2 = nu.denormalize_depth_image(t(depth), "mean_std", 0.9, (-2.0, 0.0, -0.7, 0.3))
+    out["depth_denorm_mean_std"] = den2.numpy()
+    save("gproc.npz", **out)
+
+
 if __name__ == "__main__":
+    if "--only-proc" in sys.argv:
+        g_proc()
+        sys.exit(0)
+    g_proc()
     g_ops()
     # G-tiny: both inits (SURVEY.md §4/§8c); 21x27 exercises H and W padding in Up (diff=1 both)
     g_net("gtiny_conditioned.npz", [4, 8, 16], 2, 21, 27, 101, "conditioned")

@@ -54,3 +54,38 @@ def test_module_refuses_cpu_tensors():
         UNet(3, 1, kernel_size=5)
     with pytest.raises(ValueError):
         UNet(3, 1, layer_dimensions=[4, 12])
+
+
+def test_checkpoint_layout_round_trips_with_the_reference_model(tmp_path):
+    """the 118-key state_dict written by the drop-in module loads into the reference's own UNet with
+    strict=True and vice versa.  Needs /root/reference (build container only); skipped where it is absent."""
+    import sys
+    import pytest
+    import torch
+    if not os.path.isdir("/root/reference/gelslim_depth"):
+        pytest.skip("reference tree not present on this machine")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    try:
+        from gelslim_depth.models.unet import UNet as RefUNet
+    finally:
+        sys.path.remove("/root/reference")
+    from gelslim_depth_amd.models.unet import UNet
+    dims = [8, 16, 32]
+    ours, ref = UNet(3, 1, layer_dimensions=dims), RefUNet(3, 1, layer_dimensions=dims)
+    sd_o, sd_r = ours.state_dict(), ref.state_dict()
+    assert list(sd_o.keys()) == list(sd_r.keys())
+    for k in sd_o:
+        assert sd_o[k].shape == sd_r[k].shape and sd_o[k].dtype == sd_r[k].dtype, k
+    assert [n for n, _ in ours.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    p = tmp_path / "w.pth"
+    torch.save(sd_o, p)
+    ref.load_state_dict(torch.load(p, map_location="cpu"), strict=True)
+    torch.save(ref.state_dict(), p)
+    ours.load_state_dict(torch.load(p, map_location="cpu"), strict=True)
+    # the reference's init loop (train_unet.py:248-250) touches the same tensors in both
+    assert [n for n, _ in ours.named_parameters() if "weight" in n] == [n for n, _ in ref.named_parameters() if "weight" in n]
+    # default initialisation statistics match torch's (kaiming-uniform bound = 1/sqrt(fan_in))
+    for (n1, p1), (n2, p2) in zip(ours.named_parameters(), ref.named_parameters()):
+        if p1.dim() == 4:
+            assert abs(p1.abs().max().item() - p2.abs().max().item()) < 0.35 * p2.abs().max().item(), n1

@@ -189,3 +189,21 @@ def test_full_size_forward_config1():
         a = col[k].astype(np.float64)
         got = np.array([a.mean(), np.abs(a).mean(), np.sqrt((a * a).sum())])
         np.testing.assert_allclose(got, v, rtol=1e-4)
+
+
+def test_processing():
+    """Inference pre/post-processing restatement vs the reference's normalisers + torch's area interpolation."""
+    from oracle import processing_ref as pr
+    g = load_golden("gproc.npz")
+    diff = pr.difference_image(g["img"], g["base"])
+    assert rel_l1(diff, g["diff"]) < 1e-6
+    small = pr.area_resize(diff, (20, 27))
+    assert rel_l1(small, g["small"]) < 1e-6
+    params = ([10.0, 20.0, 5.0], [240.0, 200.0, 250.0], [120.0, 110.0, 130.0], [40.0, 50.0, 60.0])
+    for m, p in (("0_255_to_0_1", None), ("0_255_to_-1_1", None), ("mean_std", params)):
+        assert rel_l1(pr.normalize_tactile(small, m, 0.9, p), g["norm_" + m]) < 1e-5, m
+    den = pr.denormalize_depth(g["depth_norm"], "min_max_to_0_-1", 0.9, (-1.9180814027786255, 0.0))
+    assert rel_l1(den, g["depth_denorm"]) < 1e-6
+    assert rel_l1(pr.area_resize(den, (41, 55)), g["depth_full"]) < 1e-6
+    assert rel_l1(pr.denormalize_depth(g["depth_norm"], "mean_std", 0.9, (-2.0, 0.0, -0.7, 0.3)),
+                  g["depth_denorm_mean_std"]) < 1e-6
