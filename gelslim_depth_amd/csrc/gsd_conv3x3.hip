@@ -34,7 +34,7 @@ struct Conv3Params {
 };
 
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
+__global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(const Conv3Params P) {
   constexpr int MT = 4, NT = 4;
   constexpr int BM = WM * 64;
   constexpr int WS = BM;             // unpadded rows: conflict-free for the ds_read_b128 A fetch (9*WS == 0 mod 64 banks)
@@ -100,16 +100,20 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
   const float* d_sent = P.src0.relu ? &gsd_pad_c3[1] : &gsd_pad_c3[0];
   int d_xo[2] = {xo0[0], xo0[1]};
 
-  auto issue_dma = [&](int chunk, int buf) {
+  // One DMA "slot" = one wave instruction group: slots 0..NWI-1 move the weight chunk (16 B per lane), slot NWI+ch
+  // moves input channel ch of the chunk (this wave's <= 2 position chunks).  The 9 k-steps of a chunk issue one
+  // slot each for the NEXT chunk, after their MFMAs, so DMA issue is spread between the MFMA bursts instead of
+  // sitting in front of the first one (sandbox: profiles/ubench/conv_loop2.hip, +3 %).
+  static_assert(NWI + 4 <= 10, "two slots behind each of the first five k-steps");
+  auto dma_slot = [&](int slot, int chunk, int buf) {
     float* Wb = smem + buf * BUF;
-    float* Xb = Wb + WTILE;
-    const float* wsrc = wsrc0 + (size_t)chunk * WTILE + tid * 4;
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      if (tid + i * 256 < W4) __builtin_amdgcn_global_load_lds(wsrc + i * 1024, Wb + (i * 256 + wave * 64) * 4, 16, 0, 0);
-    }
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
+    if (slot < NWI) {
+      const float* wsrc = wsrc0 + (size_t)chunk * WTILE + tid * 4;
+      if (tid + slot * 256 < W4)
+        __builtin_amdgcn_global_load_lds(wsrc + slot * 1024, Wb + (slot * 256 + wave * 64) * 4, 16, 0, 0);
+    } else if (slot < NWI + 4) {
+      const int ch = slot - NWI;
+      float* Xb = Wb + WTILE;
       if (d_left == 0 && d_seg == 0) {  // first segment exhausted: continue in the concatenated second one
         d_seg = 1;
         d_left = P.src1.C;
@@ -135,23 +139,24 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
     }
   };
 
-  // per-lane transform of the B operand for one chunk (lane's k row = channel chunk*4 + j)
-  auto load_affine = [&](int chunk, float& sc, float& sh, float& lo) {
-    const int c = chunk * 4 + j;
+  // Per-channel deferred-BN coefficients of the whole K range, once, into LDS (behind the two tile images):
+  // sAff[c] = scale, sAff[Kpad + c] = shift.  A lane then fetches its k-row's pair per chunk with two ds_reads
+  // instead of two dependent global loads.
+  const int Kpad = P.nchunks * 4;
+  float* sAff = smem + 2 * BUF;
+  for (int c = tid; c < Kpad; c += 256) {
     const bool first = c < P.src0.C;
     const SrcD& S = first ? P.src0 : P.src1;
     const int cc = first ? c : c - P.src0.C;
-    sc = 1.f;
-    sh = 0.f;
-    lo = -__builtin_inff();
-    if (c < P.Cin && cc < S.C) {
-      if (S.scale != nullptr) {
-        sc = S.scale[cc];
-        sh = S.shift[cc];
-      }
-      if (S.relu) lo = 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (c < P.Cin && cc < S.C && S.scale != nullptr) {
+      sc = S.scale[cc];
+      sh = S.shift[cc];
     }
-  };
+    sAff[c] = sc;
+    sAff[Kpad + c] = sh;
+  }
+  const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -160,17 +165,15 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
     for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int a_lane = wm * 64 + l16 * 4;
-  float sc_n, sh_n, lo_n;
-  issue_dma(0, 0);
-  load_affine(0, sc_n, sh_n, lo_n);
+#pragma unroll
+  for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
     __syncthreads();  // this chunk's DMA has landed (vmcnt(0) + barrier); everyone has left the other buffer
-    const float sc = sc_n, sh = sh_n, lo = lo_n;
-    if (chunk + 1 < P.nchunks) {
-      issue_dma(chunk + 1, cur ^ 1);
-      load_affine(chunk + 1, sc_n, sh_n, lo_n);
-    }
+    const int kc = chunk * 4 + j;   // this lane's k row (input channel) in this chunk
+    const float sc = sAff[kc], sh = sAff[Kpad + kc];
+    const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
+    const bool more = chunk + 1 < P.nchunks;
     const float* Wc = smem + cur * BUF;
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
@@ -186,6 +189,10 @@ __global__ __launch_bounds__(256) void conv3x3_dma_kernel(const Conv3Params P) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+      if (more && s < 5) {   // two slots behind each of the first five k-steps: the last four cover the DMA's flight
+        dma_slot(2 * s, chunk + 1, cur ^ 1);
+        dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+      }
     }
   }
 
@@ -366,7 +373,7 @@ extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Ci
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: halo window too large");
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
-  size_t lds = (size_t)2 * (36 * pl.BM + 4 * P.PS) * sizeof(float);
+  size_t lds = (size_t)(2 * (36 * pl.BM + 4 * P.PS) + 2 * 4 * P.nchunks) * sizeof(float);   // 2 tile images + BN coefficients
   static const int lds_min = getenv("GSD_CONV_LDS_MIN") ? atoi(getenv("GSD_CONV_LDS_MIN")) : 0;   // tuning: cap blocks/CU
   if ((size_t)lds_min > lds) lds = lds_min;
   if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);

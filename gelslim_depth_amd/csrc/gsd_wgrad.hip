@@ -223,9 +223,11 @@ __device__ const float gsd_pad[2] = {0.f, __builtin_nanf("")};
 template <int WM, int WN, int NBUF>
 __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgrad3x3_dma_kernel(const WgradParams P) {
   constexpr int MT = 4, NW = WM * WN;
-  constexpr int BMw = WM * 64, BNw = WN * 16, DS = 66;
   constexpr bool SWAP = NBUF == 3;
+  constexpr bool KSP = NBUF == 4;   // <= 16 input channels: one 64 x 16ci tile, the 4 waves take every 4th k-step
+  constexpr int BMw = WM * 64, BNw = KSP ? 16 : WN * 16, DS = 66;
   static_assert(NW == 4, "4 waves per group");
+  static_assert(!KSP || WM == 1, "k-split form is for M <= 64 tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.PS;
   const int BUF = BMw * DS + BNw * XS;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3;        // role inside the group: MFMA sub-tile and share of the DMA work
   const int grp = wave8 >> 2;        // 0 / 1 (always 0 unless SWAP)
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = KSP ? 0 : wave / WN, wn = KSP ? 0 : wave % WN;
   const int j = lane >> 4, l16 = lane & 15;
 
   // XCD-aware block order: the blocks of one split (same pixel range, different (m,n) tiles) read the same dy /
@@ -329,6 +331,25 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
   const int b_off = BMw * DS + (wn * 16 + l16) * XS + j;
 
   auto compute = [&](int cur) {
+    if constexpr (KSP) {
+      const float* Ab = smem + a_off;
+      const float* Bb = smem + b_off;
+      for (int s = wave; s < nk; s += 4) {
+        const int q0 = 4 * s;
+        const int r = q0 / P.TW, c = q0 - r * P.TW;
+        const int xb = r * P.WC + c;
+        float a[MT], b[9];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = Ab[m * 16 * DS + q0];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = fmaxf(fmaf(Bb[xb + (t / 3) * P.WC + (t % 3)], sc, sh), lo);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+      }
+      return;
+    }
     const float* Ab = smem + cur * BUF + a_off;
     const float* Bb = smem + cur * BUF + b_off;
     int r = 0, c = 0;
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
   } else {
     if (NBUF == 2 && nst > 0) issue_dma(s_begin, 0);
     for (int it = 0; it < nst; ++it) {
-      const int cur = NBUF == 2 ? it & 1 : 0;
+      const int cur = NBUF == 2 ? it & 1 : 0;   // NBUF 1 and 4: one image
       __syncthreads();  // NBUF 2: this stage's DMA has landed, everyone left the other image; NBUF 1: everyone left the image
       if (NBUF == 2) {
         if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
     }
   }
 
-  const int slab = SWAP ? split * 2 + grp : split;
+  const int slab = SWAP ? split * 2 + grp : (KSP ? split * 4 + wave : split);
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -519,6 +540,7 @@ int plane_stride_2mod32(int n) {
 }
 
 struct WgradPlan {
+  bool ksplit;  // conv3x3 with <= 16 input channels and M <= 64: one 64 x 16 tile, waves split the pixels
   bool wide;  // WM=1,WN=4 (M<=64) else WM=2,WN=2
   int BMw, BNw, mblocks, nblocks, TH, TW, tiles_y, tiles_x, tiles_flat, stages_total, splits;
   int64_t slab_elems;
@@ -527,9 +549,10 @@ struct WgradPlan {
 WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
   WgradPlan p;
   p.wide = M <= 64;
+  p.ksplit = mode == 0 && p.wide && Ncols <= 16;
   p.BMw = p.wide ? 64 : 128;
   const int WN = p.wide ? 4 : 2;
-  p.BNw = mode == 0 ? WN * 16 : WN * 64;
+  p.BNw = mode == 0 ? (p.ksplit ? 16 : WN * 16) : WN * 64;
   p.mblocks = ceil_div(M, p.BMw);
   p.nblocks = ceil_div(Ncols, p.BNw);
   p.TH = p.TW = p.tiles_y = p.tiles_x = p.tiles_flat = 0;
@@ -549,7 +572,7 @@ WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
   if (splits < 1) splits = 1;
   p.splits = splits;
   // conv3x3: the role-swap kernel writes two slabs per split (one per wave group)
-  p.slab_elems = (int64_t)splits * (mode == 0 ? 18 : 1) * M * Ncols;
+  p.slab_elems = (int64_t)splits * (mode == 0 ? (p.ksplit ? 36 : 18) : 1) * M * Ncols;
   return p;
 }
 
@@ -642,13 +665,15 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
                 "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
   static const bool use_old = getenv("GSD_WGRAD_OLD") != nullptr;
   static const int wmode = getenv("GSD_WGRAD_MODE") ? atoi(getenv("GSD_WGRAD_MODE")) : 1;   // 1 (default, fastest) / 2 / 3: see kernel
-  const int nslabs = (!use_old && wmode == 3) ? 2 * pl.splits : pl.splits;
+  const int nslabs = pl.ksplit ? 4 * pl.splits : ((!use_old && wmode == 3) ? 2 * pl.splits : pl.splits);
   int rc;
   if (use_old) {
     rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
                  : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
   } else {
-    if (wmode == 1)
+    if (pl.ksplit)
+      rc = launch_dma<1, 4, 4>(P, grid, lds, (hipStream_t)stream);
+    else if (wmode == 1)
       rc = pl.wide ? launch_dma<1, 4, 1>(P, grid, lds, (hipStream_t)stream) : launch_dma<2, 2, 1>(P, grid, lds, (hipStream_t)stream);
     else if (wmode == 2)
       rc = pl.wide ? launch_dma<1, 4, 2>(P, grid, 2 * lds, (hipStream_t)stream)
