@@ -28,6 +28,13 @@ struct Conv3Params {
   DstD dst0, dst1;
   const float* wt;   // [mblocks][nchunks*36][BM], columns permuted so a lane's 4 m-tiles are one float4
   float* partials;
+  // fused backward of relu(bn(raw)) on the destination (dgrad only): dst receives dz = d * [raw*scale+shift > 0] and
+  // the partial sums become (sum dz, sum dz*xhat); all null for a plain convolution
+  const float* bw_raw;
+  const float* bw_scale;
+  const float* bw_shift;
+  const float* bw_mean;
+  const float* bw_invstd;
   int Cin, Cout, Mpad, nchunks, mblocks;
   int N, H, W;
   int TH, TW, tiles_y, tiles_x, WR, WC, PS, NPV;
@@ -222,14 +229,30 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(const Conv3Params P
       const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
       float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
       float s1 = 0.f, s2 = 0.f;
+      if (P.bw_raw == nullptr) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (opix[t] >= 0) {
-          const float v = acc[m][t][reg];
-          s1 += v;
-          s2 = fmaf(v, v, s2);
-          const int off = first ? ooff0[t] : ooff1[t];
-          if (co_ok && off >= 0) plane[off] = v;
+        for (int t = 0; t < NT; ++t) {
+          if (opix[t] >= 0) {
+            const float v = acc[m][t][reg];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+            const int off = first ? ooff0[t] : ooff1[t];
+            if (co_ok && off >= 0) plane[off] = v;
+          }
+        }
+      } else if (co_ok) {
+        // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry
+        const float bsc = P.bw_scale[co], bsh = P.bw_shift[co], bmu = P.bw_mean[co], bis = P.bw_invstd[co];
+        const float* const rplane = P.bw_raw + (long long)n * P.dst0.ns + (long long)co * P.dst0.cs;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (opix[t] >= 0 && ooff0[t] >= 0) {
+            const float x = rplane[ooff0[t]];
+            const float dz = fmaf(x, bsc, bsh) > 0.f ? acc[m][t][reg] : 0.f;
+            plane[ooff0[t]] = dz;
+            s1 += dz;
+            s2 = fmaf(dz, (x - bmu) * bis, s2);
+          }
         }
       }
       if (P.partials != nullptr) {
@@ -329,8 +352,9 @@ extern "C" int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout) {
   return N * p.tiles_y * p.tiles_x * p.WN;
 }
 
-extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst,
-                           int ndst, float* partials, int N, int H, int W, void* stream) {
+static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                        float* partials, const float* bw_raw, const float* bw_scale, const float* bw_shift,
+                        const float* bw_mean, const float* bw_invstd, int N, int H, int W, void* stream) {
   GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3: null argument");
   GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3: nsrc/ndst must be 1 or 2");
   GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3: bad sizes");
@@ -360,6 +384,7 @@ extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Ci
   P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
   P.wt = wt;
   P.partials = partials;
+  P.bw_raw = bw_raw; P.bw_scale = bw_scale; P.bw_shift = bw_shift; P.bw_mean = bw_mean; P.bw_invstd = bw_invstd;
   P.Cin = Cin;
   P.Cout = Cout;
   P.Mpad = round_up(Cout, 64);
@@ -378,4 +403,20 @@ extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Ci
   if ((size_t)lds_min > lds) lds = lds_min;
   if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);
   return launch<2, 2>(P, (int)grid, lds, (hipStream_t)stream);
+}
+
+extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                           int ndst, float* partials, int N, int H, int W, void* stream) {
+  return conv3x3_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W,
+                      stream);
+}
+
+extern "C" int gsd_conv3x3_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                        const float* raw, const float* scale, const float* shift, const float* mean,
+                                        const float* invstd, float* partials, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(dst && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
+  return conv3x3_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream);
 }

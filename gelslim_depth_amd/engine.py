@@ -252,13 +252,19 @@ class UNetEngine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def _bn_bwd_tail(self, u: _Unit, P, G, st: int, dwout: Optional[torch.Tensor] = None) -> None:
-        """u.g holds dz and self.partials its per-block sums: finish BN backward, then dW."""
+    def _bn_bwd_tail(self, u: _Unit, P, G, st: int, dwout: Optional[torch.Tensor] = None, fused: bool = False) -> None:
+        """u.g holds dz and self.partials its per-block sums: finish BN backward, then dW.
+        fused: the partials come from gsd_conv3x3_dgrad_bnrelu (conv layout) instead of gsd_bn_bwd_reduce."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        rows = lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw)
-        check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
-              "bn_bwd_reduce_partials")
+        if fused:
+            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
+                  "bn_reduce_partials")
+        else:
+            rows = lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw)
+            check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
+                  "bn_bwd_reduce_partials")
         count = float(n * lh * lw)
         gsum = None
         if self.sync_fn is not None:
@@ -296,6 +302,20 @@ class UNetEngine:
               "conv3x3 dgrad")
         self._log_end(ev, u.cin, u.cout, n, lh, lw)
 
+    def _dgrad_fused(self, u: _Unit, prev: _Unit, P, st: int) -> None:
+        """dX of unit u straight into prev.g as dz of prev's relu(bn(.)) (+ partial sums): u's input is prev's output."""
+        n = u.raw.shape[0]
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        check(lib.gsd_weight_layout(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        s = L.make_src(u.g)
+        d = L.make_dst(prev.g)
+        ev = self._log_begin()
+        check(lib.gsd_conv3x3_dgrad_bnrelu(C.byref(s), u.wt_d.data_ptr(), u.cout, u.cin, C.byref(d), prev.raw.data_ptr(),
+                                           prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
+                                           prev.invstd.data_ptr(), self.partials.data_ptr(), n, lh, lw, st),
+              "conv3x3_dgrad_bnrelu")
+        self._log_end(ev, u.cin, u.cout, n, lh, lw)
+
     def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
         """dout: (N, n_classes, H, W) gradient of the loss w.r.t. the output.
         G: name -> tensor to receive every parameter's gradient (overwritten, not accumulated)."""
@@ -315,9 +335,8 @@ class UNetEngine:
             lvl = self.L - 1 - j
             self._bn_bwd_tail(u1, P, G, st, dwout)
             dwout = None
-            self._dgrad(u1, P, [L.make_dst(u0.g)], st)
-            self._reduce(0, u0, st)
-            self._bn_bwd_tail(u0, P, G, st)
+            self._dgrad_fused(u1, u0, P, st)
+            self._bn_bwd_tail(u0, P, G, st, fused=True)
             skip = self.enc[lvl][1]
             self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st)
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
@@ -338,9 +357,8 @@ class UNetEngine:
                 self._reduce(1, u1, st, dpool=self.dpooled[lvl + 1])
             self._bn_bwd_tail(u1, P, G, st, dwout)
             dwout = None
-            self._dgrad(u1, P, [L.make_dst(u0.g)], st)
-            self._reduce(0, u0, st)
-            self._bn_bwd_tail(u0, P, G, st)
+            self._dgrad_fused(u1, u0, P, st)
+            self._bn_bwd_tail(u0, P, G, st, fused=True)
             if self.block_done_cb is not None:
                 self.block_done_cb(f"enc{lvl}")
             if lvl > 0:

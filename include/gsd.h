@@ -94,6 +94,15 @@ int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout);
 int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout,
                 const gsd_dst* dst, int ndst, float* partials, int N, int H, int W, void* stream);
 
+/* conv3x3 dX fused with the backward of the relu(bn(raw)) that produced this convolution's INPUT: instead of
+ * da it writes dz = da * [raw*scale+shift > 0] to dst (one full (Cout,H,W) buffer with raw's strides) and the
+ * partials hold (sum dz, sum dz*xhat) per channel, layout as gsd_conv3x3 -- saves the separate
+ * gsd_bn_bwd_reduce pass (one read and one write of the tensor). aten: convolution_backward(dX) +
+ * threshold_backward + the reduction half of native_batch_norm_backward (unet.py:11-16). */
+int gsd_conv3x3_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                             const float* raw, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, float* partials, int N, int H, int W, void* stream);
+
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 2. */
 int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin, int Cout,

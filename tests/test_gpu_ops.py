@@ -349,3 +349,34 @@ def test_bad_arguments_are_refused(gsd):
     assert gsd.lib.gsd_conv3x3(src, 3, wt.data_ptr(), 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
     with pytest.raises(gsd.GsdError):
         gsd.check(gsd.lib.gsd_weight_layout(7, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 6, 9, 9, 11), (1, 64, 130, 21, 29)])
+def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, n, ci, co, h, w):
+    """gsd_conv3x3_dgrad_bnrelu == conv dX followed by gsd_bn_bwd_reduce(mode PLAIN): dz and (sum dz, sum dz*xhat)."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(co)
+    # forward unit "prev": raw (n, ci, h, w) with its BN; this conv maps ci -> co
+    raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, ci, h, w)
+    wt_ = rnd(rng, co, ci, 3, 3, scale=0.2)
+    dy = rnd(rng, n, co, h, w)
+    da, _ = on.conv3x3_bwd(a, wt_, dy)
+    dz_ref = da * (a > 0)
+    xhat = (raw.astype(np.float64) - mean[None, :, None, None]) * invstd[None, :, None, None]
+    s1_ref, s2_ref = dz_ref.astype(np.float64).sum(axis=(0, 2, 3)), (dz_ref * xhat).sum(axis=(0, 2, 3))
+    dyd, rawd = dev(dy), dev(raw)
+    vecs = [dev(v) for v in (scale, shift, mean, invstd)]
+    dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
+    rows = gsd.lib.gsd_conv3x3_partial_rows(n, h, w, ci)
+    mpad = (ci + 63) // 64 * 64
+    part = torch.zeros(rows * 2 * mpad, device="cuda")
+    wl = layout(gsd, 1, dev(wt_), co, ci)
+    s, d = gsd.make_src(dyd), gsd.make_dst(dz)
+    gsd.check(gsd.lib.gsd_conv3x3_dgrad_bnrelu(C.byref(s), wl.data_ptr(), co, ci, C.byref(d), rawd.data_ptr(),
+                                               *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, gsd.stream_ptr()))
+    assert rel_l1(dz.cpu().numpy(), dz_ref) < TOL
+    sums = torch.zeros(65 * 2 * ci, device="cuda", dtype=torch.float64)
+    gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, ci, sums.data_ptr(), gsd.stream_ptr()))
+    got = sums[:2 * ci].cpu().numpy()
+    np.testing.assert_allclose(got[:ci], s1_ref, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(got[ci:], s2_ref, rtol=2e-4, atol=2e-3)
