@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
       const bool pix_ok = p < HW;
       const int h = pix_ok ? p / P.W : 0;
       const int w = pix_ok ? p - h * P.W : 0;
-#pragma unroll 8
+#pragma unroll
       for (int i = 0; i < BMw / 8; ++i) {
         const int rr = lrow + 4 * i;  // (co_i, kh)
         const int co = (m0 >> 2) + (rr >> 1);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     } else {
       const int p = p0 + q;
       const bool pix_ok = p < HW;
-#pragma unroll 8
+#pragma unroll
       for (int i = 0; i < BNw / 4; ++i) {
         const int ch = lrow + 4 * i;
         const int c = n0 + ch;
