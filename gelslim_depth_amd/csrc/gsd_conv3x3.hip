@@ -40,9 +40,9 @@ struct Conv3Params {
   int TH, TW, tiles_y, tiles_x, WR, WC, PS, NPV;
 };
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(const Conv3Params P) {
-  constexpr int MT = 4, NT = 4;
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const Conv3Params P) {
+  constexpr int MT = 4;
   constexpr int BM = WM * 64;
   constexpr int WS = BM;             // unpadded rows: conflict-free for the ds_read_b128 A fetch (9*WS == 0 mod 64 banks)
   constexpr int WTILE = 36 * WS;     // floats per chunk
@@ -310,15 +310,18 @@ int plane_stride_16mod32(int n) {  // smallest PS >= n with PS % 32 == 16
 }
 
 struct ConvPlan {
-  bool wide;  // true: 64x256 block tile (M<=64), false: 128x128
+  bool wide;  // true: 64x256 block tile (M<=64), false: 128x128 or 128x256
+  bool big;   // 128x256 block tile (wave tile 64 x 128, 2 blocks per CU): tuning option, measured no faster than 128x128
   int BM, BN, WN, TH, TW, tiles_y, tiles_x, mblocks;
 };
 
 ConvPlan plan_conv3x3(int H, int W, int M) {
+  static const int big_min = getenv("GSD_CONV_BIG") ? atoi(getenv("GSD_CONV_BIG")) : 0;   // tuning: min H*W for 128x256
   ConvPlan p;
   p.wide = M <= 64;
+  p.big = !p.wide && big_min > 0 && H * W >= big_min;
   p.BM = p.wide ? 64 : 128;
-  p.BN = p.wide ? 256 : 128;
+  p.BN = (p.wide || p.big) ? 256 : 128;
   p.WN = p.wide ? 4 : 2;
   choose_tile(H, W, p.BN, &p.TH, &p.TW);
   p.tiles_y = ceil_div(H, p.TH);
@@ -327,11 +330,11 @@ ConvPlan plan_conv3x3(int H, int W, int M) {
   return p;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int NT>
 int launch(const Conv3Params& P, int grid, size_t lds, hipStream_t st) {
   static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<WM, WN, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       gsd_set_error("gsd_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -339,7 +342,7 @@ int launch(const Conv3Params& P, int grid, size_t lds, hipStream_t st) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<WM, WN, NT>), dim3(grid), dim3(256), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3");
   return GSD_OK;
 }
@@ -401,8 +404,9 @@ static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, 
   size_t lds = (size_t)(2 * (36 * pl.BM + 4 * P.PS) + 2 * 4 * P.nchunks) * sizeof(float);   // 2 tile images + BN coefficients
   static const int lds_min = getenv("GSD_CONV_LDS_MIN") ? atoi(getenv("GSD_CONV_LDS_MIN")) : 0;   // tuning: cap blocks/CU
   if ((size_t)lds_min > lds) lds = lds_min;
-  if (pl.wide) return launch<1, 4>(P, (int)grid, lds, (hipStream_t)stream);
-  return launch<2, 2>(P, (int)grid, lds, (hipStream_t)stream);
+  if (pl.wide) return launch<1, 4, 4>(P, (int)grid, lds, (hipStream_t)stream);
+  if (pl.big) return launch<2, 2, 8>(P, (int)grid, lds, (hipStream_t)stream);
+  return launch<2, 2, 4>(P, (int)grid, lds, (hipStream_t)stream);
 }
 
 extern "C" int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst,
