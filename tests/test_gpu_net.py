@@ -186,3 +186,25 @@ def test_batch_properties_full_resolution():
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert torch.equal(results[0][2], results[1][2])
     assert np.isfinite(results[0][0]) and np.isfinite(results[0][1])
+
+
+@pytest.mark.parametrize("h,w,dims", [(160, 213, [8, 16, 32, 64, 128]), (97, 131, [8, 16, 32]), (64, 64, [16, 32]),
+                                      (33, 470, [8, 16])])
+def test_other_resolutions_vs_oracle(h, w, dims):
+    """The model is fully convolutional: the reference ships 160x213 (config_unet_bigdata.py:29), BASELINE fixes
+    320x427.  Other sizes exercise the host-side tile choosers (odd widths, very wide rows, square images)."""
+    from oracle import unet_numpy as on
+    st = synth.make_state(3, 1, dims, h * 1000 + w, "conditioned")
+    x, tgt = synth.make_batch(2, h, w, h + w)
+    m = make_model(dims, st)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    m.eval()
+    assert rel_l1(m(x=xd).cpu().numpy(), on.UNetOracle(st).forward(x, train=False)) < 1e-4
+    m.train()
+    out = m(x=xd)
+    loss = torch.mean((out - td) ** 2)
+    loss.backward()
+    net, losses, first, _ = on.train_steps(st, x, tgt, 1)
+    assert abs(loss.item() - losses[0]) < 2e-4 * losses[0]
+    for k, p in m.named_parameters():
+        assert rel_l1(p.grad.cpu().numpy(), first["grads"][k]) < 2e-2, k
