@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json: 32)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed GLOBAL batch split over the ranks (configs[3]: 64); overrides --batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
@@ -113,6 +115,10 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     B = args.batch
+    if args.global_batch > 0:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be divisible by the number of ranks")
+        B = args.global_batch // world
     x = torch.rand((B, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
     tgt = -0.9 * torch.rand((B, 1, H, W), device=dev, generator=g)         # U(-0.9,0] (normalised depth)
 
@@ -186,7 +192,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch > 0 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
