@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["gsd_conv3x3.hip", "gsd_igemm.hip", "gsd_wgrad.hip", "gsd_pointwise.hip"]
+SOURCES = ["gsd_conv3x3.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_pointwise.hip", "gsd_dataset.hip"]
 OUT = os.path.join(CSRC, "libgsd.so")
 
 

@@ -1,16 +1,16 @@
 // gsd_wgrad.hip -- weight gradients as implicit GEMM over pixels on v_mfma_f32_16x16x4_f32 (gfx950).
 //
-//   MODE 0  conv3x3:  dW[co][ci][tap] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1]
-//           (the dW half of aten::convolution_backward for /root/reference/gelslim_depth/models/unet.py:11,14)
-//   MODE 1  convT2x2: dW[ci][co][kh][kw] = sum_{n,h,w} x[n,ci,h,w] * dy[n,co,2h+kh,2w+kw]   (unet.py:36)
+//   conv3x3:  dW[co][ci][tap] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1]      (wgrad3x3_dma_kernel)
+//             (the dW half of aten::convolution_backward for /root/reference/gelslim_depth/models/unet.py:11,14)
+//   convT2x2: dW[ci][co][kh][kw] = sum_{n,h,w} x[n,ci,h,w] * dy[n,co,2h+kh,2w+kw]      (convT_wgrad_kernel, unet.py:36)
 //
 // GEMM view: D[m][col] = sum_pixels A[m][pixel] * B[pixel][col] with the pixel index on the MFMA
-// k dimension (4 consecutive pixels of one row per instruction).  A = dy rows (MODE 1: space-to-depth
-// rows (co,kh,kw)), B = activation `a` with deferred BatchNorm+ReLU, zero padding and the two-segment
+// k dimension (4 consecutive pixels of one row per instruction).  A = dy rows (convT: space-to-depth
+// rows (co,kh,kw)), B = activation with deferred BatchNorm+ReLU, zero padding and the two-segment
 // channel concat recomputed on load, so the tensors the reference saves for backward (relu outputs,
 // padded/concatenated inputs) are never stored.
 //
-// Wave tile: 64 m-rows x (16 input channels x 9 taps) [MODE 0] or 64 x 64 [MODE 1].
+// Wave tile: 64 m-rows x (16 input channels x 9 taps) [conv3x3] or 64 x 64 [convT].
 // Reduction over pixels is split across blocks (split-K); every block writes a partial slab and a
 // second kernel sums the slabs in a fixed order => bitwise reproducible.
 #include "gsd_common.h"
@@ -27,27 +27,26 @@ struct WgradParams {
   float* slabs;
   int M, Ncols, Cact;  // M rows (Cout or Cout*4), Ncols = Cin, Cact = total channels of a0+a1
   int N, H, W;
-  int TH, TW, tiles_y, tiles_x, WR, WC, PS;  // MODE 0
-  int tiles_flat;                            // MODE 1
+  int TH, TW, tiles_y, tiles_x, WR, WC, PS;  // conv3x3
+  int tiles_flat;                            // convT
   int stages_total, splits, mblocks, nblocks;
 };
 
-template <int MODE, int WM, int WN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
-  constexpr int MT = 4;
-  constexpr int NTB = MODE == 0 ? 9 : 4;
-  constexpr int BMw = WM * 64;
-  constexpr int BNw = MODE == 0 ? WN * 16 : WN * 64;
+// ConvT2x2 dW: flat 64-pixel stages, register-staged operand tiles (A = space-to-depth dy rows (co,kh,kw),
+// B = x with the deferred BatchNorm+ReLU applied on load), wave tile 64 x 64.
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void convT_wgrad_kernel(const WgradParams P) {
+  constexpr int MT = 4, NTB = 4;
+  constexpr int BMw = WM * 64, BNw = WN * 64;
   constexpr int DS = 66;  // == 2 (mod 32): 16 rows x 2 k-pixels of a half-wave hit 32 distinct banks
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Al = smem;             // [BMw][DS]
-  float* Xl = smem + BMw * DS;  // MODE 0: [BNw][PS]; MODE 1: [BNw][DS]
+  float* Xl = smem + BMw * DS;  // [BNw][DS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int j = lane >> 4, l16 = lane & 15;
-  const int XS = MODE == 0 ? P.PS : DS;
 
   const int per_split = P.mblocks * P.nblocks;
   const int split = blockIdx.x / per_split;
@@ -64,118 +63,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
 #pragma unroll
     for (int t = 0; t < NTB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int q = tid & 63;   // loader pixel
+  const int q = tid & 63;     // loader pixel
   const int lrow = tid >> 6;  // loader row phase 0..3
 
   for (int stage = s_begin; stage < s_end; ++stage) {
-    int n, h0 = 0, w0 = 0, p0 = 0;
-    if constexpr (MODE == 0) {
-      const int tpi = P.tiles_y * P.tiles_x;
-      n = stage / tpi;
-      const int r = stage - n * tpi;
-      const int ty = r / P.tiles_x;
-      h0 = ty * P.TH;
-      w0 = (r - ty * P.tiles_x) * P.TW;
-    } else {
-      n = stage / P.tiles_flat;
-      p0 = (stage - n * P.tiles_flat) * 64;
-    }
+    const int n = stage / P.tiles_flat;
+    const int p = (stage - n * P.tiles_flat) * 64 + q;
+    const bool pix_ok = p < HW;
+    const int h = pix_ok ? p / P.W : 0;
+    const int w = pix_ok ? p - h * P.W : 0;
     __syncthreads();  // previous stage's MFMAs are done with LDS
-    // ---- A tile ------------------------------------------------------------------------------
-    if constexpr (MODE == 0) {
-      const bool qin = q < P.TH * P.TW;
-      const int r = qin ? q / P.TW : 0;
-      const int c = qin ? q - r * P.TW : 0;
-      const bool pix_ok = qin && (h0 + r) < P.H && (w0 + c) < P.W;
-      const float* base = P.dy.p + (long long)n * P.dy.ns + (long long)(h0 + r) * P.dy.W + (w0 + c);
-#pragma unroll 8
-      for (int i = 0; i < BMw / 4; ++i) {
-        const int row = lrow + 4 * i;
-        const int co = m0 + row;
-        float v = 0.f;
-        if (pix_ok && co < P.M) v = base[(long long)co * P.dy.cs];
-        Al[row * DS + q] = v;
-      }
-    } else {
-      const int p = p0 + q;
-      const bool pix_ok = p < HW;
-      const int h = pix_ok ? p / P.W : 0;
-      const int w = pix_ok ? p - h * P.W : 0;
 #pragma unroll
-      for (int i = 0; i < BMw / 8; ++i) {
-        const int rr = lrow + 4 * i;  // (co_i, kh)
-        const int co = (m0 >> 2) + (rr >> 1);
-        const int kh = rr & 1;
-        float2 v = make_float2(0.f, 0.f);
-        if (pix_ok && co < P.dy.C)
-          v = *reinterpret_cast<const float2*>(P.dy.p + (long long)n * P.dy.ns + (long long)co * P.dy.cs +
-                                               (long long)(2 * h + kh) * P.dy.W + 2 * w);
-        const int mrow = (rr >> 1) * 4 + kh * 2;
-        Al[mrow * DS + q] = v.x;
-        Al[(mrow + 1) * DS + q] = v.y;
-      }
+    for (int i = 0; i < BMw / 8; ++i) {
+      const int rr = lrow + 4 * i;  // (co_i, kh)
+      const int co = (m0 >> 2) + (rr >> 1);
+      const int kh = rr & 1;
+      float2 v = make_float2(0.f, 0.f);
+      if (pix_ok && co < P.dy.C)
+        v = *reinterpret_cast<const float2*>(P.dy.p + (long long)n * P.dy.ns + (long long)co * P.dy.cs +
+                                             (long long)(2 * h + kh) * P.dy.W + 2 * w);
+      const int mrow = (rr >> 1) * 4 + kh * 2;
+      Al[mrow * DS + q] = v.x;
+      Al[(mrow + 1) * DS + q] = v.y;
     }
-    // ---- B tile ------------------------------------------------------------------------------
-    if constexpr (MODE == 0) {
-      const bool pos_ok = tid < P.WR * P.WC;
-      const int rr = tid / P.WC;
-      const int gh = h0 - 1 + rr, gw = w0 - 1 + (tid - rr * P.WC);
-      if (pos_ok) {
-#pragma unroll 4
-        for (int ch = 0; ch < BNw; ++ch) {
-          const int c = n0 + ch;
-          const bool first = c < P.a0.C;
-          const SrcD& S = first ? P.a0 : P.a1;
-          const int cc = first ? c : c - P.a0.C;
-          const int hs = gh - S.oh, ws = gw - S.ow;
-          float v = 0.f;
-          if (c < P.Cact && cc < S.C && (unsigned)hs < (unsigned)S.H && (unsigned)ws < (unsigned)S.W) {
-            v = S.p[(long long)n * S.ns + (long long)cc * S.cs + hs * S.W + ws];
-            if (S.scale != nullptr) v = apply_affine(v, S.scale[cc], S.shift[cc], S.relu);
-            else if (S.relu) v = fmaxf(v, 0.f);
-          }
-          Xl[ch * XS + tid] = v;
-        }
-      }
-    } else {
-      const int p = p0 + q;
-      const bool pix_ok = p < HW;
 #pragma unroll
-      for (int i = 0; i < BNw / 4; ++i) {
-        const int ch = lrow + 4 * i;
-        const int c = n0 + ch;
-        float v = 0.f;
-        if (pix_ok && c < P.a0.C) {
-          v = P.a0.p[(long long)n * P.a0.ns + (long long)c * P.a0.cs + p];
-          if (P.a0.scale != nullptr) v = apply_affine(v, P.a0.scale[c], P.a0.shift[c], P.a0.relu);
-          else if (P.a0.relu) v = fmaxf(v, 0.f);
-        }
-        Xl[ch * XS + q] = v;
+    for (int i = 0; i < BNw / 4; ++i) {
+      const int ch = lrow + 4 * i;
+      const int c = n0 + ch;
+      float v = 0.f;
+      if (pix_ok && c < P.a0.C) {
+        v = P.a0.p[(long long)n * P.a0.ns + (long long)c * P.a0.cs + p];
+        if (P.a0.scale != nullptr) v = apply_affine(v, P.a0.scale[c], P.a0.shift[c], P.a0.relu);
+        else if (P.a0.relu) v = fmaxf(v, 0.f);
       }
+      Xl[ch * DS + q] = v;
     }
     __syncthreads();
-    // ---- MFMA over the stage's pixels ----------------------------------------------------------
-    const int nk = MODE == 0 ? (P.TH * P.TW) / 4 : 16;
-    int r = 0, c = 0;
     const int a_base = (wm * 64 + l16) * DS + j;
-    const int b_base = MODE == 0 ? (wn * 16 + l16) * XS + j : (wn * 64 + l16) * XS + j;
-    for (int s = 0; s < nk; ++s) {
+    const int b_base = (wn * 64 + l16) * DS + j;
+    for (int s = 0; s < 16; ++s) {
       float a[MT], b[NTB];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a[m] = Al[a_base + m * 16 * DS + 4 * s];
-      if constexpr (MODE == 0) {
-        const int xb = b_base + r * P.WC + c;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) b[t] = Xl[xb + (t / 3) * P.WC + (t % 3)];
-        c += 4;
-        if (c >= P.TW) {
-          c = 0;
-          ++r;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = Xl[b_base + t * 16 * XS + 4 * s];
-      }
+      for (int t = 0; t < NTB; ++t) b[t] = Xl[b_base + t * 16 * DS + 4 * s];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -183,7 +114,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
     }
   }
 
-  // ---- slab store: D[row = m][col = l16] ---------------------------------------------------------
+  // ---- slab store: slab[split][m][ci] ------------------------------------------------------------
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -192,12 +123,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams P) {
       if (mr < P.M) {
 #pragma unroll
         for (int t = 0; t < NTB; ++t) {
-          const int col = MODE == 0 ? (n0 + wn * 16 + l16) : (n0 + wn * 64 + t * 16 + l16);
-          if (col < P.Ncols) {
-            const size_t idx = MODE == 0 ? (((size_t)split * 9 + t) * P.M + mr) * P.Ncols + col
-                                         : ((size_t)split * P.M + mr) * P.Ncols + col;
-            P.slabs[idx] = acc[m][t][reg];
-          }
+          const int col = n0 + wn * 64 + t * 16 + l16;
+          if (col < P.Ncols) P.slabs[((size_t)split * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
         }
       }
     }
@@ -585,20 +512,20 @@ int check_plain(const gsd_src& s, const char* what) {
   return 0;
 }
 
-template <int MODE, int WM, int WN>
-int launch_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t st, const char* what) {
-  static bool attr_done = false;
+template <int WM, int WN>
+int launch_convT_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MODE, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wgrad_kernel<WM, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
-      gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+      gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return GSD_ERR_HIP;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<MODE, WM, WN>), dim3(grid), dim3(256), lds, st, P);
-  GSD_LAUNCH_CHECK(what);
+  hipLaunchKernelGGL((convT_wgrad_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");
   return GSD_OK;
 }
 
@@ -663,25 +590,19 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
   for (int i = 0; i < nsrc; ++i)
     GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
                 "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
-  static const bool use_old = getenv("GSD_WGRAD_OLD") != nullptr;
   static const int wmode = getenv("GSD_WGRAD_MODE") ? atoi(getenv("GSD_WGRAD_MODE")) : 1;   // 1 (default, fastest) / 2 / 3: see kernel
-  const int nslabs = pl.ksplit ? 4 * pl.splits : ((!use_old && wmode == 3) ? 2 * pl.splits : pl.splits);
+  const int nslabs = pl.ksplit ? 4 * pl.splits : (wmode == 3 ? 2 * pl.splits : pl.splits);
   int rc;
-  if (use_old) {
-    rc = pl.wide ? launch_wgrad<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad")
-                 : launch_wgrad<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_conv3x3_wgrad");
-  } else {
-    if (pl.ksplit)
-      rc = launch_dma<1, 4, 4>(P, grid, lds, (hipStream_t)stream);
-    else if (wmode == 1)
-      rc = pl.wide ? launch_dma<1, 4, 1>(P, grid, lds, (hipStream_t)stream) : launch_dma<2, 2, 1>(P, grid, lds, (hipStream_t)stream);
-    else if (wmode == 2)
-      rc = pl.wide ? launch_dma<1, 4, 2>(P, grid, 2 * lds, (hipStream_t)stream)
-                   : launch_dma<2, 2, 2>(P, grid, 2 * lds, (hipStream_t)stream);
-    else
-      rc = pl.wide ? launch_dma<1, 4, 3>(P, grid, 2 * lds, (hipStream_t)stream)
-                   : launch_dma<2, 2, 3>(P, grid, 2 * lds, (hipStream_t)stream);
-  }
+  if (pl.ksplit)
+    rc = launch_dma<1, 4, 4>(P, grid, lds, (hipStream_t)stream);
+  else if (wmode == 1)
+    rc = pl.wide ? launch_dma<1, 4, 1>(P, grid, lds, (hipStream_t)stream) : launch_dma<2, 2, 1>(P, grid, lds, (hipStream_t)stream);
+  else if (wmode == 2)
+    rc = pl.wide ? launch_dma<1, 4, 2>(P, grid, 2 * lds, (hipStream_t)stream)
+                 : launch_dma<2, 2, 2>(P, grid, 2 * lds, (hipStream_t)stream);
+  else
+    rc = pl.wide ? launch_dma<1, 4, 3>(P, grid, 2 * lds, (hipStream_t)stream)
+                 : launch_dma<2, 2, 3>(P, grid, 2 * lds, (hipStream_t)stream);
   if (rc) return rc;
   const long long per = 9LL * Cout * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
@@ -726,8 +647,8 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   const size_t lds = (size_t)(pl.BMw * 66 + pl.BNw * 66) * sizeof(float);
-  int rc = pl.wide ? launch_wgrad<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_convT2x2_wgrad")
-                   : launch_wgrad<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_convT2x2_wgrad");
+  int rc = pl.wide ? launch_convT_wgrad<1, 4>(P, grid, lds, (hipStream_t)stream)
+                   : launch_convT_wgrad<2, 2>(P, grid, lds, (hipStream_t)stream);
   if (rc) return rc;
   const long long per = (long long)M * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);

@@ -199,6 +199,25 @@ int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64
 int gsd_area_resize_affine(const float* in, const float* base, int N, int C, int H, int W, float* out, int OH, int OW,
                            const float* A, const float* B, int nab, float pre_add, float pre_mul, void* stream);
 
+/* ---- device-resident dataset path (gelslim_depth/datasets/general_dataset.py) ----------------- */
+/* Ingest of one object file's images into the dataset arena: finger split (the caller passes the channel view
+ * through strides; general_dataset.py:69-72), difference image (image_utils.py:6-10, when base != NULL:
+ * pre(x) = (x - base + pre_add) * pre_mul) and F.interpolate(mode='area') (image_utils.py:12-15) in one pass.
+ * dtype: 0 = float32, 1 = uint8 source (strides in ELEMENTS). out is contiguous (N,C,OH,OW) float32. */
+int gsd_ingest_images(const void* in, const void* base, int dtype, int N, int C, int H, int W, int64_t in_n_stride,
+                      int64_t in_c_stride, int64_t base_n_stride, int64_t base_c_stride, float* out, int OH, int OW,
+                      float pre_add, float pre_mul, void* stream);
+/* Per-channel {min, max, mean, unbiased std} over x (N,C,HW) -> out[4*C] doubles
+ * (calculate_image_normalization_params / calculate_depth_normalization_params, general_dataset.py:199-220).
+ * workspace: gsd_channel_stats_workspace(C) doubles. Deterministic (fixed reduction order). */
+int64_t gsd_channel_stats_workspace(int C);
+int gsd_channel_stats(const float* x, int64_t N, int C, int64_t HW, double* out, double* workspace, void* stream);
+/* Batch assembly (__getitem__ + normalize_sample, general_dataset.py:222-236, behind DataLoader's shuffle):
+ *   out[b,c,:] = A[min(c,nab-1)] * src[idx[b],c,:] + B[min(c,nab-1)],  src (M,C,HW), idx int64[B] on the device.
+ * An index outside [0,M) fills its row with NaN (never reads out of bounds). */
+int gsd_gather_affine(const float* src, const int64_t* idx, int64_t M, int B, int C, int64_t HW, const float* A,
+                      const float* Bc, int nab, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -294,11 +294,45 @@ def g_proc():
     save("gproc.npz", **out)
 
 
+def g_dataset():
+    """Dataset path (general_dataset.py): GeneralDataset imports torchvision (absent) so the class glue comes from
+    oracle/dataset_ref.py (a restatement of its text) -- but run HERE with the reference's own normalisers
+    (normalization_utils.py, importable) injected, so the normalised samples are the reference's arithmetic."""
+    import torch
+    from gelslim_depth.processing_utils import normalization_utils as nu       # reference
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import dataset_ref as dr
+    out = {}
+    for tag, kw in (("a", dict(use_difference_image=True, image_normalization_method="0_255_to_0_1",
+                               depth_normalization_method="min_max_to_0_-1", norm_scale=0.9,
+                               max_datapoints_per_object=5)),
+                    ("b", dict(use_difference_image=False, image_normalization_method="mean_std",
+                               depth_normalization_method="mean_std", norm_scale=1.0, separate_fingers=False))):
+        torch.manual_seed(7)
+        ds = dr.DatasetOracle(dr.synthetic_objects(11, [3, 4]), dr.synthetic_objects(12, [2]),
+                              normalizers=(nu.normalize_tactile_image, nu.normalize_depth_image), **kw)
+        out[tag + "_tactile_raw"] = ds.entire_dataset["tactile_image"].numpy()
+        out[tag + "_depth_raw"] = ds.entire_dataset["depth_image"].numpy()
+        out[tag + "_object_index"] = ds.entire_dataset["object_index"].numpy()
+        out[tag + "_depth_params"] = np.array(ds.depth_normalization_parameters, np.float64)
+        out[tag + "_image_params"] = np.array(ds.image_normalization_parameters, np.float64)
+        samples = [ds[i] for i in range(len(ds))]
+        out[tag + "_tactile"] = np.stack([s["tactile_image"].numpy() for s in samples])
+        out[tag + "_depth"] = np.stack([s["depth_image"].numpy() for s in samples])
+        torch.manual_seed(21)
+        out[tag + "_order"] = np.concatenate([b.numpy() for b in dr.loader_order(len(ds), 4)])
+    save("gdataset.npz", **out)
+
+
 if __name__ == "__main__":
     if "--only-proc" in sys.argv:
         g_proc()
         sys.exit(0)
+    if "--only-dataset" in sys.argv:
+        g_dataset()
+        sys.exit(0)
     g_proc()
+    g_dataset()
     g_ops()
     # G-tiny: both inits (SURVEY.md §4/§8c); 21x27 exercises H and W padding in Up (diff=1 both)
     g_net("gtiny_conditioned.npz", [4, 8, 16], 2, 21, 27, 101, "conditioned")

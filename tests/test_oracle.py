@@ -207,3 +207,45 @@ def test_processing():
     assert rel_l1(pr.area_resize(den, (41, 55)), g["depth_full"]) < 1e-6
     assert rel_l1(pr.denormalize_depth(g["depth_norm"], "mean_std", 0.9, (-2.0, 0.0, -0.7, 0.3)),
                   g["depth_denorm_mean_std"]) < 1e-6
+
+
+DATASET_CASES = (("a", dict(use_difference_image=True, image_normalization_method="0_255_to_0_1",
+                            depth_normalization_method="min_max_to_0_-1", norm_scale=0.9, max_datapoints_per_object=5)),
+                 ("b", dict(use_difference_image=False, image_normalization_method="mean_std",
+                            depth_normalization_method="mean_std", norm_scale=1.0, separate_fingers=False)))
+
+
+@pytest.mark.parametrize("tag,kw", DATASET_CASES)
+def test_dataset_oracle(tag, kw):
+    """oracle/dataset_ref.py with its OWN normalisers reproduces the fixture made with the reference's normalisers."""
+    from oracle import dataset_ref as dr
+    g = load_golden("gdataset.npz")
+    torch.manual_seed(7)
+    ds = dr.DatasetOracle(dr.synthetic_objects(11, [3, 4]), dr.synthetic_objects(12, [2]), **kw)
+    assert np.array_equal(ds.entire_dataset["object_index"].numpy(), g[tag + "_object_index"])
+    assert np.array_equal(ds.entire_dataset["tactile_image"].numpy(), g[tag + "_tactile_raw"])
+    assert np.allclose(np.array(ds.depth_normalization_parameters), g[tag + "_depth_params"], rtol=0, atol=0)
+    assert np.allclose(np.array(ds.image_normalization_parameters), g[tag + "_image_params"], rtol=0, atol=0)
+    tac = np.stack([ds[i]["tactile_image"].numpy() for i in range(len(ds))])
+    dep = np.stack([ds[i]["depth_image"].numpy() for i in range(len(ds))])
+    assert np.abs(tac - g[tag + "_tactile"]).max() <= 1e-6
+    assert np.abs(dep - g[tag + "_depth"]).max() <= 1e-6
+    torch.manual_seed(21)
+    assert np.array_equal(np.concatenate([b.numpy() for b in dr.loader_order(len(ds), 4)]), g[tag + "_order"])
+
+
+def test_device_loader_order_equals_torch_dataloader():
+    """DeviceLoader draws its permutation the way torch's RandomSampler does (host logic, no GPU needed)."""
+    from gelslim_depth_amd.dataset import DeviceLoader
+    g = load_golden("gdataset.npz")
+
+    class Stub:
+        device = "cpu"
+
+        def __len__(self):
+            return 14
+    torch.manual_seed(21)
+    assert np.array_equal(DeviceLoader(Stub(), 4, shuffle=True).order().numpy(), g["a_order"])
+    assert np.array_equal(DeviceLoader(Stub(), 4, shuffle=False).order().numpy(), np.arange(14))
+    assert len(DeviceLoader(Stub(), 4)) == 4 and len(DeviceLoader(Stub(), 4, drop_last=True)) == 3
+    assert len(DeviceLoader(Stub(), 4, world_size=2)) == 2
