@@ -32,6 +32,11 @@ class gsd_dst(C.Structure):
                 ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
 
 
+class gsd_nhwc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("pitch", C.c_int64),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -39,8 +44,10 @@ _F = C.c_float
 _D = C.c_double
 _SRC = C.POINTER(gsd_src)
 _DST = C.POINTER(gsd_dst)
+_NHWC = C.POINTER(gsd_nhwc)
+_IP = C.POINTER(C.c_int)
 
-# name -> (restype, argtypes); mirrors include/gsd.h one to one (tests check every symbol loads)
+# name -> (restype, argtypes); mirrors include/gsd.h and include/gsd_bf16.h one to one (tests check every symbol loads)
 SIGNATURES = {
     "gsd_version": (C.c_char_p, []),
     "gsd_last_error": (C.c_char_p, []),
@@ -74,6 +81,22 @@ SIGNATURES = {
     "gsd_channel_stats_workspace": (_L, [_I]),
     "gsd_channel_stats": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "gsd_gather_affine": (_I, [_P, _P, _L, _I, _I, _L, _P, _P, _I, _P, _P]),
+    # ---- include/gsd_bf16.h
+    "gsd_bf16_conv_mpad": (_I, [_I]),
+    "gsd_bf16_conv_partial_rows": (_I, [_I, _I, _I, _I]),
+    "gsd_bf16_conv3x3": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P]),
+    "gsd_bf16_conv_dense": (_I, [_NHWC, _P, _NHWC, _I, _I, _I, _I, _IP, _IP, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gsd_bf16_weight_image_size": (_L, [_I, _I, _I]),
+    "gsd_bf16_weight_image": (_I, [_I, _P, _I, _I, _P, _P]),
+    "gsd_bf16_im2col3x3": (_I, [_P, _I, _I, _I, _I, _NHWC, _P]),
+    "gsd_bf16_bn_apply": (_I, [_NHWC, _P, _P, _NHWC, _I, _P]),
+    "gsd_bf16_maxpool2": (_I, [_NHWC, _NHWC, _P]),
+    "gsd_bf16_conv1x1_out": (_I, [_NHWC, _P, _P, _I, _P, _P]),
+    "gsd_bf16_bn_bwd_partial_rows": (_I, [_I, _I, _I]),
+    "gsd_bf16_bn_bwd_reduce": (_I, [_I, _NHWC, _P, _P, _P, _P, _NHWC, _NHWC, _NHWC, _P, _P, _NHWC, _P, _P]),
+    "gsd_bf16_bn_bwd_apply": (_I, [_NHWC, _NHWC, _P, _P, _P, _P, _P, _P]),
+    "gsd_bf16_wgrad_workspace": (_L, [_I, _I, _I, _I, _I, _I]),
+    "gsd_bf16_wgrad": (_I, [_NHWC, _NHWC, _I, _I, _IP, _IP, _P, _I, _P, _L, _P]),
 }
 
 
@@ -149,6 +172,23 @@ def make_dst(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None, off: 
     d.n_stride = ct * h * w
     d.c_stride = h * w
     return d
+
+
+def make_nhwc(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None) -> gsd_nhwc:
+    """Channels [c_off, c_off+c_len) of a contiguous (N,H,W,C) bfloat16 tensor as a gsd_nhwc view."""
+    if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 4 or not t.is_contiguous():
+        raise GsdError(f"expected a contiguous (N,H,W,C) bfloat16 CUDA(HIP) tensor, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    n, h, w, ct = t.shape
+    d = gsd_nhwc()
+    d.ptr = t.data_ptr() + 2 * c_off
+    d.pitch = ct
+    d.N, d.H, d.W = n, h, w
+    d.C = ct - c_off if c_len is None else c_len
+    return d
+
+
+def int_array(vals: Sequence[int]):
+    return (C.c_int * len(vals))(*vals)
 
 
 def src_array(items: Sequence[gsd_src]):

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["gsd_conv3x3.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_pointwise.hip", "gsd_dataset.hip"]
+SOURCES = ["gsd_conv3x3.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_pointwise.hip", "gsd_dataset.hip", "gsd_bf16_conv.hip", "gsd_bf16_pointwise.hip", "gsd_bf16_wgrad.hip"]
 OUT = os.path.join(CSRC, "libgsd.so")
 
 
@@ -20,8 +20,8 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "gsd_common.h"),
-                                                        os.path.join(INCLUDE, "gsd.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES]
+    deps += [os.path.join(d, f) for d in (CSRC, INCLUDE) for f in os.listdir(d) if f.endswith(".h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,53 @@
+// gsd_bf16_common.h -- shared pieces of the bf16 mixed-precision path (BASELINE.json configs[4]).
+//
+// Layout: activations NHWC bf16 ("pixel-major": the C channels of one pixel are contiguous, `pitch` elements from one
+// pixel to the next, so a tensor may be a channel slice of a wider buffer -- that is how torch.cat([skip, up]) exists
+// without ever being copied).  v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane; with k = input channel that is
+// one 16-byte piece of a pixel, which LDS-DMA (global_load_lds_dwordx4, per-lane source address) moves without touching
+// a register.  Weight gradients need k = pixel instead: those tiles are read back with ds_read_b64_tr_b16.
+#pragma once
+#include "gsd_common.h"
+#include "gsd_bf16.h"
+
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// D[row=(lane>>4)*4+reg][col=lane&15] += sum_k A[row i=lane&15][k=8*(lane>>4)+e] * B[k][col j=lane&15]
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_to_f32(u16 v) { return __uint_as_float((unsigned)v << 16); }
+// round-to-nearest-even through the hardware convert (v_cvt_pk_bf16_f32 keeps NaN a NaN)
+__device__ __forceinline__ u16 f32_to_bf16(float v) {
+  const __bf16 h = (__bf16)v;
+  return __builtin_bit_cast(u16, h);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+struct NhwcD {
+  u16* p;
+  long long pitch;
+  int N, H, W, C;
+};
+static inline NhwcD to_nhwc(const gsd_nhwc& t) {
+  NhwcD d;
+  d.p = (u16*)t.ptr; d.pitch = t.pitch; d.N = t.N; d.H = t.H; d.W = t.W; d.C = t.C;
+  return d;
+}
+static inline int gsd_check_nhwc(const gsd_nhwc* t, const char* what) {
+  GSD_REQUIRE(t != nullptr && t->ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null tensor", what);
+  GSD_REQUIRE(t->N > 0 && t->H > 0 && t->W > 0 && t->C > 0, GSD_ERR_BAD_ARG, "%s: bad dims N=%d H=%d W=%d C=%d", what, t->N,
+              t->H, t->W, t->C);
+  GSD_REQUIRE(t->pitch >= t->C, GSD_ERR_BAD_ARG, "%s: pitch %lld < C %d", what, (long long)t->pitch, t->C);
+  GSD_REQUIRE(((uintptr_t)t->ptr & 15) == 0 && (t->pitch & 7) == 0, GSD_ERR_UNSUPPORTED,
+              "%s: base must be 16-byte aligned and pitch a multiple of 8 elements", what);
+  GSD_REQUIRE((long long)t->H * t->W * t->pitch < 2147483647LL, GSD_ERR_UNSUPPORTED, "%s: one image exceeds 2^31 elements",
+              what);
+  return 0;
+}

@@ -1,0 +1,388 @@
+// gsd_bf16_conv.hip -- forward-type convolutions of the bf16 path as implicit GEMM on v_mfma_f32_16x16x32_bf16.
+//
+//   out[pixel][m] = sum_taps sum_k  in[pixel moved by the tap][k] * Wt[tap][m][k]          (fp32 accumulation)
+//
+//   MODE 0  conv3x3 p1 s1 (unet.py:11,14 forward, and with transposed/flipped weights the dX half of its backward):
+//           one (TH+2)x(TW+2) halo tile of 32 input channels in LDS serves all 9 taps; K walks (channel chunk, kernel
+//           row), three taps per barrier.
+//   MODE 1  "dense" taps without spatial reuse: 1x1 (the im2col'd first layer, K = 27 -> 32), ConvTranspose2d k2 s2
+//           forward (1 tap, M = (kh,kw,co), scatter epilogue + bias; unet.py:36,41) and its dX (4 taps at stride 2).
+//
+// Operands reach LDS by global_load_lds_dwordx4 with per-lane source addresses (the halo gather, zero padding from a
+// zero line, and the XOR swizzle of the weight tile all happen in the address computation; no register staging):
+//   weights     [tap][BM rows][64 B], 16-byte piece g of row r stored at slot g ^ {0,2,3,1}[(r>>2)&3]
+//   activations [pixel][96 B] (64 B of data + 32 B never written): with 6 pieces per pixel the ds_read_b128 of the B
+//               operand (16 consecutive pixels x 4 pieces) is bank-conflict free for EVERY tap shift; 64-byte pixels
+//               are 2-way conflicted whenever the shift is not a multiple of 4 pixels.
+// Block = 4 waves; wave tile 64 (m) x 128 (pixels) = 4 x 8 MFMA tiles = 128 accumulator registers; block tile
+// 128 x 256 (WM=2, WN=2) or 64 x 512 (WM=1, WN=4): L2->LDS traffic per FLOP falls with the PIXEL extent of the tile
+// (weights are re-read per pixel tile), which is why the tile is wide in pixels.
+#include "gsd_bf16_common.h"
+
+__device__ const uint4 gsd_zero16[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+struct GConvP {
+  const u16* in;
+  long long in_pitch;
+  int Hin, Win;
+  const u16* wt;  // [ntaps][Mpad][K]
+  u16* out;
+  long long out_pitch;
+  int Hob, Wob;   // output BUFFER extent
+  int N, H, W;    // GEMM pixel grid
+  int K, M, Mpad, mblocks;
+  int ntaps, stride;
+  int ty[9], tx[9];
+  int TH, TW, tiles_y, tiles_x, HC, HP;
+  int Cs, oy, ox;  // scatter (Cs > 0): m = q*Cs + co -> out pixel (2h + (q>>1) + oy, 2w + (q&1) + ox), channel co
+  const float* bias;
+  float* partials;
+};
+
+template <int MODE, int WM, int WN>
+__global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
+  constexpr int BM = WM * 64, NPX = WN * 128;
+  constexpr int MT = 4, NT = 8;
+  constexpr int NTAPI = MODE == 0 ? 3 : 1;          // taps (k-steps) per barrier
+  constexpr int WBUF = NTAPI * BM * 64;             // bytes of one weight image
+  constexpr int NWI = NTAPI * BM / 16 / 4;          // weight DMA instructions per wave per iteration
+  constexpr int MAXX = MODE == 0 ? (WN == 2 ? 10 : 16) : NPX * 3 / 32 / 4;   // activation DMA instructions per wave
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int XBUF = (MODE == 0 ? P.HP : NPX) * 96;
+  unsigned char* Wl = smem;
+  unsigned char* Xl = smem + 2 * WBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, j = lane & 15;
+
+  const int mb = blockIdx.x % P.mblocks;
+  const int pt = blockIdx.x / P.mblocks;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = pt / tpi;
+  const int trem = pt - n * tpi;
+  const int tyi = trem / P.tiles_x;
+  const int h0 = tyi * P.TH, w0 = (trem - tyi * P.tiles_x) * P.TW;
+  const int m0 = mb * BM;
+  const int cbs = P.TW >> 4;  // 16-pixel column blocks per tile row
+
+  const u16* in_img = P.in + (long long)n * P.Hin * P.Win * P.in_pitch;
+
+  // ---- DMA bookkeeping (chunk-invariant part of every source address) ---------------------------------------------
+  int woff[NWI];
+#pragma unroll
+  for (int k = 0; k < NWI; ++k) {
+    const int idx = (k * 4 + wave) * 64 + lane;
+    const int tapk = idx / (BM * 4);
+    const int row = (idx >> 2) % BM;
+    const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
+    woff[k] = (tapk * P.Mpad + m0 + row) * P.K + gg * 8;
+  }
+  // activations: MODE 0 -> element offset inside the image of this lane's 16-byte piece (-1: zeros, -2: no transfer);
+  //              MODE 1 -> (r << 16 | c << 4 | slot) of the tile pixel, or -2
+  int xoff[MAXX];
+#pragma unroll
+  for (int k = 0; k < MAXX; ++k) {
+    const int o = (k * 4 + wave) * 1024 + lane * 16;
+    const int px = o / 96, slot = (o - px * 96) >> 4;
+    int v = -2;
+    if (MODE == 0) {
+      if (px < P.HP && slot < 4) {
+        const int hy = px / P.HC, hx = px - hy * P.HC;
+        const int hi = h0 - 1 + hy, wi = w0 - 1 + hx;
+        v = ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win) ? (int)((hi * P.Win + wi) * P.in_pitch) + slot * 8
+                                                                              : -1;
+      }
+    } else {
+      if (px < NPX && slot < 4) {
+        const int r = px / P.TW, c = px - r * P.TW;
+        v = (h0 + r < P.H && w0 + c < P.W) ? ((r << 16) | (c << 4) | slot) : -1;
+      }
+    }
+    xoff[k] = v;
+  }
+
+  auto issue = [&](int it) {
+    int chunk, tap0;
+    if (MODE == 0) {
+      chunk = it / 3;
+      tap0 = (it - chunk * 3) * 3;
+    } else {
+      const int nch = P.K >> 5;
+      tap0 = it / nch;
+      chunk = it - tap0 * nch;
+    }
+    unsigned char* wdst = Wl + (it & 1) * WBUF;
+    const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
+#pragma unroll
+    for (int k = 0; k < NWI; ++k)
+      __builtin_amdgcn_global_load_lds((const void*)(wsrc + woff[k]), wdst + (k * 4 + wave) * 1024, 16, 0, 0);
+    if (MODE == 0) {
+      if (tap0 != 0) return;   // the halo tile of a chunk arrives with its first kernel row
+      unsigned char* xdst = Xl + (chunk & 1) * XBUF;
+      const u16* src = in_img + chunk * 32;
+#pragma unroll
+      for (int k = 0; k < MAXX; ++k) {
+        if (xoff[k] != -2) {
+          const void* s = xoff[k] >= 0 ? (const void*)(src + xoff[k]) : (const void*)gsd_zero16;
+          __builtin_amdgcn_global_load_lds(s, xdst + (k * 4 + wave) * 1024, 16, 0, 0);
+        }
+      }
+    } else {
+      unsigned char* xdst = Xl + (it & 1) * XBUF;
+      const u16* src = in_img + chunk * 32;
+      const int ty = P.ty[tap0], tx = P.tx[tap0];
+#pragma unroll
+      for (int k = 0; k < MAXX; ++k) {
+        if (xoff[k] != -2) {
+          const void* s = (const void*)gsd_zero16;
+          if (xoff[k] >= 0) {
+            const int hi = P.stride * (h0 + (xoff[k] >> 16)) + ty, wi = P.stride * (w0 + ((xoff[k] >> 4) & 0xfff)) + tx;
+            if ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win)
+              s = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (xoff[k] & 15) * 8);
+          }
+          __builtin_amdgcn_global_load_lds(s, xdst + (k * 4 + wave) * 1024, 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  // ---- operand read offsets ------------------------------------------------------------------------------------
+  const int aoff = (wm * 64 + j) * 64 + ((g ^ ((0x1320 >> (((j >> 2) & 3) * 4)) & 3)) << 4);
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nt = wn * NT + t;
+    if (MODE == 0) {
+      const int r = nt / cbs, cb = nt - r * cbs;
+      boff[t] = (r * P.HC + cb * 16 + j) * 96 + g * 16;
+    } else {
+      boff[t] = (nt * 16 + j) * 96 + g * 16;
+    }
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * (P.K >> 5);
+  issue(0);
+  for (int it = 0; it < iters; ++it) {
+    __syncthreads();   // iteration it's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
+    if (it + 1 < iters) issue(it + 1);
+    const unsigned char* Wc = Wl + (it & 1) * WBUF + aoff;
+    const unsigned char* Xc;
+    if (MODE == 0) {
+      const int chunk = it / 3, kh = it - chunk * 3;
+      Xc = Xl + (chunk & 1) * XBUF + kh * P.HC * 96;
+    } else {
+      Xc = Xl + (it & 1) * XBUF;
+    }
+#pragma unroll
+    for (int kw = 0; kw < NTAPI; ++kw) {
+      u32x4 a[MT], b[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const u32x4*>(Wc + kw * BM * 64 + m * 1024);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const u32x4*>(Xc + boff[t] + kw * 96);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma_bf16(a[m], b[t], acc[m][t]);
+    }
+  }
+
+  // ---- epilogue: bf16 store (4 consecutive channels per lane), optional bias / scatter / BatchNorm partial sums ----
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int nt = wn * NT + t;
+    const int r = nt / cbs, cb = nt - r * cbs;
+    const int h = h0 + r, w = w0 + cb * 16 + j;
+    const bool pix_ok = h < P.H && w < P.W;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+      if (mrow < P.M) {
+        int co = mrow, ho = h, wo = w;
+        if (P.Cs > 0) {
+          const int q = mrow / P.Cs;
+          co = mrow - q * P.Cs;
+          ho = 2 * h + (q >> 1) + P.oy;
+          wo = 2 * w + (q & 1) + P.ox;
+        }
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[m][t][e] + (P.bias != nullptr ? P.bias[co + e] : 0.f);
+        const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if (pix_ok) {
+          u16* o = P.out + ((long long)(n * P.Hob + ho) * P.Wob + wo) * P.out_pitch + co;
+          *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+          if (P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
+            const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
+            const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
+            s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
+            s1[m][1] += q1; s2[m][1] = fmaf(q1, q1, s2[m][1]);
+            s1[m][2] += q2; s2[m][2] = fmaf(q2, q2, s2[m][2]);
+            s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
+          }
+        }
+      }
+    }
+  }
+  if (P.partials != nullptr) {
+    float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a1 = reduce16(s1[m][r]), a2 = reduce16(s2[m][r]);
+        const int mrow = m0 + wm * 64 + m * 16 + g * 4 + r;
+        if (j == 0 && mrow < P.Mpad) {
+          row[mrow] = a1;
+          row[P.Mpad + mrow] = a2;
+        }
+      }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+namespace {
+
+struct Plan {
+  bool wide;   // M <= 64: 64 x 512 tile, else 128 x 256
+  int BM, NPX, TH, TW, tiles_y, tiles_x, mblocks, Mpad, HC, HP;
+};
+
+Plan make_plan(int H, int W, int M) {
+  Plan p;
+  p.wide = M <= 64;
+  p.BM = p.wide ? 64 : 128;
+  p.NPX = p.wide ? 512 : 256;
+  long best = -1;
+  for (int tw = 16; tw <= 64; tw *= 2) {
+    const int th = p.NPX / tw;
+    const long cost = (long)ceil_div(H, th) * ceil_div(W, tw);   // tiles; ties -> wider rows (longer DMA row segments)
+    if (best < 0 || cost <= best) {
+      best = cost;
+      p.TW = tw;
+      p.TH = th;
+    }
+  }
+  p.tiles_y = ceil_div(H, p.TH);
+  p.tiles_x = ceil_div(W, p.TW);
+  p.Mpad = round_up(M, 128);
+  p.mblocks = ceil_div(M, p.BM);
+  p.HC = p.TW + 2;
+  p.HP = (p.TH + 2) * (p.TW + 2);
+  return p;
+}
+
+template <int MODE, int WM, int WN>
+int launch(const GConvP& P, long grid, size_t lds, hipStream_t st, const char* what) {
+  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  GSD_REQUIRE(grid > 0 && grid < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: grid %ld out of range", what, grid);
+  GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "%s: LDS %zu B too large", what, lds);
+  hipLaunchKernelGGL((gconv_bf16_kernel<MODE, WM, WN>), dim3((unsigned)grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK(what);
+  return GSD_OK;
+}
+
+}  // namespace
+
+extern "C" int gsd_bf16_conv_mpad(int M) { return M > 0 ? round_up(M, 128) : 0; }
+
+extern "C" int gsd_bf16_conv_partial_rows(int N, int H, int W, int M) {
+  if (N <= 0 || H <= 0 || W <= 0 || M <= 0) return 0;
+  const Plan p = make_plan(H, W, M);
+  return N * p.tiles_y * p.tiles_x * (p.wide ? 4 : 2);
+}
+
+extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
+                                void* stream) {
+  if (int e = gsd_check_nhwc(in, "gsd_bf16_conv3x3 in")) return e;
+  if (int e = gsd_check_nhwc(out, "gsd_bf16_conv3x3 out")) return e;
+  GSD_REQUIRE(wt != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3: null weights");
+  GSD_REQUIRE(K > 0 && K % 32 == 0 && in->C == K, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv3x3: K=%d must be a multiple of 32 and in->C",
+              K);
+  GSD_REQUIRE(M > 0 && M % 16 == 0 && out->C == M, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv3x3: M=%d must be a multiple of 16 and out->C",
+              M);
+  GSD_REQUIRE(in->N == out->N && in->H == out->H && in->W == out->W, GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3: in/out extents differ");
+  GSD_REQUIRE((out->pitch & 3) == 0, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv3x3: out pitch must be a multiple of 4");
+  const Plan pl = make_plan(in->H, in->W, M);
+  GConvP P;
+  P.in = (const u16*)in->ptr; P.in_pitch = in->pitch; P.Hin = in->H; P.Win = in->W;
+  P.wt = (const u16*)wt;
+  P.out = (u16*)out->ptr; P.out_pitch = out->pitch; P.Hob = out->H; P.Wob = out->W;
+  P.N = in->N; P.H = in->H; P.W = in->W;
+  P.K = K; P.M = M; P.Mpad = pl.Mpad; P.mblocks = pl.mblocks;
+  P.ntaps = 9; P.stride = 1;
+  for (int t = 0; t < 9; ++t) { P.ty[t] = t / 3 - 1; P.tx[t] = t % 3 - 1; }
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HC = pl.HC; P.HP = pl.HP;
+  P.Cs = 0; P.oy = P.ox = 0;
+  P.bias = nullptr;
+  P.partials = partials;
+  const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
+  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * pl.HP * 96;
+  if (pl.wide) return launch<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
+  return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
+}
+
+extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
+                                   const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
+                                   float* partials, void* stream) {
+  if (int e = gsd_check_nhwc(in, "gsd_bf16_conv_dense in")) return e;
+  if (int e = gsd_check_nhwc(out, "gsd_bf16_conv_dense out")) return e;
+  GSD_REQUIRE(wt != nullptr && ty != nullptr && tx != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: null argument");
+  GSD_REQUIRE(K > 0 && K % 32 == 0 && in->C == K, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv_dense: K=%d must be a multiple of 32 and in->C",
+              K);
+  GSD_REQUIRE(M > 0 && M % 16 == 0, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv_dense: M=%d must be a multiple of 16", M);
+  GSD_REQUIRE(ntaps >= 1 && ntaps <= 9 && (stride == 1 || stride == 2), GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: bad taps/stride");
+  GSD_REQUIRE(H > 0 && W > 0 && H < 65536 && W < 4096 && in->N == out->N, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: bad grid");
+  GSD_REQUIRE((out->pitch & 3) == 0, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv_dense: out pitch must be a multiple of 4");
+  if (scatter_cs > 0) {
+    GSD_REQUIRE(M == 4 * scatter_cs && scatter_cs % 16 == 0 && out->C == scatter_cs, GSD_ERR_BAD_ARG,
+                "gsd_bf16_conv_dense: scatter needs M == 4*Cs, Cs %% 16 == 0, out->C == Cs");
+    GSD_REQUIRE(oy >= 0 && ox >= 0 && 2 * H + oy <= out->H && 2 * W + ox <= out->W, GSD_ERR_BAD_ARG,
+                "gsd_bf16_conv_dense: scattered block (%d,%d)+(%d,%d) leaves the output buffer (%d,%d)", 2 * H, 2 * W, oy, ox,
+                out->H, out->W);
+    GSD_REQUIRE(partials == nullptr, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv_dense: no statistics in scatter mode");
+  } else {
+    GSD_REQUIRE(out->C == M && H <= out->H && W <= out->W, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: out must hold (H,W,M)");
+  }
+  const Plan pl = make_plan(H, W, M);
+  GConvP P;
+  P.in = (const u16*)in->ptr; P.in_pitch = in->pitch; P.Hin = in->H; P.Win = in->W;
+  P.wt = (const u16*)wt;
+  P.out = (u16*)out->ptr; P.out_pitch = out->pitch; P.Hob = out->H; P.Wob = out->W;
+  P.N = in->N; P.H = H; P.W = W;
+  P.K = K; P.M = M; P.Mpad = pl.Mpad; P.mblocks = pl.mblocks;
+  P.ntaps = ntaps; P.stride = stride;
+  for (int t = 0; t < 9; ++t) { P.ty[t] = t < ntaps ? ty[t] : 0; P.tx[t] = t < ntaps ? tx[t] : 0; }
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HC = 0; P.HP = 0;
+  P.Cs = scatter_cs; P.oy = oy; P.ox = ox;
+  P.bias = bias;
+  P.partials = partials;
+  const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
+  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96;
+  if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
+  return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
+}

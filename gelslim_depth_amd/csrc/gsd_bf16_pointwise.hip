@@ -1,0 +1,416 @@
+// gsd_bf16_pointwise.hip -- the HBM-bound kernels of the bf16 path: weight images, first-layer im2col, BatchNorm apply
+// (+ReLU), max-pool, the 1x1 output convolution and BatchNorm/ReLU/max-pool backward.  All tensors NHWC bf16 (gsd_nhwc),
+// a thread owns 8 consecutive channels of a pixel (one 16-byte load/store), a wave therefore moves 1 KiB contiguous
+// when pitch == C.  All arithmetic in fp32.
+#include "gsd_bf16_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float f[8]) {
+  return make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+}
+__device__ __forceinline__ uint4 ld16(const u16* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(u16* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ---- weight images ----------------------------------------------------------------------------------------------
+struct WImg {
+  int T, M, K, Mp, Kp;
+};
+WImg wimg_dims(int mode, int Cout, int Cin) {
+  WImg d;
+  switch (mode) {
+    case 0: d.T = 9; d.M = Cout; d.K = Cin; break;           // conv3x3 forward      [t][co][ci]
+    case 1: d.T = 9; d.M = Cin; d.K = Cout; break;           // conv3x3 dX           [8-t][ci][co]
+    case 2: d.T = 1; d.M = Cout; d.K = Cin * 9; break;       // im2col'd first layer [co][ci*9+t]
+    case 3: d.T = 1; d.M = 4 * Cout; d.K = Cin; break;       // convT forward        [(kh,kw,co)][ci]
+    default: d.T = 4; d.M = Cin; d.K = Cout; break;          // convT dX             [(kh,kw)][ci][co]
+  }
+  d.Mp = round_up(d.M, 128);
+  d.Kp = round_up(d.K, 32);
+  return d;
+}
+
+__global__ void weight_image_kernel(int mode, const float* __restrict__ w, int Cout, int Cin, u16* __restrict__ out, WImg d) {
+  const long long total = (long long)d.T * d.Mp * d.Kp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % d.Kp);
+    const int m = (int)((e / d.Kp) % d.Mp);
+    const int t = (int)(e / ((long long)d.Kp * d.Mp));
+    float v = 0.f;
+    if (m < d.M && k < d.K) {
+      switch (mode) {
+        case 0: v = w[((size_t)m * Cin + k) * 9 + t]; break;
+        case 1: v = w[((size_t)k * Cin + m) * 9 + (8 - t)]; break;
+        case 2: v = w[(size_t)m * Cin * 9 + k]; break;
+        case 3: { const int q = m / Cout, co = m - q * Cout; v = w[((size_t)k * Cout + co) * 4 + q]; break; }
+        default: v = w[((size_t)m * Cout + k) * 4 + t]; break;
+      }
+    }
+    out[e] = f32_to_bf16(v);
+  }
+}
+
+// ---- first-layer im2col: x (N,C,H,W) fp32 -> col (N,H,W,Kp) bf16, k = c*9 + tap ---------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int C, int H, int W, NhwcD col) {
+  const int n = blockIdx.y;
+  const int groups = col.C >> 3;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)H * W * groups) return;
+  const int gk = (int)(e % groups);
+  const int p = (int)(e / groups);
+  const int h = p / W, wq = p - h * W;
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = gk * 8 + i;
+    float v = 0.f;
+    if (k < C * 9) {
+      const int c = k / 9, t = k - c * 9;
+      const int hi = h + t / 3 - 1, wi = wq + t % 3 - 1;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((size_t)n * C + c) * H + hi) * W + wi];
+    }
+    f[i] = v;
+  }
+  st16(col.p + ((long long)n * H * W + p) * col.pitch + gk * 8, pack8(f));
+}
+
+// ---- a = relu(y * scale + shift) ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(NhwcD y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       NhwcD a, int relu, long long npix) {
+  const int groups = y.C >> 3;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= npix * groups) return;
+  const int gk = (int)(e % groups);
+  const long long p = e / groups;
+  float f[8];
+  unpack8(ld16(y.p + p * y.pitch + gk * 8), f);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + gk * 8), s1 = *reinterpret_cast<const f32x4*>(scale + gk * 8 + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + gk * 8), h1 = *reinterpret_cast<const f32x4*>(shift + gk * 8 + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[i] = fmaf(f[i], s0[i], h0[i]);
+    f[4 + i] = fmaf(f[4 + i], s1[i], h1[i]);
+  }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f);
+  }
+  st16(a.p + p * a.pitch + gk * 8, pack8(f));
+}
+
+// ---- MaxPool2d(2), floor mode (unet.py:26) --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_bf16_kernel(NhwcD a, NhwcD o) {
+  const int groups = a.C >> 3;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)o.N * o.H * o.W * groups) return;
+  const int gk = (int)(e % groups);
+  const long long p = e / groups;
+  const int wp = (int)(p % o.W);
+  const int hp = (int)((p / o.W) % o.H);
+  const int n = (int)(p / ((long long)o.W * o.H));
+  const u16* b = a.p + (((long long)n * a.H + 2 * hp) * a.W + 2 * wp) * a.pitch + gk * 8;
+  float v0[8], v1[8], v2[8], v3[8];
+  unpack8(ld16(b), v0);
+  unpack8(ld16(b + a.pitch), v1);
+  unpack8(ld16(b + (long long)a.W * a.pitch), v2);
+  unpack8(ld16(b + (long long)(a.W + 1) * a.pitch), v3);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v0[i] = fmaxf(fmaxf(v0[i], v1[i]), fmaxf(v2[i], v3[i]));
+  st16(o.p + p * o.pitch + gk * 8, pack8(v0));
+}
+
+// ---- 1x1 output conv (+bias), fp32 NCHW result (unet.py:54) --------------------------------------------------------
+constexpr int OUTC_MAXK = 4;
+__global__ __launch_bounds__(256) void conv1x1_out_bf16_kernel(NhwcD a, const float* __restrict__ w, const float* __restrict__ b,
+                                                               int K, float* __restrict__ out) {
+  const long long HW = (long long)a.H * a.W;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long long)a.N * HW) return;
+  float acc[OUTC_MAXK];
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k) acc[k] = 0.f;
+  const u16* src = a.p + p * a.pitch;
+  for (int c = 0; c < a.C; c += 8) {
+    float f[8];
+    unpack8(ld16(src + c), f);
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXK; ++k)
+      if (k < K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[k] = fmaf(f[i], w[(size_t)k * a.C + c + i], acc[k]);
+      }
+  }
+  const long long n = p / HW, q = p - n * HW;
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k)
+    if (k < K) out[(n * K + k) * HW + q] = acc[k] + (b != nullptr ? b[k] : 0.f);
+}
+
+// ---- BatchNorm + ReLU (+ max-pool / output conv) backward, pass 1 ---------------------------------------------------
+struct BnBwdB {
+  NhwcD y, g, a, dpool, dz;
+  const float* scale; const float* shift; const float* mean; const float* invstd;
+  const float* dout; const float* wout;
+  float* partials;
+  int pixb, chunks;
+};
+
+// grid (chunks, N); block: 256 threads = (256 / groups) pixels x groups 8-channel groups per pass (groups <= 256)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const BnBwdB P) {
+  extern __shared__ float red[];   // [256][24]
+  const int C = P.y.C, groups = C >> 3;
+  const int tpp = groups < 256 ? groups : 256;     // threads per pixel
+  const int ppi = 256 / tpp;                       // pixels per pass
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int HW = P.y.H * P.y.W;
+  const int pl = threadIdx.x / tpp, gl = threadIdx.x - pl * tpp;
+  float s1[8], s2[8], s3[8];
+  const int p_end = min((chunk + 1) * P.pixb, HW);
+  for (int gk = gl; gk < groups; gk += tpp) {      // one trip unless C > 2048
+    float sc[8], sh[8], mu[8], is[8], wo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = P.scale[gk * 8 + i]; sh[i] = P.shift[gk * 8 + i]; mu[i] = P.mean[gk * 8 + i]; is[i] = P.invstd[gk * 8 + i];
+      wo[i] = MODE == 2 ? P.wout[gk * 8 + i] : 0.f;
+      s1[i] = s2[i] = s3[i] = 0.f;
+    }
+    for (int p = chunk * P.pixb + pl; p < p_end && pl < ppi; p += ppi) {
+      const long long pix = (long long)n * HW + p;
+      float yv[8], gv[8];
+      unpack8(ld16(P.y.p + pix * P.y.pitch + gk * 8), yv);
+      if (MODE == 2) {
+        const float d = P.dout[pix];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gv[i] = d * wo[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float av = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(yv[i], sc[i], sh[i]), 0.f)));   // the activation as stored
+          s3[i] = fmaf(d, av, s3[i]);
+        }
+      } else {
+        unpack8(ld16(P.g.p + pix * P.g.pitch + gk * 8), gv);
+      }
+      if (MODE == 1) {
+        const int h = p / P.y.W, w = p - h * P.y.W;
+        const int hp = h >> 1, wp = w >> 1;
+        if (hp < P.dpool.H && wp < P.dpool.W) {
+          // arg-max of the stored activations of the 2x2 window; first maximum in (0,0),(0,1),(1,0),(1,1) order wins
+          const u16* wb = P.a.p + (((long long)n * P.a.H + 2 * hp) * P.a.W + 2 * wp) * P.a.pitch + gk * 8;
+          float a0[8], a1[8], a2[8], a3[8], dp[8];
+          unpack8(ld16(wb), a0);
+          unpack8(ld16(wb + P.a.pitch), a1);
+          unpack8(ld16(wb + (long long)P.a.W * P.a.pitch), a2);
+          unpack8(ld16(wb + (long long)(P.a.W + 1) * P.a.pitch), a3);
+          unpack8(ld16(P.dpool.p + (((long long)n * P.dpool.H + hp) * P.dpool.W + wp) * P.dpool.pitch + gk * 8), dp);
+          const int me = ((h & 1) << 1) | (w & 1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float best = a0[i];
+            int bi = 0;
+            if (a1[i] > best) { best = a1[i]; bi = 1; }
+            if (a2[i] > best) { best = a2[i]; bi = 2; }
+            if (a3[i] > best) { best = a3[i]; bi = 3; }
+            if (bi == me) gv[i] += dp[i];
+          }
+        }
+      }
+      float dzv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float yn = fmaf(yv[i], sc[i], sh[i]);
+        dzv[i] = yn > 0.f ? gv[i] : 0.f;
+      }
+      const uint4 packed = pack8(dzv);
+      st16(P.dz.p + pix * P.dz.pitch + gk * 8, packed);
+      float dq[8];
+      unpack8(packed, dq);     // sums of the values as stored: the apply pass reads these back
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1[i] += dq[i];
+        s2[i] = fmaf(dq[i], (yv[i] - mu[i]) * is[i], s2[i]);
+      }
+    }
+    // reduce over the ppi pixel lanes that share this channel group
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[threadIdx.x * 24 + i] = s1[i];
+      red[threadIdx.x * 24 + 8 + i] = s2[i];
+      red[threadIdx.x * 24 + 16 + i] = s3[i];
+    }
+    __syncthreads();
+    if (pl == 0) {
+      float* row = P.partials + (size_t)(n * P.chunks + chunk) * 3 * C;
+      for (int q = 0; q < 24; ++q) {
+        float s = 0.f;
+        for (int r = 0; r < ppi; ++r) s += red[(r * tpp + gl) * 24 + q];
+        row[(q >> 3) * C + gk * 8 + (q & 7)] = s;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(NhwcD dz, NhwcD y, const float* __restrict__ scale,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                long long npix) {
+  const int groups = y.C >> 3;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= npix * groups) return;
+  const int gk = (int)(e % groups);
+  const long long p = e / groups;
+  float d[8], yv[8];
+  unpack8(ld16(dz.p + p * dz.pitch + gk * 8), d);
+  unpack8(ld16(y.p + p * y.pitch + gk * 8), yv);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = gk * 8 + i;
+    const float xh = (yv[i] - mean[c]) * invstd[c];
+    d[i] = scale[c] * (d[i] - c1[c] - xh * c2[c]);
+  }
+  st16(dz.p + p * dz.pitch + gk * 8, pack8(d));
+}
+
+int pick_pixb(int N, int HW) {
+  long long pixb = ((long long)N * HW + 2047) / 2048;
+  pixb = (pixb + 31) / 32 * 32;
+  return (int)(pixb < 32 ? 32 : pixb);
+}
+
+int check_c8(const gsd_nhwc* t, const char* what) {
+  if (int e = gsd_check_nhwc(t, what)) return e;
+  GSD_REQUIRE(t->C % 8 == 0, GSD_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of 8", what, t->C);
+  return 0;
+}
+bool same_extent(const gsd_nhwc* a, const gsd_nhwc* b) { return a->N == b->N && a->H == b->H && a->W == b->W && a->C == b->C; }
+long long npix_of(const gsd_nhwc* t) { return (long long)t->N * t->H * t->W; }
+
+}  // namespace
+
+extern "C" int64_t gsd_bf16_weight_image_size(int mode, int Cout, int Cin) {
+  if (mode < 0 || mode > 4 || Cout <= 0 || Cin <= 0) return 0;
+  const WImg d = wimg_dims(mode, Cout, Cin);
+  return (int64_t)d.T * d.Mp * d.Kp;
+}
+
+extern "C" int gsd_bf16_weight_image(int mode, const float* w, int Cout, int Cin, void* out, void* stream) {
+  GSD_REQUIRE(w && out && mode >= 0 && mode <= 4 && Cout > 0 && Cin > 0, GSD_ERR_BAD_ARG, "gsd_bf16_weight_image: bad argument");
+  const WImg d = wimg_dims(mode, Cout, Cin);
+  const long long total = (long long)d.T * d.Mp * d.Kp;
+  const int grid = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
+  hipLaunchKernelGGL(weight_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Cout, Cin, (u16*)out, d);
+  GSD_LAUNCH_CHECK("gsd_bf16_weight_image");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_im2col3x3(const float* x, int N, int C, int H, int W, const gsd_nhwc* col, void* stream) {
+  GSD_REQUIRE(x && N > 0 && C > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG, "gsd_bf16_im2col3x3: bad argument");
+  if (int e = check_c8(col, "gsd_bf16_im2col3x3 col")) return e;
+  GSD_REQUIRE(col->N == N && col->H == H && col->W == W && col->C == round_up(9 * C, 32), GSD_ERR_BAD_ARG,
+              "gsd_bf16_im2col3x3: col must be (N,H,W,round_up(9*C,32))");
+  GSD_REQUIRE(N <= 65535, GSD_ERR_UNSUPPORTED, "gsd_bf16_im2col3x3: N must be <= 65535");
+  const long long per = (long long)H * W * (col->C / 8);
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)ceil_div64(per, 256), N), dim3(256), 0, (hipStream_t)stream, x, C, H, W,
+                     to_nhwc(*col));
+  GSD_LAUNCH_CHECK("gsd_bf16_im2col3x3");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a, int relu,
+                                 void* stream) {
+  if (int e = check_c8(y, "gsd_bf16_bn_apply y")) return e;
+  if (int e = check_c8(a, "gsd_bf16_bn_apply a")) return e;
+  GSD_REQUIRE(scale && shift && same_extent(y, a), GSD_ERR_BAD_ARG, "gsd_bf16_bn_apply: bad argument");
+  const long long np = npix_of(y), total = np * (y->C / 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
+                     scale, shift, to_nhwc(*a), relu, np);
+  GSD_LAUNCH_CHECK("gsd_bf16_bn_apply");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream) {
+  if (int e = check_c8(a, "gsd_bf16_maxpool2 a")) return e;
+  if (int e = check_c8(pooled, "gsd_bf16_maxpool2 pooled")) return e;
+  GSD_REQUIRE(a->H > 1 && a->W > 1 && pooled->N == a->N && pooled->C == a->C && pooled->H == a->H / 2 && pooled->W == a->W / 2,
+              GSD_ERR_BAD_ARG, "gsd_bf16_maxpool2: pooled must be (N,H/2,W/2,C)");
+  const long long total = npix_of(pooled) * (a->C / 8);
+  hipLaunchKernelGGL(maxpool2_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     to_nhwc(*a), to_nhwc(*pooled));
+  GSD_LAUNCH_CHECK("gsd_bf16_maxpool2");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_conv1x1_out(const gsd_nhwc* a, const float* w, const float* bias, int K, float* out, void* stream) {
+  if (int e = check_c8(a, "gsd_bf16_conv1x1_out a")) return e;
+  GSD_REQUIRE(w && out && K >= 1 && K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv1x1_out: n_classes must be in [1,%d]",
+              OUTC_MAXK);
+  hipLaunchKernelGGL(conv1x1_out_bf16_kernel, dim3((unsigned)ceil_div64(npix_of(a), 256)), dim3(256), 0, (hipStream_t)stream,
+                     to_nhwc(*a), w, bias, K, out);
+  GSD_LAUNCH_CHECK("gsd_bf16_conv1x1_out");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_bwd_partial_rows(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return N * ceil_div(H * W, pick_pixb(N, H * W));
+}
+
+extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const gsd_nhwc* dpool,
+                                      const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream) {
+  if (int e = check_c8(y, "gsd_bf16_bn_bwd_reduce y")) return e;
+  if (int e = check_c8(dz, "gsd_bf16_bn_bwd_reduce dz")) return e;
+  GSD_REQUIRE(mode >= 0 && mode <= 2 && scale && shift && mean && invstd && partials && same_extent(y, dz), GSD_ERR_BAD_ARG,
+              "gsd_bf16_bn_bwd_reduce: bad argument");
+  GSD_REQUIRE(y->N <= 65535 && (y->C <= 2048 || y->C % 2048 == 0), GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_bn_bwd_reduce: N must be <= 65535 and C <= 2048 or a multiple of 2048");
+  BnBwdB P;
+  P.y = to_nhwc(*y);
+  P.dz = to_nhwc(*dz);
+  P.g = P.a = P.dpool = P.y;
+  if (mode != 2) {
+    if (int e = check_c8(g, "gsd_bf16_bn_bwd_reduce g")) return e;
+    GSD_REQUIRE(same_extent(y, g), GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: g extent differs from y");
+    P.g = to_nhwc(*g);
+  } else {
+    GSD_REQUIRE(dout && wout, GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: mode OUTC needs dout, wout (n_classes == 1)");
+  }
+  if (mode == 1) {
+    if (int e = check_c8(a, "gsd_bf16_bn_bwd_reduce a")) return e;
+    if (int e = check_c8(dpool, "gsd_bf16_bn_bwd_reduce dpool")) return e;
+    GSD_REQUIRE(same_extent(y, a) && dpool->N == y->N && dpool->C == y->C && dpool->H == y->H / 2 && dpool->W == y->W / 2,
+                GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: mode POOL needs a (N,H,W,C) and dpool (N,H/2,W/2,C)");
+    P.a = to_nhwc(*a);
+    P.dpool = to_nhwc(*dpool);
+  }
+  P.scale = scale; P.shift = shift; P.mean = mean; P.invstd = invstd;
+  P.dout = dout; P.wout = wout; P.partials = partials;
+  P.pixb = pick_pixb(y->N, y->H * y->W);
+  P.chunks = ceil_div(y->H * y->W, P.pixb);
+  const dim3 grid(P.chunks, y->N);
+  const size_t lds = 256 * 24 * sizeof(float);
+  if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, P);
+  else if (mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, P);
+  GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_reduce");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* scale, const float* mean,
+                                     const float* invstd, const float* c1, const float* c2, void* stream) {
+  if (int e = check_c8(dz, "gsd_bf16_bn_bwd_apply dz")) return e;
+  if (int e = check_c8(y, "gsd_bf16_bn_bwd_apply y")) return e;
+  GSD_REQUIRE(scale && mean && invstd && c1 && c2 && same_extent(dz, y), GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_apply: bad argument");
+  const long long np = npix_of(y), total = np * (y->C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     to_nhwc(*dz), to_nhwc(*y), scale, mean, invstd, c1, c2, np);
+  GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_apply");
+  return GSD_OK;
+}

@@ -1,0 +1,101 @@
+/*
+ * gsd_bf16.h -- C ABI of libgsd.so, bf16 mixed-precision family (BASELINE.json configs[4]: "bf16 mixed-precision
+ * training ... with MFMA im2col conv path").  Same conventions as gsd.h (caller-owned memory, explicit stream, negative
+ * status + gsd_last_error(), re-entrant).  The reference has no reduced-precision path; these entry points stand in for
+ * the same ATen operators as their fp32 counterparts in gsd.h (cited per function), with
+ *   - activations and activation gradients stored as bfloat16, NHWC ("pixel-major"), described by gsd_nhwc;
+ *   - fp32 accumulation in every contraction and reduction, fp32 BatchNorm statistics;
+ *   - fp32 master parameters, gradients, Adam and EMA state (gsd_adam_ema is shared with the fp32 path).
+ */
+#ifndef GSD_BF16_H
+#define GSD_BF16_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A bf16 NHWC tensor, possibly a channel slice of a wider buffer: element (n,h,w,c) lives at
+ * ptr + (((n*H + h)*W + w) * pitch + c).  ptr 16-byte aligned, pitch a multiple of 8. */
+typedef struct {
+  void* ptr;
+  int64_t pitch;   /* elements from one pixel to the next (>= C) */
+  int32_t N, H, W, C;
+} gsd_nhwc;
+
+/* Row padding of the m (output channel) dimension in every bf16 weight image: gsd_bf16_conv_mpad(M) rows. */
+int gsd_bf16_conv_mpad(int M);
+
+/* conv3x3 p1 s1, no bias (unet.py:11,14; with a dgrad weight image the dX half of its backward):
+ *   out[n,h,w,m] = sum_{t,k} in[n,h+t/3-1,w+t%3-1,k] * wt[t][m][k];  wt: [9][mpad(M)][K] bf16, K % 32 == 0, M % 16 == 0.
+ * partials (or NULL): per-block BatchNorm partial sums of the STORED (rounded) values, gsd_bf16_conv_partial_rows rows of
+ * 2*mpad(M) floats, to be reduced with gsd_bn_reduce_partials(partials, rows, mpad(M), M, ...) from gsd.h. */
+int gsd_bf16_conv_partial_rows(int N, int H, int W, int M);
+int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials, void* stream);
+
+/* Taps without spatial reuse on an (N,H,W) pixel grid:
+ *   acc[n,h,w,m] = sum_{t<ntaps} sum_k in[n, stride*h+ty[t], stride*w+tx[t], k] * wt[t][m][k]   (zeros outside in)
+ * scatter_cs == 0: out[n,h,w,m] = acc (+ bias[m]).   -- 1x1 convolution (first layer after gsd_bf16_im2col3x3)
+ * scatter_cs  > 0: M == 4*scatter_cs, m = q*Cs + co: out[n, 2h+(q>>1)+oy, 2w+(q&1)+ox, co] = acc + bias[co]
+ *                  -- ConvTranspose2d(k=2,s=2) forward written straight into its F.pad position inside the concat
+ *                     buffer (unet.py:36,41,46-48).
+ * With 4 taps at stride 2 and a dgrad weight image it is the dX of that ConvTranspose2d. */
+int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
+                        const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
+                        float* partials, void* stream);
+
+/* ---- weight images (fp32 master -> bf16 GEMM layout [T][mpad(M)][round_up(K,32)], zero padded) ---------------------
+ * mode 0 conv3x3 forward  from (Cout,Cin,3,3):  [t][co][ci]
+ *      1 conv3x3 dX       from (Cout,Cin,3,3):  [t][ci][co] with the tap flipped (8-t)
+ *      2 first layer on the im2col'd input:     [0][co][ci*9+t]
+ *      3 ConvTranspose2d forward from (Cin,Cout,2,2): [0][(kh*2+kw)*Cout+co][ci]
+ *      4 ConvTranspose2d dX:                         [kh*2+kw][ci][co]                                             */
+int64_t gsd_bf16_weight_image_size(int mode, int Cout, int Cin);
+int gsd_bf16_weight_image(int mode, const float* w, int Cout, int Cin, void* out, void* stream);
+
+/* First layer: x (N,C,H,W) fp32 NCHW -> col (N,H,W,round_up(9C,32)) bf16 with col[..,c*9+t] = x[n,c,h+t/3-1,w+t%3-1]
+ * (zero padded), so that conv3x3(x) is a 1x1 convolution of col (gsd_bf16_conv_dense). unet.py:11 for `inc`. */
+int gsd_bf16_im2col3x3(const float* x, int N, int C, int H, int W, const gsd_nhwc* col, void* stream);
+
+/* a = y*scale[c] + shift[c], then max(0,.) if relu: BatchNorm2d (batch or running statistics folded into scale/shift
+ * by gsd_bn_finalize / gsd_bn_eval_coeffs) + ReLU (unet.py:12-13,15-16). `a` may be a channel slice of a concat buffer. */
+int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a, int relu, void* stream);
+
+/* MaxPool2d(2), floor mode (unet.py:26). */
+int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream);
+
+/* OutConv: out (N,K,H,W) fp32 NCHW = conv1x1(a; w (K,C), bias) (unet.py:54), K <= 4. */
+int gsd_bf16_conv1x1_out(const gsd_nhwc* a, const float* w, const float* bias, int K, float* out, void* stream);
+
+/* BatchNorm+ReLU backward, pass 1 (+ the adjoining max-pool / output-conv backward), as gsd_bn_bwd_reduce in gsd.h:
+ *   da = g                                  (mode 0)
+ *      = g + maxpool2 backward of dpool     (mode 1: arg-max over the STORED activations a, first maximum wins)
+ *      = dout[n,0,h,w] * wout[c]            (mode 2: n_classes == 1; third partial = sum dout * a -> dW of the OutConv)
+ *   dz = da where y*scale+shift > 0 else 0, written to `dz` (may alias g);
+ *   partials: gsd_bf16_bn_bwd_partial_rows rows of [sum dz | sum dz*xhat | third] (3*C floats), to be reduced with
+ *   gsd_bn_bwd_reduce_partials / gsd_bn_bwd_finalize from gsd.h. */
+int gsd_bf16_bn_bwd_partial_rows(int N, int H, int W);
+int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const gsd_nhwc* dpool,
+                           const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream);
+/* pass 2, in place: dz <- scale * (dz - c1 - xhat * c2), the gradient w.r.t. the raw convolution output. */
+int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* scale, const float* mean, const float* invstd,
+                          const float* c1, const float* c2, void* stream);
+
+/* ---- weight gradients --------------------------------------------------------------------------------------------
+ *   D[t][m][n] = sum_{n_img,h,w} a[n_img,h,w,m] * b[n_img, stride*h+ty[t], stride*w+tx[t], n]   (zeros outside b)
+ *   dw[(m*ncols_out + n)*ntaps + t] = D[t][m][n]   for n < ncols_out          (fp32; overwritten, not accumulated)
+ * conv3x3 (unet.py:11,14):  a = dy, b = layer input, 9 taps (t/3-1, t%3-1)      -> dw == dW (Cout,Cin,3,3)
+ * first layer:              a = dy, b = im2col'd input, 1 tap, ncols_out = 9*Cin -> dw == dW (Cout,Cin,3,3)
+ * ConvTranspose2d (unet.py:36): a = x, b = gradient of its (padded) output slice, taps (kh+oy, kw+ox) at stride 2
+ *                                                                               -> dw == dW (Cin,Cout,2,2)
+ * workspace: gsd_bf16_wgrad_workspace(ntaps, N, H, W, a->C, b->C) floats (split-K slabs, summed in a fixed order). */
+int64_t gsd_bf16_wgrad_workspace(int ntaps, int N, int H, int W, int M, int Ncols);
+int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, int stride, const int* ty, const int* tx, float* dw,
+                   int ncols_out, float* workspace, int64_t workspace_elems, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSD_BF16_H */

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads here (no GPU) and exports every symbol include/gsd.h declares; the ctypes
+"""CPU: the C-ABI library loads here (no GPU) and exports every symbol include/*.h declares; the ctypes
 binding lists exactly those symbols.  No compute call is made."""
 import ctypes
 import os
@@ -8,9 +8,13 @@ from conftest import REPO
 
 
 def header_functions():
-    src = open(os.path.join(REPO, "include", "gsd.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gsd_[a-z0-9_A-Z]+)\s*\(", src)))
+    names = set()
+    inc = os.path.join(REPO, "include")
+    for f in sorted(os.listdir(inc)):
+        if f.endswith(".h"):
+            src = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, f)).read(), flags=re.S)
+            names |= set(re.findall(r"\b(gsd_[a-z0-9_A-Z]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -21,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
-        assert hasattr(raw, n), f"{n} declared in gsd.h but not exported by libgsd.so"
+        assert hasattr(raw, n), f"{n} declared in include/*.h but not exported by libgsd.so"
     assert sorted(_lib.SIGNATURES.keys()) == names
     assert "gfx950" in _lib.version()
 
@@ -32,6 +36,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.gsd_src) == 3 * 8 + 6 * 4 + 2 * 8
     assert ctypes.sizeof(_lib.gsd_dst) == 8 + 5 * 4 + 4 + 2 * 8
     assert _lib.gsd_src.n_stride.offset == 48 and _lib.gsd_dst.n_stride.offset == 32
+    assert ctypes.sizeof(_lib.gsd_nhwc) == 8 + 8 + 4 * 4 and _lib.gsd_nhwc.N.offset == 16
 
 
 def test_product_never_imports_oracle():

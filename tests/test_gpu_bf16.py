@@ -1,0 +1,313 @@
+"""GPU parity of the bf16 mixed-precision kernel family (include/gsd_bf16.h) against fp64 torch-CPU evaluations of the
+same contractions on the SAME bf16-rounded operands: what is left is fp32 accumulation order and the final rounding of
+the result to bf16 (half an ulp = 2^-9 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 2.0 ** -8      # one bf16 ulp, relative, per element (rounding of the stored result + accumulation noise)
+
+
+def _lib():
+    from gelslim_depth_amd import _lib as L
+    return L
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def to_nhwc(x, c_total=None, c_off=0):
+    """(N,C,H,W) float -> contiguous (N,H,W,c_total) bf16 CUDA buffer holding x in channels [c_off, c_off+C)."""
+    n, c, h, w = x.shape
+    ct = c if c_total is None else c_total
+    buf = torch.full((n, h, w, ct), 7.0, dtype=torch.bfloat16)       # 7: a wrong read of a neighbouring slice shows up
+    buf[..., c_off:c_off + c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return buf.cuda()
+
+
+def from_nhwc(buf, c_off, c):
+    return buf[..., c_off:c_off + c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def weight_image(w_tmk):
+    """(T, M, K) float -> (T, mpad(M), K) bf16 on the GPU, zero padded rows."""
+    L = _lib()
+    t, m, k = w_tmk.shape
+    mp = L.lib.gsd_bf16_conv_mpad(m)
+    img = torch.zeros((t, mp, k), dtype=torch.bfloat16)
+    img[:, :m] = w_tmk.to(torch.bfloat16)
+    return img.cuda()
+
+
+def assert_close_bf16(got, ref, what):
+    err = (got.double() - ref.double()).abs()
+    tol = BF16_TOL * ref.double().abs() + 1e-3 * float(ref.abs().max()) * BF16_TOL * 4
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} of {bad.numel()} off, worst {float((err / (ref.abs() + 1e-6)).max()):.3e}"
+
+
+@pytest.mark.parametrize("n,h,w,k,m,in_tot,in_off,out_tot,out_off", [
+    (2, 20, 26, 64, 128, 64, 0, 128, 0),        # 128x256 tile, bottom-level extent, K two chunks
+    (1, 33, 70, 32, 64, 96, 32, 64, 0),         # 64x512 tile, input is a channel slice
+    (2, 17, 21, 96, 48, 96, 0, 80, 16),         # M not a multiple of 64, output is a channel slice, 3 chunks
+    (1, 40, 53, 128, 256, 128, 0, 256, 0),      # two m-blocks
+])
+def test_conv3x3_bf16(n, h, w, k, m, in_tot, in_off, out_tot, out_off):
+    L = _lib()
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + m)
+    x = bf16r(torch.randn((n, k, h, w), generator=g))
+    wt = bf16r(torch.randn((m, k, 3, 3), generator=g) / (3.0 * k ** 0.5))
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    xin = to_nhwc(x, in_tot, in_off)
+    out = torch.full((n, h, w, out_tot), 5.0, dtype=torch.bfloat16, device="cuda")
+    img = weight_image(wt.permute(2, 3, 0, 1).reshape(9, m, k))
+    rows = L.lib.gsd_bf16_conv_partial_rows(n, h, w, m)
+    mp = L.lib.gsd_bf16_conv_mpad(m)
+    part = torch.zeros((rows, 2 * mp), dtype=torch.float32, device="cuda")
+    din, dout = L.make_nhwc(xin, in_off, k), L.make_nhwc(out, out_off, m)
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), k, m, part.data_ptr(), L.stream_ptr()), "conv")
+    torch.cuda.synchronize()
+    got = from_nhwc(out, out_off, m)
+    assert_close_bf16(got, ref, "conv3x3")
+    # channels outside the slice are untouched
+    if out_tot > m:
+        rest = torch.cat([out[..., :out_off], out[..., out_off + m:]], dim=-1).float()
+        assert bool((rest == 5.0).all())
+    # BatchNorm partial sums are those of the stored values
+    sums = torch.zeros((65 * 2 * m,), dtype=torch.float64, device="cuda")
+    L.check(L.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mp, m, sums.data_ptr(), L.stream_ptr()), "reduce")
+    s = sums[:2 * m].cpu()
+    assert torch.allclose(s[:m], got.double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[m:], (got.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+def test_dense_1x1_and_convT_bf16():
+    L = _lib()
+    g = torch.Generator().manual_seed(5)
+    # 1x1 (the im2col'd first layer): K 32 -> M 64
+    n, h, w, k, m = 2, 21, 37, 32, 64
+    x = bf16r(torch.randn((n, k, h, w), generator=g))
+    wt = bf16r(torch.randn((m, k), generator=g) / k ** 0.5)
+    ref = torch.einsum("nkhw,mk->nmhw", x.double(), wt.double())
+    xin, out = to_nhwc(x), torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    din, dout = L.make_nhwc(xin), L.make_nhwc(out)
+    z = L.int_array([0])
+    img1 = weight_image(wt[None])
+    L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img1.data_ptr(), C.byref(dout), k, m, 1, 1, z, z, h, w, 0, 0,
+                                      0, None, None, L.stream_ptr()), "1x1")
+    assert_close_bf16(from_nhwc(out, 0, m), ref, "1x1")
+
+    # ConvTranspose2d(k2,s2)+bias scattered into the second half of a concat buffer, with the F.pad offset (0,1)
+    n, h, w, cin, cout = 2, 10, 13, 64, 32
+    x = bf16r(torch.randn((n, cin, h, w), generator=g))
+    wT = bf16r(torch.randn((cin, cout, 2, 2), generator=g) / cin ** 0.5)
+    bias = torch.randn((cout,), generator=g)
+    ref = F.conv_transpose2d(x.double(), wT.double(), bias.double(), stride=2)            # (n, cout, 2h, 2w)
+    cat = torch.zeros((n, 2 * h + 1, 2 * w + 1, 2 * cout), dtype=torch.bfloat16, device="cuda")
+    img = weight_image(wT.permute(2, 3, 1, 0).reshape(1, 4 * cout, cin))                    # m = (kh*2+kw)*cout + co
+    xin = to_nhwc(x)
+    din, dout = L.make_nhwc(xin), L.make_nhwc(cat, cout, cout)
+    bias_d = bias.cuda()
+    L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img.data_ptr(), C.byref(dout), cin, 4 * cout, 1, 1, z, z, h, w, cout, 0, 1,
+                                      bias_d.data_ptr(), None, L.stream_ptr()), "convT")
+    got = cat.float().cpu()
+    assert_close_bf16(got[:, 0:2 * h, 1:2 * w + 1, cout:].permute(0, 3, 1, 2), ref, "convT")
+    assert float(got[..., :cout].abs().max()) == 0.0 and float(got[:, 2 * h:].abs().max()) == 0.0
+    assert float(got[:, :, 0].abs().max()) == 0.0
+
+    # its dX: 4 taps at stride 2 over the (cropped) gradient slice
+    gy = bf16r(torch.randn((n, cout, 2 * h, 2 * w), generator=g))
+    gcat = torch.zeros((n, 2 * h + 1, 2 * w + 1, 2 * cout), dtype=torch.bfloat16)
+    gcat[:, 0:2 * h, 1:2 * w + 1, cout:] = gy.permute(0, 2, 3, 1).to(torch.bfloat16)
+    gcat = gcat.cuda()
+    xd = x.double().requires_grad_(True)
+    F.conv_transpose2d(xd, wT.double(), None, stride=2).backward(gy.double())
+    img_d = weight_image(wT.permute(2, 3, 0, 1).reshape(4, cin, cout))                      # [q][ci][co]
+    dx = torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device="cuda")
+    din, dout = L.make_nhwc(gcat, cout, cout), L.make_nhwc(dx)
+    ty, tx = L.int_array([0, 0, 1, 1]), L.int_array([1, 2, 1, 2])                            # (kh, kw + pad offset 1)
+    L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img_d.data_ptr(), C.byref(dout), cout, cin, 4, 2, ty, tx, h, w, 0, 0, 0,
+                                      None, None, L.stream_ptr()), "convT dgrad")
+    assert_close_bf16(from_nhwc(dx, 0, cin), xd.grad, "convT dX")
+
+
+def _wgrad(L, a_buf, a_off, m, b_buf, b_off, ncols, ntaps, stride, ty, tx, ncols_out):
+    da, db = L.make_nhwc(a_buf, a_off, m), L.make_nhwc(b_buf, b_off, ncols)
+    n, h, w = a_buf.shape[0], a_buf.shape[1], a_buf.shape[2]
+    ws_n = L.lib.gsd_bf16_wgrad_workspace(ntaps, n, h, w, m, ncols)
+    ws = torch.empty((ws_n,), dtype=torch.float32, device="cuda")
+    dw = torch.full((m * ncols_out * ntaps,), 3.0, dtype=torch.float32, device="cuda")
+    L.check(L.lib.gsd_bf16_wgrad(C.byref(da), C.byref(db), ntaps, stride, L.int_array(ty), L.int_array(tx), dw.data_ptr(),
+                                 ncols_out, ws.data_ptr(), ws_n, L.stream_ptr()), "wgrad")
+    return dw.cpu()
+
+
+T3Y = [t // 3 - 1 for t in range(9)]
+T3X = [t % 3 - 1 for t in range(9)]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,b_tot,b_off", [
+    (2, 20, 45, 64, 128, 64, 0),       # 128 x 32 tiles, two n-blocks
+    (1, 9, 70, 96, 64, 96, 0),         # 64 x 64 tiles (M <= 64), ragged n-block
+    (2, 21, 27, 32, 48, 96, 64),       # M not a multiple of the tile, B a channel slice of a concat buffer
+    (1, 40, 53, 128, 256, 128, 0),     # two m-blocks
+])
+def test_wgrad_conv3x3_bf16(n, h, w, cin, cout, b_tot, b_off):
+    L = _lib()
+    g = torch.Generator().manual_seed(h * 100 + cout)
+    a_in = bf16r(torch.randn((n, cin, h, w), generator=g))
+    dy = bf16r(torch.randn((n, cout, h, w), generator=g))
+    wt = torch.zeros((cout, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(a_in.double(), wt, padding=1).backward(dy.double())
+    got = _wgrad(L, to_nhwc(dy), 0, cout, to_nhwc(a_in, b_tot, b_off), b_off, cin, 9, 1, T3Y, T3X, cin).reshape(cout, cin, 3, 3)
+    ref = wt.grad
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "conv3x3 dW"
+
+
+def test_wgrad_first_layer_and_convT_bf16():
+    L = _lib()
+    g = torch.Generator().manual_seed(9)
+    # first layer: dy (64 ch) against the im2col'd 3-channel input produced by gsd_bf16_im2col3x3
+    n, h, w = 2, 19, 33
+    x = torch.rand((n, 3, h, w), generator=g)
+    dy = bf16r(torch.randn((n, 64, h, w), generator=g))
+    col = torch.zeros((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
+    dcol = L.make_nhwc(col)
+    x_d = x.cuda()
+    L.check(L.lib.gsd_bf16_im2col3x3(x_d.data_ptr(), n, 3, h, w, C.byref(dcol), L.stream_ptr()), "im2col")
+    unf = F.unfold(x, 3, padding=1).reshape(n, 27, h, w)                       # k = c*9 + t
+    colr = col.float().cpu()
+    assert torch.equal(colr[..., :27], bf16r(unf).permute(0, 2, 3, 1)) and float(colr[..., 27:].abs().max()) == 0.0
+    wt = torch.zeros((64, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(bf16r(x).double(), wt, padding=1).backward(dy.double())
+    got = _wgrad(L, to_nhwc(dy), 0, 64, col, 0, 32, 1, 1, [0], [0], 27).reshape(64, 3, 3, 3)
+    assert float((got.double() - wt.grad).abs().max()) <= 2e-5 * float(wt.grad.abs().max())
+    # ConvTranspose2d dW: a = x (64 ch, low res), b = gradient slice of the concat buffer at pad offset (1, 0)
+    n, h, w, cin, cout = 2, 10, 13, 64, 32
+    xs = bf16r(torch.randn((n, cin, h, w), generator=g))
+    gy = bf16r(torch.randn((n, cout, 2 * h, 2 * w), generator=g))
+    gcat = torch.zeros((n, 2 * h + 1, 2 * w, 2 * cout), dtype=torch.bfloat16)
+    gcat[:, 1:2 * h + 1, :, cout:] = gy.permute(0, 2, 3, 1).to(torch.bfloat16)
+    wT = torch.zeros((cin, cout, 2, 2), dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(xs.double(), wT, None, stride=2).backward(gy.double())
+    got = _wgrad(L, to_nhwc(xs), 0, cin, gcat.cuda(), cout, cout, 4, 2, [1, 1, 2, 2], [0, 1, 0, 1], cout).reshape(cin, cout, 2, 2)
+    assert float((got.double() - wT.grad).abs().max()) <= 2e-5 * float(wT.grad.abs().max())
+
+
+def test_weight_images_bf16():
+    L = _lib()
+    g = torch.Generator().manual_seed(3)
+    cout, cin = 48, 40
+    w = torch.randn((cout, cin, 3, 3), generator=g)
+    wT = torch.randn((cin, cout, 2, 2), generator=g)
+    w0 = torch.randn((cout, 3, 3, 3), generator=g)
+
+    def image(mode, src, co, ci):
+        nel = L.lib.gsd_bf16_weight_image_size(mode, co, ci)
+        out = torch.full((nel,), 9.0, dtype=torch.bfloat16, device="cuda")
+        src_d = src.cuda()
+        L.check(L.lib.gsd_bf16_weight_image(mode, src_d.data_ptr(), co, ci, out.data_ptr(), L.stream_ptr()), "wimg")
+        torch.cuda.synchronize()
+        return out.float().cpu()
+    r32 = lambda v: (v + 31) // 32 * 32          # noqa: E731
+    r128 = lambda v: (v + 127) // 128 * 128      # noqa: E731
+    i0 = image(0, w, cout, cin).reshape(9, r128(cout), r32(cin))
+    assert torch.equal(i0[:, :cout, :cin], bf16r(w).permute(2, 3, 0, 1).reshape(9, cout, cin))
+    assert float(i0[:, cout:].abs().max()) == 0.0 and float(i0[:, :, cin:].abs().max()) == 0.0
+    i1 = image(1, w, cout, cin).reshape(9, r128(cin), r32(cout))
+    assert torch.equal(i1[:, :cin, :cout], bf16r(w).flip(2, 3).permute(2, 3, 1, 0).reshape(9, cin, cout))
+    i2 = image(2, w0, cout, 3).reshape(1, r128(cout), 32)
+    assert torch.equal(i2[0, :cout, :27], bf16r(w0).reshape(cout, 27)) and float(i2[0, :, 27:].abs().max()) == 0.0
+    i3 = image(3, wT, cout, cin).reshape(1, r128(4 * cout), r32(cin))
+    assert torch.equal(i3[0, :4 * cout, :cin], bf16r(wT).permute(2, 3, 1, 0).reshape(4 * cout, cin))
+    i4 = image(4, wT, cout, cin).reshape(4, r128(cin), r32(cout))
+    assert torch.equal(i4[:, :cin, :cout], bf16r(wT).permute(2, 3, 0, 1).reshape(4, cin, cout))
+
+
+def test_pointwise_forward_bf16():
+    L = _lib()
+    g = torch.Generator().manual_seed(4)
+    n, h, w, c = 2, 11, 15, 40
+    y = bf16r(torch.randn((n, c, h, w), generator=g))
+    scale, shift = torch.rand((c,), generator=g) + 0.5, torch.randn((c,), generator=g)
+    ybuf = to_nhwc(y)
+    cat = torch.zeros((n, h, w, c + 24), dtype=torch.bfloat16, device="cuda")
+    dy_, da_ = L.make_nhwc(ybuf), L.make_nhwc(cat, 0, c)
+    sc_d, sh_d = scale.cuda(), shift.cuda()          # keep device copies alive across the launch
+    L.check(L.lib.gsd_bf16_bn_apply(C.byref(dy_), sc_d.data_ptr(), sh_d.data_ptr(), C.byref(da_), 1, L.stream_ptr()), "bn_apply")
+    a_ref = bf16r(torch.relu(torch.addcmul(shift[None, :, None, None], y, scale[None, :, None, None])))
+    a_got = from_nhwc(cat, 0, c)
+    assert float((a_got - a_ref).abs().max()) <= 2.0 ** -7 * float(a_ref.abs().max())     # fma vs mul+add: <= 1 ulp
+    assert float(cat[..., c:].float().abs().max()) == 0.0
+    pooled = torch.zeros((n, h // 2, w // 2, c), dtype=torch.bfloat16, device="cuda")
+    dp_ = L.make_nhwc(pooled)
+    L.check(L.lib.gsd_bf16_maxpool2(C.byref(da_), C.byref(dp_), L.stream_ptr()), "maxpool")
+    assert torch.equal(from_nhwc(pooled, 0, c), F.max_pool2d(a_got, 2))
+    wout, bout = torch.randn((1, c), generator=g), torch.randn((1,), generator=g)
+    out = torch.zeros((n, 1, h, w), device="cuda")
+    wo_d, bo_d = wout.cuda(), bout.cuda()
+    L.check(L.lib.gsd_bf16_conv1x1_out(C.byref(da_), wo_d.data_ptr(), bo_d.data_ptr(), 1, out.data_ptr(), L.stream_ptr()), "outc")
+    ref = F.conv2d(a_got.double(), wout.double()[:, :, None, None], bout.double())
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_bn_bwd_bf16(mode):
+    """Pass 1 (mask, pooled-gradient routing, output-conv gradient, per-channel sums) and pass 2 against torch fp64."""
+    L = _lib()
+    g = torch.Generator().manual_seed(10 + mode)
+    n, h, w, c = 2, 13, 18, 72
+    y = bf16r(torch.randn((n, c, h, w), generator=g))
+    gamma, beta = torch.rand((c,), generator=g) + 0.5, 0.3 * torch.randn((c,), generator=g)
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    yn = torch.addcmul(shift[None, :, None, None], y, scale[None, :, None, None])
+    a = bf16r(torch.relu(yn))
+    dev = lambda t: t.cuda()     # noqa: E731
+    ybuf, abuf = to_nhwc(y), to_nhwc(a)
+    gsrc = bf16r(torch.randn((n, c, h, w), generator=g))
+    dpool = bf16r(torch.randn((n, c, h // 2, w // 2), generator=g))
+    dout = torch.randn((n, 1, h, w), generator=g)
+    wout = torch.randn((1, c), generator=g)
+    if mode == 0:
+        da = gsrc.clone()
+    elif mode == 1:
+        ad = a.double().requires_grad_(True)
+        F.max_pool2d(ad, 2).backward(dpool.double())          # torch routes to the first maximum, like the kernel
+        da = gsrc + ad.grad.float()
+    else:
+        da = dout * wout[0][None, :, None, None]
+    dz_ref = torch.where(yn > 0, da, torch.zeros_like(da))
+    gbuf, pbuf = to_nhwc(gsrc), to_nhwc(dpool)
+    dzbuf = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device="cuda")
+    rows = L.lib.gsd_bf16_bn_bwd_partial_rows(n, h, w)
+    part = torch.zeros((rows, 3 * c), dtype=torch.float32, device="cuda")
+    keep = [dev(scale), dev(shift), dev(mean), dev(invstd), dev(dout), dev(wout)]
+    L.check(L.lib.gsd_bf16_bn_bwd_reduce(mode, C.byref(L.make_nhwc(ybuf)), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                         keep[3].data_ptr(), C.byref(L.make_nhwc(gbuf)), C.byref(L.make_nhwc(abuf)),
+                                         C.byref(L.make_nhwc(pbuf)), keep[4].data_ptr(), keep[5].data_ptr(),
+                                         C.byref(L.make_nhwc(dzbuf)), part.data_ptr(), L.stream_ptr()), "bn_bwd_reduce")
+    dz_got = from_nhwc(dzbuf, 0, c)
+    assert float((dz_got - bf16r(dz_ref)).abs().max()) <= 2.0 ** -7 * float(dz_ref.abs().max())
+    sums = part.double().sum(dim=0).cpu()
+    xhat = (y - mean[None, :, None, None]) * invstd[None, :, None, None]
+    assert torch.allclose(sums[:c], dz_got.double().sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(sums[c:2 * c], (dz_got.double() * xhat.double()).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    if mode == 2:
+        assert torch.allclose(sums[2 * c:], (dout.double() * a.double()).sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    cnt = float(n * h * w)
+    c1, c2 = (sums[:c] / cnt).float(), (sums[c:2 * c] / cnt).float()
+    keep2 = [dev(c1), dev(c2)]
+    L.check(L.lib.gsd_bf16_bn_bwd_apply(C.byref(L.make_nhwc(dzbuf)), C.byref(L.make_nhwc(ybuf)), keep[0].data_ptr(), keep[2].data_ptr(),
+                                        keep[3].data_ptr(), keep2[0].data_ptr(), keep2[1].data_ptr(), L.stream_ptr()), "bn_bwd_apply")
+    ref = scale[None, :, None, None] * (dz_got - c1[None, :, None, None] - xhat * c2[None, :, None, None])
+    got = from_nhwc(dzbuf, 0, c)
+    assert float((got - bf16r(ref)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
