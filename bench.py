@@ -25,6 +25,7 @@ import torch  # noqa: E402
 DIMS = [64, 128, 256, 512, 1024]
 H, W = 320, 427
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: bf16 MFMA dense peak (not the 2:1-sparsity figure)
 
 
 def host_cores() -> int:
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the metric's arithmetic (BASELINE configs[1-3], default); bf16: mixed precision, configs[4]")
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train: BASELINE configs[2] (the metric, default); infer: configs[1], eval-mode forward only")
     args = ap.parse_args()
@@ -106,7 +109,7 @@ def main():
     from gelslim_depth_amd.models.unet import UNet
     from gelslim_depth_amd.train import TrainStep
 
-    model = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS)
+    model = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS, precision="bf16" if args.dtype == "bf16" else "fp32")
     st = synth.make_state(3, 1, DIMS, 0, "conditioned")            # random-init weights of the named architecture
     model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
     model = model.to(dev).train()
@@ -156,7 +159,8 @@ def main():
 
     if rank == 0:
         # dominant kernel: the 128x128-tile conv3x3 implicit GEMM (forward + dgrad of every layer with >64 out channels)
-        dom = "conv3x3_dma_kernel<2,2>"
+        dom = "conv3x3_dma_kernel<2,2>" if args.dtype == "f32" else "bf16_conv3x3"
+        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
         flops = sum(f for v, f, _, _, _ in klog if v == dom)
         ms = sum(a.elapsed_time(b) for v, _, a, b, _ in klog if v == dom)
         launches = sum(1 for v, _, _, _, _ in klog if v == dom)
@@ -170,14 +174,25 @@ def main():
                 d[0] += f
                 d[1] += a.elapsed_time(b)
                 d[2] += 1
-            for sig, (f, t, c) in agg.items():
-                print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
-                      (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
+            if args.dtype == "bf16":
+                byname = collections.OrderedDict()
+                for v, f, a, b, _ in klog:
+                    d = byname.setdefault(v, [0.0, 0.0, 0])
+                    d[0] += f
+                    d[1] += a.elapsed_time(b)
+                    d[2] += 1
+                for v, (f, t, c) in byname.items():
+                    print("%-16s launches %4d total %.2f ms/step  %.1f TFLOP/s" %
+                          (v, c, t / args.steps, f / (t * 1e-3) / 1e12), file=sys.stderr)
+            else:
+                for sig, (f, t, c) in agg.items():
+                    print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
+                          (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json)
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            if tj.get("kernel") == dom and B == 32:
+            if tj.get("kernel") == dom and B == 32 and args.dtype == "f32":
                 traffic = round(float(tj["hbm_bytes_per_launch"]))
         except (OSError, ValueError, KeyError):
             pass
@@ -194,9 +209,12 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.global_batch > 0 else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: batch-32 full train step (fwd+MSE+bwd+Adam+EMA) fp32, "
+            "config": {"workload": (("BASELINE.json configs[2]: batch-%d full train step (fwd+MSE+bwd+Adam+EMA) fp32, " % B
+                                     if args.dtype == "f32" else
+                                     "BASELINE.json configs[4] (per-GPU share): batch-%d full train step, bf16 mixed precision "
+                                     "(bf16 NHWC activations on bf16 MFMA, fp32 master weights/statistics/Adam), " % B) +
                                     "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels")
                                    if args.workload == "train" else
                                    ("BASELINE.json configs[1]: eval-mode forward fp32, 3x320x427 -> 1x320x427, "
@@ -204,8 +222,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6)},
             "roofline": {"bound": "mfma", "kernel": dom,
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
                          "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,

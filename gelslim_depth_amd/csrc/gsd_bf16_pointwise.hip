@@ -278,6 +278,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(NhwcD dz, NhwcD 
   st16(dz.p + p * dz.pitch + gk * 8, pack8(d));
 }
 
+// ---- per-channel sums over a window of every image (ConvTranspose2d bias gradient) -------------------------------------
+// stage 1: grid (chunks, N), same thread layout as the BatchNorm reduction; stage 2: one thread per channel, fp64
+__global__ __launch_bounds__(256) void channel_sums_stage1(NhwcD t, int y0, int x0, int hh, int ww, int pixb, int chunks,
+                                                           float* __restrict__ ws) {
+  extern __shared__ float red[];   // [256][8]
+  const int C = t.C, groups = C >> 3;
+  const int tpp = groups < 256 ? groups : 256, ppi = 256 / tpp;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int pl = threadIdx.x / tpp, gl = threadIdx.x - pl * tpp;
+  const int p_end = min((chunk + 1) * pixb, hh * ww);
+  for (int gk = gl; gk < groups; gk += tpp) {
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    for (int p = chunk * pixb + pl; p < p_end && pl < ppi; p += ppi) {
+      const int r = p / ww, c = p - r * ww;
+      float f[8];
+      unpack8(ld16(t.p + (((long long)n * t.H + y0 + r) * t.W + x0 + c) * t.pitch + gk * 8), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+    __syncthreads();
+    if (pl == 0) {
+      float* row = ws + (size_t)(n * chunks + chunk) * C;
+      for (int i = 0; i < 8; ++i) {
+        float a = 0.f;
+        for (int r = 0; r < ppi; ++r) a += red[(r * tpp + gl) * 8 + i];
+        row[gk * 8 + i] = a;
+      }
+    }
+  }
+}
+__global__ void channel_sums_stage2(const float* __restrict__ ws, int rows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)ws[(size_t)r * C + c];
+  out[c] = (float)s;
+}
+
 int pick_pixb(int N, int HW) {
   long long pixb = ((long long)N * HW + 2047) / 2048;
   pixb = (pixb + 31) / 32 * 32;
@@ -412,5 +455,28 @@ extern "C" int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, cons
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      to_nhwc(*dz), to_nhwc(*y), scale, mean, invstd, c1, c2, np);
   GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_apply");
+  return GSD_OK;
+}
+
+extern "C" int64_t gsd_bf16_channel_sums_workspace(int N, int hh, int ww, int C) {
+  if (N <= 0 || hh <= 0 || ww <= 0 || C <= 0) return 0;
+  return (int64_t)N * ceil_div(hh * ww, pick_pixb(N, hh * ww)) * C;
+}
+
+extern "C" int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, int ww, float* out, float* workspace,
+                                     int64_t workspace_elems, void* stream) {
+  if (int e = check_c8(t, "gsd_bf16_channel_sums t")) return e;
+  GSD_REQUIRE(out && workspace && y0 >= 0 && x0 >= 0 && hh > 0 && ww > 0 && y0 + hh <= t->H && x0 + ww <= t->W, GSD_ERR_BAD_ARG,
+              "gsd_bf16_channel_sums: window (%d,%d)+(%d,%d) outside (%d,%d)", y0, x0, hh, ww, t->H, t->W);
+  GSD_REQUIRE(t->N <= 65535 && (t->C <= 2048 || t->C % 2048 == 0), GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_channel_sums: N must be <= 65535 and C <= 2048 or a multiple of 2048");
+  const int pixb = pick_pixb(t->N, hh * ww), chunks = ceil_div(hh * ww, pixb);
+  GSD_REQUIRE(workspace_elems >= (int64_t)t->N * chunks * t->C, GSD_ERR_WORKSPACE, "gsd_bf16_channel_sums: workspace too small");
+  hipLaunchKernelGGL(channel_sums_stage1, dim3(chunks, t->N), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream, to_nhwc(*t),
+                     y0, x0, hh, ww, pixb, chunks, workspace);
+  GSD_LAUNCH_CHECK("gsd_bf16_channel_sums stage1");
+  hipLaunchKernelGGL(channel_sums_stage2, dim3(ceil_div(t->C, 64)), dim3(64), 0, (hipStream_t)stream, workspace, t->N * chunks,
+                     t->C, out);
+  GSD_LAUNCH_CHECK("gsd_bf16_channel_sums stage2");
   return GSD_OK;
 }

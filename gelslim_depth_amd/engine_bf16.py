@@ -1,0 +1,377 @@
+"""Host-side schedule of the U-Net hot path in bf16 mixed precision (BASELINE.json configs[4]) over include/gsd_bf16.h.
+
+Same interface as engine.UNetEngine (forward / backward / sync_fn / block_done_cb / kernel_log), same reference control
+flow (/root/reference/gelslim_depth/models/unet.py:79-88), different data layout:
+
+  * activations and their gradients: bfloat16, NHWC.  Per conv unit u:
+        y[u]  raw convolution output           a[u]  relu(bn(y)) -- materialised (2 B/element, one extra HBM pass that
+        g[u]  gradient: da -> dz -> dy in place       costs <2 % of the step and lets every GEMM operand go HBM -> LDS by DMA)
+  * torch.cat([skip, up]) (unet.py:48) is ONE buffer cat[l] of C_skip + C_up channels per level: the encoder's BatchNorm
+    apply writes a[skip] into channels [0, C_skip), the transposed convolution scatters its output (+bias) into channels
+    [C_skip, ..) at its F.pad offset (unet.py:43-47; the padding border is zeroed once), the decoder conv reads the
+    buffer as one tensor.  gcat[l] is its gradient: one dX launch, whose two channel slices feed the skip unit's
+    BatchNorm backward and the transposed convolution's dX / dW.
+  * fp32: master parameters (the module's own tensors), every accumulation, BatchNorm statistics, gradients, Adam/EMA.
+    Per step each weight is re-laid-out to its bf16 GEMM image (gsd_bf16_weight_image).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+T3Y = [t // 3 - 1 for t in range(9)]
+T3X = [t % 3 - 1 for t in range(9)]
+
+
+def _r32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+class _Unit:
+    """conv3x3(no bias) + BatchNorm2d + ReLU (unet.py:11-13 / :14-16)."""
+
+    def __init__(self, prefix: str, conv_idx: int, bn_idx: int, cin: int, cout: int, level: int):
+        self.cin, self.cout, self.level = cin, cout, level
+        self.wname = f"{prefix}.double_conv.{conv_idx}.weight"
+        bn = f"{prefix}.double_conv.{bn_idx}."
+        self.gname, self.bname = bn + "weight", bn + "bias"
+        self.rmname, self.rvname, self.nbtname = bn + "running_mean", bn + "running_var", bn + "num_batches_tracked"
+        self.first = False          # the im2col'd first layer
+        self.need_dgrad = True
+        self.wt_f = self.wt_d = None
+        self.scale = self.shift = self.mean = self.invstd = self.c1 = self.c2 = self.sums = None
+        self.y = self.g = None      # (N,H,W,Cout) bf16
+        self.a = None               # gsd_nhwc view of the activation (own tensor or a slice of a concat buffer)
+        self.a_t = None             # tensor backing `a`
+        self.a_off = 0
+        self.src = None             # (tensor, c_off, c_len) of the unit's input, kept for the weight gradient
+
+
+class _Up:
+    """ConvTranspose2d(cin, cin//2, 2, 2) (unet.py:36)."""
+
+    def __init__(self, j: int, cin: int, level_in: int):
+        self.j, self.cin, self.cout, self.level_in = j, cin, cin // 2, level_in
+        self.wname, self.bname = f"up.{j}.up.weight", f"up.{j}.up.bias"
+        self.wt_f = self.wt_d = None
+
+
+class UNetEngineBF16:
+    precision = "bf16"
+
+    def __init__(self, n_channels: int, n_classes: int, layer_dimensions: Sequence[int]):
+        dims = list(layer_dimensions)
+        if any(d % 32 for d in dims):
+            raise ValueError(f"bf16 path needs layer_dimensions that are multiples of 32 (MFMA k-step), got {dims}")
+        if n_classes != 1:
+            raise NotImplementedError("bf16 path implements n_classes == 1 (what every reference config uses)")
+        self.n_channels, self.n_classes, self.dims = n_channels, n_classes, dims
+        self.L = len(dims) - 1
+        self.enc: List[Tuple[_Unit, _Unit]] = []
+        self.dec: List[Tuple[_Unit, _Unit]] = []
+        self.ups: List[_Up] = []
+        self.enc.append((_Unit("inc", 0, 1, n_channels, dims[0], 0), _Unit("inc", 3, 4, dims[0], dims[0], 0)))
+        self.enc[0][0].first = True
+        self.enc[0][0].need_dgrad = False
+        for i in range(self.L):
+            p = f"down.{i}.maxpool_conv.1"
+            self.enc.append((_Unit(p, 0, 1, dims[i], dims[i + 1], i + 1), _Unit(p, 3, 4, dims[i + 1], dims[i + 1], i + 1)))
+        for j, i in enumerate(range(self.L, 0, -1)):
+            cin, cout = dims[i], dims[i - 1]
+            if dims[i - 1] + cin // 2 != cin:
+                raise ValueError(f"layer_dimensions {dims}: level {i} needs dims[i-1] + dims[i]//2 == dims[i] "
+                                 "(the reference model fails at torch.cat/conv otherwise)")
+            self.ups.append(_Up(j, cin, i))
+            p = f"up.{j}.conv"
+            self.dec.append((_Unit(p, 0, 1, cin, cout, i - 1), _Unit(p, 3, 4, cout, cout, i - 1)))
+        self.units: List[_Unit] = [u for pair in self.enc for u in pair] + [u for pair in self.dec for u in pair]
+        self._shape = None
+        self.sync_fn: Optional[Callable[[torch.Tensor], None]] = None
+        self.world = 1
+        self._saved_train = False
+        self.block_done_cb: Optional[Callable[[str], None]] = None
+        self.kernel_log: Optional[list] = None
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
+        key = (n, h, w, str(dev), train)
+        if self._shape == key:
+            return
+        if self._shape is not None and self._shape[:4] == key[:4] and not train:
+            return                      # eval after train at the same shape: everything needed exists
+        self._shape = key
+        hs, ws = [h], [w]
+        for _ in range(self.L):
+            hs.append(hs[-1] // 2)
+            ws.append(ws[-1] // 2)
+        assert hs[-1] >= 1 and ws[-1] >= 1, "input too small for this many max-pools"
+        self.hs, self.ws = hs, ws
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.col0 = torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
+        # concat buffers (zeroed once: the F.pad border of the `up` slice is never written again)
+        self.cat = [torch.zeros((n, hs[l], ws[l], self.dims[l] + self.dims[l + 1] // 2), **bf) for l in range(self.L)]
+        self.gcat = [torch.empty_like(c) for c in self.cat] if train else [None] * self.L
+        self.pooled = [None] + [torch.empty((n, hs[l], ws[l], self.dims[l - 1]), **bf) for l in range(1, self.L + 1)]
+        self.dpooled = [None] + ([torch.empty_like(self.pooled[l]) for l in range(1, self.L + 1)] if train else [None] * self.L)
+        max_part, max_ws = 1, 64
+        for u in self.units:
+            self._alloc_unit(u, n, dev, train)
+        skips = {id(self.enc[l][1]) for l in range(self.L)}
+        for l in range(self.L):         # skip connection: the activation lives in the concat buffer
+            self.enc[l][1].a_t, self.enc[l][1].a_off = self.cat[l], 0
+        for u in self.units:
+            if id(u) not in skips and (u.a_t is None or tuple(u.a_t.shape) != (n, hs[u.level], ws[u.level], u.cout)):
+                u.a_t, u.a_off = torch.empty((n, hs[u.level], ws[u.level], u.cout), **bf), 0
+        for u in self.units:
+            lh, lw = hs[u.level], ws[u.level]
+            u.a = L.make_nhwc(u.a_t, u.a_off, u.cout)
+            mp = lib.gsd_bf16_conv_mpad(u.cout)
+            max_part = max(max_part, lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout) * 2 * mp)
+            if train:
+                max_part = max(max_part, lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw) * 3 * u.cout)
+                kcols = _r32(9 * u.cin) if u.first else u.cin
+                max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(1 if u.first else 9, n, lh, lw, u.cout, kcols))
+        for up in self.ups:
+            li = up.level_in
+            if up.wt_f is None or up.wt_f.device != dev:
+                up.wt_f = torch.empty((lib.gsd_bf16_weight_image_size(3, up.cout, up.cin),), **bf)
+                up.wt_d = torch.empty((lib.gsd_bf16_weight_image_size(4, up.cout, up.cin),), **bf)
+            if train:
+                max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(4, n, hs[li], ws[li], up.cin, up.cout))
+                max_ws = max(max_ws, lib.gsd_bf16_channel_sums_workspace(n, 2 * hs[li], 2 * ws[li], up.cout))
+        self.partials = torch.empty((max_part,), **f32)
+        self.wspace = torch.empty((max(max_ws, 64),), **f32) if train else None
+
+    def _alloc_unit(self, u: _Unit, n: int, dev: torch.device, train: bool) -> None:
+        lh, lw = self.hs[u.level], self.ws[u.level]
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        f32 = dict(device=dev, dtype=torch.float32)
+        if u.y is None or tuple(u.y.shape) != (n, lh, lw, u.cout):
+            u.y = torch.empty((n, lh, lw, u.cout), **bf)
+            u.g = None
+            u.a_t = None
+        if train and u.g is None:
+            u.g = torch.empty((n, lh, lw, u.cout), **bf)
+        if u.scale is None or u.scale.device != dev:
+            for nm in ("scale", "shift", "mean", "invstd", "c1", "c2"):
+                setattr(u, nm, torch.empty((u.cout,), **f32))
+            u.sums = torch.empty((65 * 3 * u.cout,), device=dev, dtype=torch.float64)
+            u.wt_f = torch.empty((lib.gsd_bf16_weight_image_size(2 if u.first else 0, u.cout, u.cin),), **bf)
+            u.wt_d = torch.empty((lib.gsd_bf16_weight_image_size(1, u.cout, u.cin),), **bf) if u.need_dgrad else None
+
+    # ------------------------------------------------------------------ helpers
+    def _pad_off(self, lvl: int) -> Tuple[int, int]:
+        # F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet.py:43-47)
+        dy = self.hs[lvl] - 2 * self.hs[lvl + 1]
+        dx = self.ws[lvl] - 2 * self.ws[lvl + 1]
+        return dy // 2, dx // 2
+
+    def _log(self, name: str, flops: float):
+        """bench hook: returns a closer that records (name, flops, start, end)."""
+        if self.kernel_log is None:
+            return lambda: None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+
+        def close():
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.kernel_log.append((name, flops, e0, e1, None))
+        return close
+
+    def _run_unit(self, u: _Unit, src: Tuple[torch.Tensor, int, int], P, train: bool, st: int) -> None:
+        n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
+        u.src = src
+        din = L.make_nhwc(*src)
+        dy = L.make_nhwc(u.y)
+        part = self.partials.data_ptr() if train else None
+        if u.first:
+            check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            z = L.int_array([0])
+            done = self._log("bf16_conv_dense", 2.0 * u.cout * src[2] * n * lh * lw)
+            check(lib.gsd_bf16_conv_dense(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), src[2], u.cout, 1, 1, z, z, lh, lw, 0, 0, 0,
+                                          None, part, st), "conv_dense(first)")
+            done()
+        else:
+            check(lib.gsd_bf16_weight_image(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+            check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, st), "conv3x3")
+            done()
+        if train:
+            rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
+            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
+                                             u.sums.data_ptr(), st), "bn_reduce_partials")
+            count = float(n * lh * lw)
+            if self.sync_fn is not None:
+                self.sync_fn(u.sums[:2 * u.cout])
+                count *= self.world
+            check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
+                                      BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
+                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_finalize")
+            P[u.nbtname].add_(1)
+        else:
+            check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
+                                         P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_eval_coeffs")
+        check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], train: bool, out: Optional[torch.Tensor] = None
+                ) -> torch.Tensor:
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise L.GsdError("UNetEngineBF16.forward needs a float32 tensor on the GPU (no CPU fallback)")
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        assert c == self.n_channels, f"expected {self.n_channels} input channels, got {c}"
+        self._ensure(n, h, w, x.device, train)
+        st = L.stream_ptr()
+        self._saved_train = train
+        dcol = L.make_nhwc(self.col0)
+        check(lib.gsd_bf16_im2col3x3(x.data_ptr(), n, c, h, w, C.byref(dcol), st), "im2col3x3")
+        for lvl in range(self.L + 1):
+            u0, u1 = self.enc[lvl]
+            if lvl == 0:
+                src = (self.col0, 0, self.col0.shape[3])
+            else:
+                prev = self.enc[lvl - 1][1]
+                dp = L.make_nhwc(self.pooled[lvl])
+                check(lib.gsd_bf16_maxpool2(C.byref(prev.a), C.byref(dp), st), "maxpool2")
+                src = (self.pooled[lvl], 0, prev.cout)
+            self._run_unit(u0, src, P, train, st)
+            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st)
+        cur = self.enc[self.L][1]
+        z = L.int_array([0])
+        for j in range(self.L):
+            up = self.ups[j]
+            lvl = self.L - 1 - j
+            check(lib.gsd_bf16_weight_image(3, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_image")
+            oy, ox = self._pad_off(lvl)
+            dslice = L.make_nhwc(self.cat[lvl], self.dims[lvl], up.cout)
+            done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * self.hs[lvl + 1] * self.ws[lvl + 1])
+            check(lib.gsd_bf16_conv_dense(C.byref(cur.a), up.wt_f.data_ptr(), C.byref(dslice), up.cin, 4 * up.cout, 1, 1, z, z,
+                                          self.hs[lvl + 1], self.ws[lvl + 1], up.cout, oy, ox, P[up.bname].data_ptr(), None, st),
+                  "convT")
+            done()
+            u0, u1 = self.dec[j]
+            self._run_unit(u0, (self.cat[lvl], 0, u0.cin), P, train, st)
+            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st)
+            cur = u1
+        if out is None:
+            out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
+        check(lib.gsd_bf16_conv1x1_out(C.byref(cur.a), P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(),
+                                       self.n_classes, out.data_ptr(), st), "conv1x1_out")
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _reduce(self, mode: int, u: _Unit, st: int, g: Optional[L.gsd_nhwc] = None, dpool: Optional[torch.Tensor] = None,
+                dout: Optional[torch.Tensor] = None, wout: Optional[torch.Tensor] = None) -> None:
+        """pass 1 of BatchNorm+ReLU backward: dz -> u.g, per-block sums -> self.partials."""
+        dy, dz = L.make_nhwc(u.y), L.make_nhwc(u.g)
+        gsrc = g if g is not None else dz
+        dp = L.make_nhwc(dpool) if dpool is not None else dz
+        check(lib.gsd_bf16_bn_bwd_reduce(mode, C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(),
+                                         u.invstd.data_ptr(), C.byref(gsrc), C.byref(u.a), C.byref(dp), L.ptr(dout), L.ptr(wout),
+                                         C.byref(dz), self.partials.data_ptr(), st), "bn_bwd_reduce")
+
+    def _tail(self, u: _Unit, G, st: int, dwout: Optional[torch.Tensor] = None) -> None:
+        """u.g holds dz and self.partials its sums: finish BatchNorm backward (dgamma, dbeta, dy in place), then dW."""
+        n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
+        rows = lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
+        check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st), "bn_bwd_reduce_partials")
+        count = float(n * lh * lw)
+        gsum = None
+        if self.sync_fn is not None:
+            gsum = u.sums[:2 * u.cout].clone()
+            self.sync_fn(gsum)
+            count *= self.world
+        check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), L.ptr(gsum), u.cout, count, G[u.gname].data_ptr(), G[u.bname].data_ptr(),
+                                      None if dwout is None else dwout.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), st),
+              "bn_bwd_finalize")
+        dz, dy = L.make_nhwc(u.g), L.make_nhwc(u.y)
+        check(lib.gsd_bf16_bn_bwd_apply(C.byref(dz), C.byref(dy), u.scale.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
+                                        u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_apply")
+        db = L.make_nhwc(*u.src)
+        if u.first:
+            z = L.int_array([0])
+            done = self._log("bf16_wgrad", 2.0 * u.cout * u.src[2] * n * lh * lw)
+            check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 1, 1, z, z, G[u.wname].data_ptr(), 9 * u.cin, self.wspace.data_ptr(),
+                                     self.wspace.numel(), st), "wgrad(first)")
+        else:
+            done = self._log("bf16_wgrad", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+            check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 9, 1, L.int_array(T3Y), L.int_array(T3X), G[u.wname].data_ptr(),
+                                     u.cin, self.wspace.data_ptr(), self.wspace.numel(), st), "wgrad")
+        done()
+
+    def _dgrad(self, u: _Unit, P, dst: torch.Tensor, st: int) -> None:
+        """dX of unit u (u.g holds dy) into the plain tensor dst (N,H,W,u.cin)."""
+        n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
+        check(lib.gsd_bf16_weight_image(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_image")
+        din, dout = L.make_nhwc(u.g), L.make_nhwc(dst)
+        done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+        check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), u.cout, u.cin, None, st), "conv3x3 dgrad")
+        done()
+
+    def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
+        if not self._saved_train:
+            raise L.GsdError("backward() needs a preceding train-mode forward()")
+        dout = dout.contiguous()
+        st = L.stream_ptr()
+        n = dout.shape[0]
+        last = self.dec[-1][1] if self.L > 0 else self.enc[0][1]
+        self._reduce(2, last, st, dout=dout, wout=P["outc.conv.weight"])
+        check(lib.gsd_sum_planes(dout.data_ptr(), n, self.n_classes, dout.shape[2] * dout.shape[3], G["outc.conv.bias"].data_ptr(),
+                                 self.wspace.data_ptr(), st), "sum_planes")
+        dwout = G["outc.conv.weight"]
+        for j in reversed(range(self.L)):
+            u0, u1 = self.dec[j]
+            up = self.ups[j]
+            lvl = self.L - 1 - j
+            self._tail(u1, G, st, dwout)
+            dwout = None
+            self._dgrad(u1, P, u0.g, st)
+            self._reduce(0, u0, st)
+            self._tail(u0, G, st)
+            self._dgrad(u0, P, self.gcat[lvl], st)
+            prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
+            hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
+            oy, ox = self._pad_off(lvl)
+            gup = L.make_nhwc(self.gcat[lvl], self.dims[lvl], up.cout)
+            ty, tx = L.int_array([oy, oy, oy + 1, oy + 1]), L.int_array([ox, ox + 1, ox, ox + 1])
+            done = self._log("bf16_wgrad", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
+            check(lib.gsd_bf16_wgrad(C.byref(prev.a), C.byref(gup), 4, 2, ty, tx, G[up.wname].data_ptr(), up.cout, self.wspace.data_ptr(),
+                                     self.wspace.numel(), st), "convT wgrad")
+            done()
+            check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), self.wspace.data_ptr(),
+                                            self.wspace.numel(), st), "convT bias grad")
+            check(lib.gsd_bf16_weight_image(4, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_image")
+            dprev = L.make_nhwc(prev.g)
+            done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
+            check(lib.gsd_bf16_conv_dense(C.byref(gup), up.wt_d.data_ptr(), C.byref(dprev), up.cout, up.cin, 4, 2, ty, tx, hi, wi, 0,
+                                          0, 0, None, None, st), "convT dgrad")
+            done()
+            self._reduce(0, prev, st)
+            if self.block_done_cb is not None:
+                self.block_done_cb(f"dec{j}")
+        for lvl in reversed(range(self.L + 1)):
+            u0, u1 = self.enc[lvl]
+            if lvl < self.L:
+                gskip = L.make_nhwc(self.gcat[lvl], 0, u1.cout)
+                self._reduce(1, u1, st, g=gskip, dpool=self.dpooled[lvl + 1])
+            self._tail(u1, G, st, dwout)
+            dwout = None
+            self._dgrad(u1, P, u0.g, st)
+            self._reduce(0, u0, st)
+            self._tail(u0, G, st)
+            if self.block_done_cb is not None:
+                self.block_done_cb(f"enc{lvl}")
+            if lvl > 0:
+                self._dgrad(u0, P, self.dpooled[lvl], st)

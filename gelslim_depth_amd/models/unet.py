@@ -126,7 +126,7 @@ class _UNetFunction(torch.autograd.Function):
 
 class UNet(nn.Module):
     def __init__(self, n_channels, n_classes, layer_dimensions=[64, 128, 256, 512, 1024], kernel_size=3,
-                 maxpool_size=2, upconv_stride=2, bilinear=False):
+                 maxpool_size=2, upconv_stride=2, bilinear=False, precision="fp32"):
         super().__init__()
         if kernel_size != 3 or maxpool_size != 2 or upconv_stride != 2:
             raise NotImplementedError(
@@ -147,10 +147,28 @@ class UNet(nn.Module):
             self.up.append(Up(dims[i], dims[i - 1], kernel_size=kernel_size - 1, stride=upconv_stride))
         self.outc = OutConv(dims[0], n_classes)
 
-        self._engine = UNetEngine(n_channels, n_classes, dims)
+        self._dims = dims
+        self._engine = None
+        self.set_precision(precision)
         self._pnames: List[str] = [n for n, _ in self.named_parameters()]
         # optional flat gradient arena installed by TrainStep: name -> view
         self._grad_views: Dict[str, torch.Tensor] = {}
+
+    def set_precision(self, precision: str) -> "UNet":
+        """"fp32" (default; the reference's arithmetic, BASELINE configs[1-3]) or "bf16" (mixed precision, configs[4]:
+        bf16 NHWC activations/gradients on the bf16 MFMA, fp32 master weights / statistics / optimiser state)."""
+        if precision == "fp32":
+            eng = UNetEngine(self.n_channels, self.n_classes, self._dims)
+        elif precision == "bf16":
+            from ..engine_bf16 import UNetEngineBF16
+            eng = UNetEngineBF16(self.n_channels, self.n_classes, self._dims)
+        else:
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if self._engine is not None:            # keep the data-parallel hooks a TrainStep installed
+            eng.world, eng.sync_fn = self._engine.world, self._engine.sync_fn
+        self._engine = eng
+        self.precision = precision
+        return self
 
     # -- plumbing -------------------------------------------------------------------------------
     def _tensor_map(self) -> Dict[str, torch.Tensor]:

@@ -83,6 +83,12 @@ int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, cons
 int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* scale, const float* mean, const float* invstd,
                           const float* c1, const float* c2, void* stream);
 
+/* out[c] = sum over n and the window rows [y0,y0+hh) x cols [x0,x0+ww) of t[n,y,x,c] (fp32): the bias gradient of
+ * ConvTranspose2d over the un-padded part of its output slice (unet.py:36). workspace: ..._workspace(N,hh,ww,C) floats. */
+int64_t gsd_bf16_channel_sums_workspace(int N, int hh, int ww, int C);
+int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, int ww, float* out, float* workspace,
+                          int64_t workspace_elems, void* stream);
+
 /* ---- weight gradients --------------------------------------------------------------------------------------------
  *   D[t][m][n] = sum_{n_img,h,w} a[n_img,h,w,m] * b[n_img, stride*h+ty[t], stride*w+tx[t], n]   (zeros outside b)
  *   dw[(m*ncols_out + n)*ntaps + t] = D[t][m][n]   for n < ncols_out          (fp32; overwritten, not accumulated)

@@ -311,3 +311,35 @@ def test_bn_bwd_bf16(mode):
     ref = scale[None, :, None, None] * (dz_got - c1[None, :, None, None] - xhat * c2[None, :, None, None])
     got = from_nhwc(dzbuf, 0, c)
     assert float((got - bf16r(ref)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_conv3x3_dgrad_through_weight_image_bf16():
+    """dX of conv3x3 == conv3x3 of dy with the mode-1 weight image (taps flipped, in/out channels swapped)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(12)
+    n, h, w, cin, cout = 2, 14, 19, 64, 96
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3.0 * cin ** 0.5)
+    dy = bf16r(torch.randn((n, cout, h, w), generator=g))
+    xz = torch.zeros((n, cin, h, w), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xz, bf16r(wt).double(), padding=1).backward(dy.double())
+    img = torch.empty((L.lib.gsd_bf16_weight_image_size(1, cout, cin),), dtype=torch.bfloat16, device="cuda")
+    wd = wt.cuda()
+    L.check(L.lib.gsd_bf16_weight_image(1, wd.data_ptr(), cout, cin, img.data_ptr(), L.stream_ptr()), "wimg")
+    dyb, dx = to_nhwc(dy), torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device="cuda")
+    din, dout = L.make_nhwc(dyb), L.make_nhwc(dx)
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), cout, cin, None, L.stream_ptr()), "dgrad")
+    assert_close_bf16(from_nhwc(dx, 0, cin), xz.grad, "conv3x3 dX")
+
+
+def test_channel_sums_bf16():
+    L = _lib()
+    g = torch.Generator().manual_seed(13)
+    n, h, w, c = 3, 21, 27, 32
+    t = bf16r(torch.randn((n, c, h, w), generator=g))
+    buf = to_nhwc(t, 64, 32)
+    view = L.make_nhwc(buf, 32, c)
+    nws = L.lib.gsd_bf16_channel_sums_workspace(n, 20, 26, c)
+    ws, out = torch.empty((nws,), device="cuda"), torch.zeros((c,), device="cuda")
+    L.check(L.lib.gsd_bf16_channel_sums(C.byref(view), 1, 0, 20, 26, out.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()), "sums")
+    ref = t[:, :, 1:21, 0:26].double().sum(dim=(0, 2, 3))
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-5, atol=1e-4)

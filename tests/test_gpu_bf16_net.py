@@ -1,0 +1,198 @@
+"""GPU: the bf16 mixed-precision U-Net path (gelslim_depth_amd/engine_bf16.py, UNet(precision="bf16")) against
+(a) oracle/torch_cpu_path.py's bf16 EMULATION (same rounding points, torch CPU operators) and (b) the fp32 reference
+arithmetic.  bf16 keeps 8 significant bits: a stored activation is off by up to 2^-9 relative, and at random
+initialisation every BatchNorm backward amplifies that (measured on the emulation itself: parameter-gradient deviation
+from fp32 grows 0.05 % -> 2.5 % -> 6 % -> 15 % -> 30 % from the last layer to the first), so the whole-network checks
+are: outputs and loss close to both, gradients close to the EMULATION (tight at the output end, direction elsewhere),
+and a short training run that tracks the fp32 run.  The tight, per-operator checks live in tests/test_gpu_bf16.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l1
+from gelslim_depth_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dims, st, precision):
+    from gelslim_depth_amd.models.unet import UNet
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    return m.to("cuda")
+
+
+def _cos(a, b):
+    a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+    return float(a @ b / np.sqrt((a @ a) * (b @ b) + 1e-300))
+
+
+def _nchw(t, off=0, c=None):
+    c = t.shape[3] - off if c is None else c
+    return t[..., off:off + c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _ulp_close(got, ref, what, ulps=1.0):
+    """bf16 tensors that may differ by rounding decisions only: |got - ref| <= ulps * 2^-8 * |ref| (+ tiny absolute)."""
+    err = (got.double() - ref.double()).abs()
+    tol = ulps * 2.0 ** -8 * ref.double().abs() + 1e-6 * float(ref.abs().max()) + 1e-30
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} beyond {ulps} ulp, worst {float((err / (ref.abs() + 1e-9)).max()):.3e}"
+
+
+@pytest.mark.parametrize("dims,n,h,w", [([32, 64, 128], 2, 21, 27), ([32, 64], 3, 40, 53), ([64, 128, 256, 512], 1, 45, 61)])
+def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
+    """Whole-network bf16 results cannot be compared element-tight with ANY other implementation: a one-ulp difference
+    in a stored activation flips ~35 roundings in the next layer (measured: 5 -> 138 -> 2407 -> 19179 differing elements
+    over four layers between this path and the CPU emulation), i.e. after a few layers two correct implementations
+    differ by independent bf16 noise.  So: (1) every layer is checked TIGHTLY against torch-CPU fp64 fed with the HIP
+    path's own inputs of that layer (forward values, BatchNorm statistics, weight gradients, BatchNorm-backward
+    invariants); (2) end to end the HIP path must be as close to the emulation as the emulation is to fp32."""
+    import torch.nn.functional as F
+    from gelslim_depth_amd.train import TrainStep
+    from oracle import torch_cpu_path as ot
+    st = synth.make_state(3, 1, dims, 11, "conditioned")
+    x, t = synth.make_batch(n, h, w, 3)
+    xt, tt = torch.from_numpy(x), torch.from_numpy(t)
+    emu, ref = ot.CpuTrainerBF16(st), ot.CpuTrainer(st)
+    with torch.no_grad():
+        out_emu = ot.forward_bf16({k: v.detach().clone() for k, v in emu.state.items()}, xt, train=True).numpy()
+        out_ref = ot.forward({k: v.detach().clone() for k, v in ref.state.items()}, xt, train=True).numpy()
+    loss_emu, loss_ref = emu.step(xt, tt), ref.step(xt, tt)
+    m = _model(dims, st, "bf16").train()
+    step = TrainStep(m, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse")
+    p0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}          # parameters the step ran with
+    loss = float(step(xt.cuda(), tt.cuda()))
+    out = step._out.cpu()
+    eng = m._engine
+    got = {k: v.cpu() for k, v in m._grad_views.items()}
+    for k, v in got.items():
+        assert bool(torch.isfinite(v).all()), k
+
+    # ---- (1) layer by layer, teacher-forced with the HIP path's own tensors ----------------------------------------
+    L_ = len(dims) - 1
+
+    def unit_input(u):
+        tsr, off, c = u.src
+        return _nchw(tsr, off, c)
+
+    for u in eng.units:
+        a_in = unit_input(u)
+        wq = _q(p0[u.wname])
+        if u.first:
+            wcol = torch.zeros((u.cout, a_in.shape[1]))
+            wcol[:, :9 * u.cin] = wq.reshape(u.cout, -1)
+            y_ref = torch.einsum("nkhw,mk->nmhw", a_in.double(), wcol.double())
+        else:
+            y_ref = F.conv2d(a_in.double(), wq.double(), padding=1)
+        y = _nchw(u.y)
+        _ulp_close(y, y_ref, f"{u.wname} forward")
+        mean, var = y.double().mean(dim=(0, 2, 3)), y.double().var(dim=(0, 2, 3), unbiased=False)
+        assert torch.allclose(u.mean.cpu().double(), mean, rtol=1e-4, atol=1e-5), u.gname
+        assert torch.allclose(u.invstd.cpu().double(), 1.0 / torch.sqrt(var + 1e-5), rtol=1e-4), u.gname
+        a_ref = torch.relu(y * u.scale.cpu()[None, :, None, None] + u.shift.cpu()[None, :, None, None])
+        _ulp_close(_nchw(u.a_t, u.a_off, u.cout), a_ref, f"{u.gname} apply")
+        # backward: u.g holds dy (gradient w.r.t. the raw conv output) after the step
+        dy = _nchw(u.g)
+        if u.first:
+            dw_ref = torch.einsum("nmhw,nkhw->mk", dy.double(), a_in.double())[:, :9 * u.cin].reshape(got[u.wname].shape)
+        else:
+            wz = torch.zeros_like(p0[u.wname], dtype=torch.float64, requires_grad=True)
+            F.conv2d(a_in.double(), wz, padding=1).backward(dy.double())
+            dw_ref = wz.grad
+        assert float((got[u.wname].double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-12, u.wname
+        # BatchNorm backward projects out the mean and the xhat component: both sums of dy vanish up to bf16 rounding
+        xhat = (y - u.mean.cpu()[None, :, None, None]) * u.invstd.cpu()[None, :, None, None]
+        cnt = dy.shape[0] * dy.shape[2] * dy.shape[3]
+        scale_mag = dy.abs().mean(dim=(0, 2, 3)) + 1e-12
+        assert float((dy.sum(dim=(0, 2, 3)).abs() / (scale_mag * cnt)).max()) < 2e-2, u.gname
+        assert float(((dy * xhat).sum(dim=(0, 2, 3)).abs() / (scale_mag * cnt)).max()) < 2e-2, u.gname
+    for lvl in range(1, L_ + 1):                      # max-pool
+        prev = eng.enc[lvl - 1][1]
+        assert torch.equal(_nchw(eng.pooled[lvl]), F.max_pool2d(_nchw(prev.a_t, prev.a_off, prev.cout), 2))
+    for j, up in enumerate(eng.ups):                  # transposed convolution into the concat buffer, and its gradients
+        lvl = L_ - 1 - j
+        prev = eng.dec[j - 1][1] if j > 0 else eng.enc[L_][1]
+        a_in = _nchw(prev.a_t, prev.a_off, prev.cout)
+        up_ref = F.conv_transpose2d(a_in.double(), _q(p0[up.wname]).double(), p0[up.bname].double(), stride=2)
+        oy, ox = eng._pad_off(lvl)
+        sl = _nchw(eng.cat[lvl], dims[lvl], up.cout)
+        _ulp_close(sl[:, :, oy:oy + up_ref.shape[2], ox:ox + up_ref.shape[3]], up_ref, f"{up.wname} forward")
+        border = sl.clone()
+        border[:, :, oy:oy + up_ref.shape[2], ox:ox + up_ref.shape[3]] = 0
+        assert float(border.abs().max()) == 0.0
+        gup = _nchw(eng.gcat[lvl], dims[lvl], up.cout)[:, :, oy:oy + up_ref.shape[2], ox:ox + up_ref.shape[3]]
+        wz = torch.zeros_like(p0[up.wname], dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros_like(p0[up.bname], dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(a_in.double(), wz, bz, stride=2).backward(gup.double())
+        assert float((got[up.wname].double() - wz.grad).abs().max()) <= 5e-5 * float(wz.grad.abs().max()) + 1e-12, up.wname
+        assert float((got[up.bname].double() - bz.grad).abs().max()) <= 5e-5 * float(bz.grad.abs().max()) + 1e-12, up.bname
+    last = eng.dec[-1][1] if L_ > 0 else eng.enc[0][1]
+    a_last = _nchw(last.a_t, last.a_off, last.cout)
+    out_tf = F.conv2d(a_last.double(), p0["outc.conv.weight"].double(), p0["outc.conv.bias"].double())
+    assert float((out.double() - out_tf).abs().max()) <= 1e-5 * float(out_tf.abs().max())
+    dout = 2.0 * (out.double() - tt.double()) / out.numel()
+    assert abs(loss - float(((out.double() - tt.double()) ** 2).mean())) <= 1e-5 * loss
+    assert torch.allclose(got["outc.conv.bias"].double(), dout.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(got["outc.conv.weight"].double().reshape(-1), (dout * a_last.double()).sum(dim=(0, 2, 3)), rtol=1e-3,
+                          atol=1e-7)
+
+    # ---- (2) end to end: as close to the emulation as the emulation is to fp32 --------------------------------------
+    e_emu, e_ref, e_noise = rel_l1(out.numpy(), out_emu), rel_l1(out.numpy(), out_ref), rel_l1(out_emu, out_ref)
+    assert e_emu <= 1.2 * e_noise + 1e-3 and e_ref <= 1.5 * e_noise + 1e-3, (e_emu, e_ref, e_noise)
+    assert abs(loss - loss_emu) < 5e-3 * abs(loss_emu) and abs(loss - loss_ref) < 2e-2 * abs(loss_ref)
+    g_emu, g_ref = emu.grads(), ref.grads()
+    for k in g_emu:
+        if g_emu[k].size >= 64:
+            c_noise = _cos(g_emu[k], g_ref[k])
+            assert _cos(got[k].numpy(), g_emu[k]) >= min(0.999, c_noise) - 0.02, (k, _cos(got[k].numpy(), g_emu[k]), c_noise)
+    for k in ("outc.conv.weight", "outc.conv.bias"):
+        assert rel_l1(got[k].numpy(), g_emu[k]) < 1e-2, k
+    sd = m.state_dict()
+    for k, v in emu.state.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_l1(sd[k].cpu().numpy(), v.detach().numpy()) < 2e-2, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v)
+    # eval-mode forward (running statistics): finite, right shape, bf16-close to the fp32 arithmetic on the same state
+    m.eval()
+    with torch.no_grad():
+        ev = m(x=xt.cuda()).cpu().numpy()
+    ev_ref = ot.forward({k: sd[k].detach().cpu().clone() for k in emu.state}, xt, train=False).detach().numpy()
+    assert ev.shape == ev_ref.shape and np.isfinite(ev).all() and rel_l1(ev, ev_ref) < 5e-2
+
+
+def test_bf16_training_tracks_fp32():
+    """20 Adam steps on one batch: the bf16 run's loss curve stays within 2 % of the fp32 HIP run's and both fall."""
+    from gelslim_depth_amd.train import TrainStep
+    dims, n, h, w = [32, 64, 128], 4, 40, 53
+    st = synth.make_state(3, 1, dims, 21, "conditioned")
+    x, t = synth.make_batch(n, h, w, 5)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        m = _model(dims, st, prec).train()
+        step = TrainStep(m, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse")
+        curves[prec] = [float(step(xd, td)) for _ in range(20)]
+    a, b = np.array(curves["fp32"]), np.array(curves["bf16"])
+    assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
+    assert np.abs(a - b).max() < 2e-2 * a[0], np.abs(a - b).max()
+
+
+def test_bf16_full_size_eval_vs_reference_golden():
+    """BASELINE config shapes: the 31 M-parameter net at 1x3x320x427, eval mode, against the fixture produced by running
+    the reference (fp32 CPU).  bf16 through 18 conv layers: 1e-2 relative L1 (the fp32 path's bound is 1e-3)."""
+    g = load_golden("gfull_b1.npz")
+    dims = [int(v) for v in g["meta/dims"]]
+    seed = int(g["meta/seed"])
+    st = synth.make_state(3, 1, dims, seed, "conditioned")
+    x, _ = synth.make_batch(1, 320, 427, seed + 1)
+    m = _model(dims, st, "bf16").eval()
+    with torch.no_grad():
+        out = m(x=torch.from_numpy(x).cuda()).cpu().numpy()
+    assert out.shape == (1, 1, 320, 427)
+    assert rel_l1(out, g["y_eval"]) < 1e-2, rel_l1(out, g["y_eval"])
