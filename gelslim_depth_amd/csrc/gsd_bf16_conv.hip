@@ -163,11 +163,23 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
   }
 
+  // The accumulators start at the bias (MODE 1 only): no load is then left for the epilogue, where it would sit between
+  // the stores -- loads and stores share vmcnt on gfx950, and hipcc answers a load of unknown age inside divergent
+  // control flow with s_waitcnt vmcnt(0) in front of EVERY store (measured: 13 us per block).
   f32x4 acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m) {
+    f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1 && P.bias != nullptr) {
+      const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+      if (mrow < P.M) {
+        const int co = P.Cs > 0 ? mrow % P.Cs : mrow;
+        init = f32x4{P.bias[co], P.bias[co + 1], P.bias[co + 2], P.bias[co + 3]};
+      }
+    }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[m][t] = init;
+  }
 
   const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * (P.K >> 5);
   issue(0);
@@ -182,17 +194,36 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     } else {
       Xc = Xl + (it & 1) * XBUF;
     }
+    // software pipeline over the taps of this iteration: the 12 operand reads of tap kw+1 are interleaved with the 32
+    // MFMAs of tap kw (1 ds_read : 2 MFMA; hipcc otherwise sinks every read to just before its first use and waits
+    // lgkmcnt(0) in front of each MFMA group -- with one wave per SIMD nothing else hides that latency)
+    u32x4 a[2][MT], b[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(Wc + m * 1024);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[0][t] = *reinterpret_cast<const u32x4*>(Xc + boff[t]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kw = 0; kw < NTAPI; ++kw) {
-      u32x4 a[MT], b[NT];
+      if (kw + 1 < NTAPI) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const u32x4*>(Wc + kw * BM * 64 + m * 1024);
+        for (int m = 0; m < MT; ++m) a[(kw + 1) & 1][m] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + m * 1024);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const u32x4*>(Xc + boff[t] + kw * 96);
+        for (int t = 0; t < NT; ++t) b[(kw + 1) & 1][t] = *reinterpret_cast<const u32x4*>(Xc + boff[t] + (kw + 1) * 96);
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = mfma_bf16(a[m], b[t], acc[m][t]);
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma_bf16(a[kw & 1][m], b[kw & 1][t], acc[m][t]);
+      if (kw + 1 < NTAPI) {
+#pragma unroll
+        for (int i = 0; i < MT + NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // two MFMAs (operands read during the previous tap)
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read for the next tap
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -203,6 +234,21 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
 
+  // per-lane output rows are the same for every pixel tile: resolve channel / scatter quadrant once
+  int co_m[MT], qy[MT], qx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+    int co = mrow, q = 0;
+    if (P.Cs > 0) {
+      q = mrow / P.Cs;
+      co = mrow - q * P.Cs;
+    }
+    co_m[m] = co;
+    qy[m] = (q >> 1) + P.oy;
+    qx[m] = (q & 1) + P.ox;
+  }
+  const int sm = P.Cs > 0 ? 2 : 1;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int nt = wn * NT + t;
@@ -213,19 +259,11 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     for (int m = 0; m < MT; ++m) {
       const int mrow = m0 + wm * 64 + m * 16 + g * 4;
       if (mrow < P.M) {
-        int co = mrow, ho = h, wo = w;
-        if (P.Cs > 0) {
-          const int q = mrow / P.Cs;
-          co = mrow - q * P.Cs;
-          ho = 2 * h + (q >> 1) + P.oy;
-          wo = 2 * w + (q & 1) + P.ox;
-        }
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[m][t][e] + (P.bias != nullptr ? P.bias[co + e] : 0.f);
-        const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        const int ho = sm * h + qy[m], wo = sm * w + qx[m];
+        const unsigned lo = pack_bf16(acc[m][t][0], acc[m][t][1]);
+        const unsigned hi = pack_bf16(acc[m][t][2], acc[m][t][3]);
         if (pix_ok) {
-          u16* o = P.out + ((long long)(n * P.Hob + ho) * P.Wob + wo) * P.out_pitch + co;
+          u16* o = P.out + ((long long)(n * P.Hob + ho) * P.Wob + wo) * P.out_pitch + co_m[m];
           *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
           if (P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
             const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);

@@ -42,11 +42,11 @@ __device__ __forceinline__ u32x2 tr_read_b64(const unsigned char* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 
-template <int HALO, int WM, int WN>
+template <int HALO, int TT, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
   constexpr int BM = WM * 64, BNC = WN * 16;
   constexpr int RSA = BM * 2 + 32, RSB = BNC * 2 + 32;       // row strides: 32 B x odd
-  constexpr int TT = HALO ? 9 : 4;
+  constexpr int KS = HALO ? 4 : 2;                            // 32-pixel k-steps per stage (NPIX = 128 / 64)
   constexpr int MT = 4;
   constexpr int MAXA = (128 * RSA + 4095) / 4096;             // A DMA instructions per wave (NPIX <= 128)
   constexpr int MAXB = (264 * RSB + 4095) / 4096;             // B DMA instructions per wave (<= 264 rows)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
   const int m0 = mb * BM, n0 = nb * BNC;
   const int s_begin = (int)((long long)split * P.stages_total / P.splits);
   const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
-  const int nbrows = HALO ? P.HP : P.T * P.NPIX;
+  const int nbrows = HALO ? P.HP : TT * P.NPIX;
 
   // ---- DMA bookkeeping: (row, piece) of every 16-byte piece this lane moves; stage-invariant ------------------------
   // A: row = tile pixel (r, c); packed (r << 20 | c << 8 | piece), -1 = no transfer
@@ -159,44 +159,69 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
       }
     }
     __syncthreads();   // vmcnt(0) + barrier: both images have landed
-    for (int ks = 0; ks < P.KS; ++ks) {
-      const int q0 = ks * 32;
-      const unsigned char* ap = Al + a_rd + q0 * RSA;
-      u32x4 a[MT];
+    // One flat, fully unrolled sequence of KS*TT steps (4 MFMAs each).  The B operand of step s+2 and, two steps before a
+    // k-step ends, the A operands of the next k-step are read while step s multiplies: every ds_read_b64_tr_b16 has at
+    // least one whole step (64 MFMA cycles, plus whatever the CU's other block interleaves) to land.
+    auto read_a = [&](int ks, u32x4* a) {
+      const unsigned char* ap = Al + a_rd + ks * 32 * RSA;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const u32x2 lo = tr_read_b64(ap + m * 32), hi = tr_read_b64(ap + m * 32 + 16 * RSA);
         a[m] = u32x4{lo[0], lo[1], hi[0], hi[1]};
       }
+    };
+    auto read_b = [&](int s) {
+      const int ks = s / TT, t = s - ks * TT;
+      const int q0 = ks * 32;
       const int r = q0 / P.TW, c = q0 - r * P.TW;
+      const int brow = HALO ? (r + t / 3) * P.HC + c + t % 3 : t * P.NPIX + q0;
+      const unsigned char* bp = Bl + b_rd + brow * RSB;
+      const u32x2 lo = tr_read_b64(bp), hi = tr_read_b64(bp + 16 * RSB);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    u32x4 a[2][MT], b[3];
+    read_a(0, a[0]);
+    b[0] = read_b(0);
+    if (KS * TT > 1) b[1] = read_b(1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        if (t < P.T) {
-          const int brow = HALO ? (r + t / 3) * P.HC + c + t % 3 : t * P.NPIX + q0;
-          const unsigned char* bp = Bl + b_rd + brow * RSB;
-          const u32x2 lo = tr_read_b64(bp), hi = tr_read_b64(bp + 16 * RSB);
-          const u32x4 b = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    for (int s = 0; s < KS * TT; ++s) {
+      const int ks = s / TT, t = s - ks * TT;
+      const bool pre_b = s + 2 < KS * TT;
+      const bool pre_a = t == (TT >= 2 ? TT - 2 : 0) && ks + 1 < KS;
+      if (pre_b) b[(s + 2) % 3] = read_b(s + 2);
+      if (pre_a) read_a(ks + 1, a[(ks + 1) & 1]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16(a[m], b, acc[m][t]);
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma_bf16(a[ks & 1][m], b[s % 3], acc[m][t]);
+      if (pre_a) {          // 8 (+2) reads beside 4 MFMAs
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         }
+      } else if (pre_b) {   // 2 reads beside 4 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   // ---- slab store: slab[split][t][m][n] ------------------------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < TT; ++t) {
-    if (t < P.T) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int mr = m0 + wm * 64 + m * 16 + g * 4 + e;
-          const int col = n0 + wn * 16 + li;
-          if (mr < P.M && col < P.Ncols)
-            P.slabs[(((size_t)split * P.T + t) * P.M + mr) * P.Ncols + col] = acc[m][t][e];
-        }
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int mr = m0 + wm * 64 + m * 16 + g * 4 + e;
+        const int col = n0 + wn * 16 + li;
+        if (mr < P.M && col < P.Ncols)
+          P.slabs[(((size_t)split * TT + t) * P.M + mr) * P.Ncols + col] = acc[m][t][e];
+      }
   }
 }
 
@@ -260,11 +285,11 @@ WPlan make_wplan(bool halo, int T, int N, int H, int W, int M, int Ncols) {
   return p;
 }
 
-template <int HALO, int WM, int WN>
+template <int HALO, int TT, int WM, int WN>
 int launch_w(const GWgradP& P, int grid, size_t lds, hipStream_t st, const char* what) {
   static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gwgrad_bf16_kernel<HALO, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gwgrad_bf16_kernel<HALO, TT, WM, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
@@ -273,7 +298,7 @@ int launch_w(const GWgradP& P, int grid, size_t lds, hipStream_t st, const char*
     attr_done = true;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "%s: LDS %zu B too large", what, lds);
-  hipLaunchKernelGGL((gwgrad_bf16_kernel<HALO, WM, WN>), dim3(grid), dim3(256), lds, st, P);
+  hipLaunchKernelGGL((gwgrad_bf16_kernel<HALO, TT, WM, WN>), dim3(grid), dim3(256), lds, st, P);
   GSD_LAUNCH_CHECK(what);
   return GSD_OK;
 }
@@ -291,8 +316,8 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
   if (int e = gsd_check_nhwc(b, "gsd_bf16_wgrad b")) return e;
   GSD_REQUIRE(dw && workspace && ty && tx, GSD_ERR_BAD_ARG, "gsd_bf16_wgrad: null argument");
   GSD_REQUIRE(a->N == b->N && a->C % 8 == 0 && b->C % 8 == 0, GSD_ERR_BAD_ARG, "gsd_bf16_wgrad: batch sizes differ or C %% 8 != 0");
-  GSD_REQUIRE((ntaps == 9 && stride == 1) || (ntaps >= 1 && ntaps <= 4 && (stride == 1 || stride == 2)), GSD_ERR_UNSUPPORTED,
-              "gsd_bf16_wgrad: 9 taps at stride 1 (3x3 halo) or 1..4 dense taps at stride 1/2");
+  GSD_REQUIRE((ntaps == 9 && stride == 1) || ((ntaps == 1 || ntaps == 4) && (stride == 1 || stride == 2)), GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_wgrad: 9 taps at stride 1 (3x3 halo) or 1 / 4 dense taps at stride 1 / 2");
   GSD_REQUIRE(ncols_out > 0 && ncols_out <= b->C, GSD_ERR_BAD_ARG, "gsd_bf16_wgrad: ncols_out out of range");
   GSD_REQUIRE(a->H < 256 * 128 && a->W < 4096, GSD_ERR_UNSUPPORTED, "gsd_bf16_wgrad: extent too large");
   const bool halo = ntaps == 9;
@@ -318,10 +343,10 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   int rc;
-  if (halo) rc = pl.wide ? launch_w<1, 1, 4>(P, grid, pl.lds, (hipStream_t)stream, "gsd_bf16_wgrad")
-                         : launch_w<1, 2, 2>(P, grid, pl.lds, (hipStream_t)stream, "gsd_bf16_wgrad");
-  else rc = pl.wide ? launch_w<0, 1, 4>(P, grid, pl.lds, (hipStream_t)stream, "gsd_bf16_wgrad")
-                    : launch_w<0, 2, 2>(P, grid, pl.lds, (hipStream_t)stream, "gsd_bf16_wgrad");
+  hipStream_t st = (hipStream_t)stream;
+  if (halo) rc = pl.wide ? launch_w<1, 9, 1, 4>(P, grid, pl.lds, st, "gsd_bf16_wgrad") : launch_w<1, 9, 2, 2>(P, grid, pl.lds, st, "gsd_bf16_wgrad");
+  else if (ntaps == 4) rc = pl.wide ? launch_w<0, 4, 1, 4>(P, grid, pl.lds, st, "gsd_bf16_wgrad") : launch_w<0, 4, 2, 2>(P, grid, pl.lds, st, "gsd_bf16_wgrad");
+  else rc = pl.wide ? launch_w<0, 1, 1, 4>(P, grid, pl.lds, st, "gsd_bf16_wgrad") : launch_w<0, 1, 2, 2>(P, grid, pl.lds, st, "gsd_bf16_wgrad");
   if (rc) return rc;
   const long long per = (long long)ntaps * M * Ncols;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);

@@ -163,6 +163,18 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
     sAff[c] = sc;
     sAff[Kpad + c] = sh;
   }
+  // fused BatchNorm-backward epilogue: the block's output-channel coefficients, also through LDS (read back with
+  // ds_read in the epilogue, so that no global load sits between its stores)
+  float* sBw = sAff + 2 * Kpad;   // [4][BM]: scale, shift, mean, invstd
+  if (P.bw_raw != nullptr) {
+    for (int c = tid; c < BM; c += 256) {
+      const int co = m0 + c < P.Cout ? m0 + c : 0;
+      sBw[c] = P.bw_scale[co];
+      sBw[BM + c] = P.bw_shift[co];
+      sBw[2 * BM + c] = P.bw_mean[co];
+      sBw[3 * BM + c] = P.bw_invstd[co];
+    }
+  }
   const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
 
   f32x4 acc[MT][NT];
@@ -219,17 +231,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
   }
   float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
   float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+  if (P.bw_raw == nullptr) {
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int co = m0 + wm * 64 + m * 16 + j * 4 + reg;
-      const bool first = co < P.dst0.C;
-      const int cd = first ? co : co - P.dst0.C;
-      const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
-      float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
-      float s1 = 0.f, s2 = 0.f;
-      if (P.bw_raw == nullptr) {
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + wm * 64 + m * 16 + j * 4 + reg;
+        const bool first = co < P.dst0.C;
+        const int cd = first ? co : co - P.dst0.C;
+        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+        float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           if (opix[t] >= 0) {
@@ -240,28 +252,57 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
             if (co_ok && off >= 0) plane[off] = v;
           }
         }
-      } else if (co_ok) {
-        // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry
-        const float bsc = P.bw_scale[co], bsh = P.bw_shift[co], bmu = P.bw_mean[co], bis = P.bw_invstd[co];
-        const float* const rplane = P.bw_raw + (long long)n * P.dst0.ns + (long long)co * P.dst0.cs;
+        if (P.partials != nullptr) {
+          s1 = reduce16(s1);
+          s2 = reduce16(s2);
+          if (l16 == 0 && co < P.Mpad) {
+            float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
+            row[co] = s1;
+            row[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  } else {
+    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX.
+    // Loads and stores share vmcnt on gfx950: a load between two stores makes the second wait for the first.  So the
+    // coefficients come from LDS, and the raw values are loaded 16 at a time (one m-tile) in front of their 16 stores.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float xr[4][NT];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + wm * 64 + m * 16 + j * 4 + reg;
+        const float* const rplane = P.bw_raw + (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xr[reg][t] = rplane[ooff0[t] >= 0 ? ooff0[t] : 0];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep this m-tile's 16 loads together, in front of its 16 stores
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + wm * 64 + m * 16 + j * 4 + reg;
+        float* const plane = d0 + (long long)co * P.dst0.cs;
+        const int cl = wm * 64 + m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (opix[t] >= 0 && ooff0[t] >= 0) {
-            const float x = rplane[ooff0[t]];
+          if (co < P.Cout && opix[t] >= 0 && ooff0[t] >= 0) {
+            const float x = xr[reg][t];
             const float dz = fmaf(x, bsc, bsh) > 0.f ? acc[m][t][reg] : 0.f;
             plane[ooff0[t]] = dz;
             s1 += dz;
             s2 = fmaf(dz, (x - bmu) * bis, s2);
           }
         }
-      }
-      if (P.partials != nullptr) {
-        s1 = reduce16(s1);
-        s2 = reduce16(s2);
-        if (l16 == 0 && co < P.Mpad) {
-          float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
-          row[co] = s1;
-          row[P.Mpad + co] = s2;
+        if (P.partials != nullptr) {
+          s1 = reduce16(s1);
+          s2 = reduce16(s2);
+          if (l16 == 0 && co < P.Mpad) {
+            float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
+            row[co] = s1;
+            row[P.Mpad + co] = s2;
+          }
         }
       }
     }
@@ -401,7 +442,7 @@ static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, 
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: halo window too large");
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
-  size_t lds = (size_t)(2 * (36 * pl.BM + 4 * P.PS) + 2 * 4 * P.nchunks) * sizeof(float);   // 2 tile images + BN coefficients
+  size_t lds = (size_t)(2 * (36 * pl.BM + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * pl.BM) * sizeof(float);   // 2 tile images + BN coefficients (input side, output side)
   static const int lds_min = getenv("GSD_CONV_LDS_MIN") ? atoi(getenv("GSD_CONV_LDS_MIN")) : 0;   // tuning: cap blocks/CU
   if ((size_t)lds_min > lds) lds = lds_min;
   if (pl.wide) return launch<1, 4, 4>(P, (int)grid, lds, (hipStream_t)stream);
