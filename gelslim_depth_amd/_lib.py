@@ -44,7 +44,13 @@ _F = C.c_float
 _D = C.c_double
 _SRC = C.POINTER(gsd_src)
 _DST = C.POINTER(gsd_dst)
+class gsd_bf16_bnbwd(C.Structure):
+    _fields_ = [("y", C.POINTER(gsd_nhwc)), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p)]
+
+
 _NHWC = C.POINTER(gsd_nhwc)
+_BNBWD = C.POINTER(gsd_bf16_bnbwd)
 _IP = C.POINTER(C.c_int)
 
 # name -> (restype, argtypes); mirrors include/gsd.h and include/gsd_bf16.h one to one (tests check every symbol loads)
@@ -84,8 +90,8 @@ SIGNATURES = {
     # ---- include/gsd_bf16.h
     "gsd_bf16_conv_mpad": (_I, [_I]),
     "gsd_bf16_conv_partial_rows": (_I, [_I, _I, _I, _I]),
-    "gsd_bf16_conv3x3": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P]),
-    "gsd_bf16_conv_dense": (_I, [_NHWC, _P, _NHWC, _I, _I, _I, _I, _IP, _IP, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gsd_bf16_conv3x3": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _BNBWD, _P]),
+    "gsd_bf16_conv_dense": (_I, [_NHWC, _P, _NHWC, _I, _I, _I, _I, _IP, _IP, _I, _I, _I, _I, _I, _P, _P, _BNBWD, _P]),
     "gsd_bf16_weight_image_size": (_L, [_I, _I, _I]),
     "gsd_bf16_weight_image": (_I, [_I, _P, _I, _I, _P, _P]),
     "gsd_bf16_im2col3x3": (_I, [_P, _I, _I, _I, _I, _NHWC, _P]),

@@ -37,6 +37,11 @@ struct GConvP {
   int Cs, oy, ox;  // scatter (Cs > 0): m = q*Cs + co -> out pixel (2h + (q>>1) + oy, 2w + (q&1) + ox), channel co
   const float* bias;
   float* partials;
+  // fused BatchNorm+ReLU backward pass 1 (dX launches): out receives dz = dX where relu(bn(bw_y)) > 0, partials the sums
+  // of dz and dz*xhat.  bw_y has out's geometry (pitch bw_pitch).
+  const u16* bw_y;
+  long long bw_pitch;
+  const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_invstd;
 };
 
 template <int MODE, int WM, int WN>
@@ -52,6 +57,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int XBUF = (MODE == 0 ? P.HP : NPX) * 96;
   unsigned char* Wl = smem;
   unsigned char* Xl = smem + 2 * WBUF;
+  float* sBw = reinterpret_cast<float*>(smem + 2 * WBUF + 2 * XBUF);   // [4][BM] output-side BatchNorm coefficients (fused dX)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +75,15 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int cbs = P.TW >> 4;  // 16-pixel column blocks per tile row
 
   const u16* in_img = P.in + (long long)n * P.Hin * P.Win * P.in_pitch;
+  if (P.bw_y != nullptr) {   // visible to everyone after the first barrier of the K loop
+    for (int c = tid; c < BM; c += 256) {
+      const int co = m0 + c < P.M ? m0 + c : 0;
+      sBw[c] = P.bw_scale[co];
+      sBw[BM + c] = P.bw_shift[co];
+      sBw[2 * BM + c] = P.bw_mean[co];
+      sBw[3 * BM + c] = P.bw_invstd[co];
+    }
+  }
 
   // ---- DMA bookkeeping (chunk-invariant part of every source address) ---------------------------------------------
   int woff[NWI];
@@ -249,9 +264,61 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     qx[m] = (q & 1) + P.ox;
   }
   const int sm = P.Cs > 0 ? 2 : 1;
+  if (P.bw_y != nullptr) {
+    // Fused pass 1 of BatchNorm+ReLU backward.  The raw outputs are loaded half a wave tile at a time IN FRONT of that
+    // half's stores (loads and stores share vmcnt: a load between two stores serialises them); coefficients from LDS.
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int nt = wn * NT + t;
+    for (int half = 0; half < 2; ++half) {
+      uint2 yr[NT / 2][MT];
+#pragma unroll
+      for (int tt = 0; tt < NT / 2; ++tt) {
+        const int t = half * (NT / 2) + tt, nt = wn * NT + t;
+        const int r = nt / cbs, cb = nt - r * cbs;
+        const int h = min(h0 + r, P.H - 1), w = min(w0 + cb * 16 + j, P.W - 1);
+        const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+          yr[tt][m] = *reinterpret_cast<const uint2*>(yp + (mrow < P.M ? mrow : 0));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < NT / 2; ++tt) {
+        const int t = half * (NT / 2) + tt, nt = wn * NT + t;
+        const int r = nt / cbs, cb = nt - r * cbs;
+        const int h = h0 + r, w = w0 + cb * 16 + j;
+        const bool pix_ok = h < P.H && w < P.W;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+          const int cl = wm * 64 + m * 16 + g * 4;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(sBw + 2 * BM + cl), is = *reinterpret_cast<const f32x4*>(sBw + 3 * BM + cl);
+          float yv[4] = {__uint_as_float(yr[tt][m].x << 16), __uint_as_float(yr[tt][m].x & 0xffff0000u),
+                         __uint_as_float(yr[tt][m].y << 16), __uint_as_float(yr[tt][m].y & 0xffff0000u)};
+          float dz[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = fmaf(yv[e], sc[e], sh[e]) > 0.f ? acc[m][t][e] : 0.f;
+          const unsigned lo = pack_bf16(dz[0], dz[1]), hi = pack_bf16(dz[2], dz[3]);
+          if (pix_ok && mrow < P.M) {
+            u16* o = P.out + ((long long)(n * P.Hob + h) * P.Wob + w) * P.out_pitch + mrow;
+            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+            const float q[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                                __uint_as_float(hi & 0xffff0000u)};   // sums of the values as stored
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s1[m][e] += q[e];
+              s2[m][e] = fmaf(q[e], (yv[e] - mu[e]) * is[e], s2[m][e]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {    const int nt = wn * NT + t;
     const int r = nt / cbs, cb = nt - r * cbs;
     const int h = h0 + r, w = w0 + cb * 16 + j;
     const bool pix_ok = h < P.H && w < P.W;
@@ -276,6 +343,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         }
       }
     }
+  }
   }
   if (P.partials != nullptr) {
     float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
@@ -355,7 +423,7 @@ extern "C" int gsd_bf16_conv_partial_rows(int N, int H, int W, int M) {
 }
 
 extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
-                                void* stream) {
+                                const gsd_bf16_bnbwd* bw, void* stream) {
   if (int e = gsd_check_nhwc(in, "gsd_bf16_conv3x3 in")) return e;
   if (int e = gsd_check_nhwc(out, "gsd_bf16_conv3x3 out")) return e;
   GSD_REQUIRE(wt != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3: null weights");
@@ -378,15 +446,25 @@ extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nh
   P.Cs = 0; P.oy = P.ox = 0;
   P.bias = nullptr;
   P.partials = partials;
+  P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
+  if (bw != nullptr) {
+    if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv3x3 bw.y")) return e;
+    GSD_REQUIRE(bw->scale && bw->shift && bw->mean && bw->invstd && partials, GSD_ERR_BAD_ARG,
+                "gsd_bf16_conv3x3: fused BatchNorm backward needs coefficients and partials");
+    GSD_REQUIRE(bw->y->N == out->N && bw->y->H == out->H && bw->y->W == out->W && bw->y->C == M && (bw->y->pitch & 3) == 0,
+                GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3: bw.y must have out's geometry");
+    P.bw_y = (const u16*)bw->y->ptr; P.bw_pitch = bw->y->pitch;
+    P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
+  }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * pl.HP * 96;
+  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * pl.HP * 96 + (size_t)4 * pl.BM * sizeof(float);
   if (pl.wide) return launch<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
   return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
 }
 
 extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
                                    const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
-                                   float* partials, void* stream) {
+                                   float* partials, const gsd_bf16_bnbwd* bw, void* stream) {
   if (int e = gsd_check_nhwc(in, "gsd_bf16_conv_dense in")) return e;
   if (int e = gsd_check_nhwc(out, "gsd_bf16_conv_dense out")) return e;
   GSD_REQUIRE(wt != nullptr && ty != nullptr && tx != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: null argument");
@@ -419,8 +497,19 @@ extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd
   P.Cs = scatter_cs; P.oy = oy; P.ox = ox;
   P.bias = bias;
   P.partials = partials;
+  P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
+  if (bw != nullptr) {
+    if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv_dense bw.y")) return e;
+    GSD_REQUIRE(scatter_cs == 0 && bias == nullptr && bw->scale && bw->shift && bw->mean && bw->invstd && partials, GSD_ERR_BAD_ARG,
+                "gsd_bf16_conv_dense: fused BatchNorm backward needs plain output, coefficients and partials");
+    GSD_REQUIRE(bw->y->N == out->N && bw->y->H == out->H && bw->y->W == out->W && out->H == H && out->W == W && bw->y->C == M &&
+                    (bw->y->pitch & 3) == 0,
+                GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: bw.y must have out's geometry (and out the GEMM's pixel grid)");
+    P.bw_y = (const u16*)bw->y->ptr; P.bw_pitch = bw->y->pitch;
+    P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
+  }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96;
+  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96 + (size_t)4 * pl.BM * sizeof(float);
   if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
   return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
 }

@@ -127,29 +127,42 @@ __global__ __launch_bounds__(256) void maxpool2_bf16_kernel(NhwcD a, NhwcD o) {
 
 // ---- 1x1 output conv (+bias), fp32 NCHW result (unet.py:54) --------------------------------------------------------
 constexpr int OUTC_MAXK = 4;
+// 8 lanes per pixel, each 16-byte pieces c8, c8+8, ... of the pixel's channels (a wave reads 8 pixels x 128 B contiguous
+// per pass for C = 64); the 8 partial dot products are combined with DPP-free xor shuffles inside the 8-lane group.
 __global__ __launch_bounds__(256) void conv1x1_out_bf16_kernel(NhwcD a, const float* __restrict__ w, const float* __restrict__ b,
                                                                int K, float* __restrict__ out) {
   const long long HW = (long long)a.H * a.W;
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (long long)a.N * HW) return;
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const bool ok = p < (long long)a.N * HW;
   float acc[OUTC_MAXK];
 #pragma unroll
   for (int k = 0; k < OUTC_MAXK; ++k) acc[k] = 0.f;
-  const u16* src = a.p + p * a.pitch;
-  for (int c = 0; c < a.C; c += 8) {
-    float f[8];
-    unpack8(ld16(src + c), f);
+  if (ok) {
+    const u16* src = a.p + p * a.pitch;
+    for (int c = sub * 8; c < a.C; c += 64) {
+      float f[8];
+      unpack8(ld16(src + c), f);
+#pragma unroll
+      for (int k = 0; k < OUTC_MAXK; ++k)
+        if (k < K) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[k] = fmaf(f[i], w[(size_t)k * a.C + c + i], acc[k]);
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k) {
+    acc[k] += __shfl_xor(acc[k], 1, 64);
+    acc[k] += __shfl_xor(acc[k], 2, 64);
+    acc[k] += __shfl_xor(acc[k], 4, 64);
+  }
+  if (ok && sub == 0) {
+    const long long n = p / HW, q = p - n * HW;
 #pragma unroll
     for (int k = 0; k < OUTC_MAXK; ++k)
-      if (k < K) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[k] = fmaf(f[i], w[(size_t)k * a.C + c + i], acc[k]);
-      }
+      if (k < K) out[(n * K + k) * HW + q] = acc[k] + (b != nullptr ? b[k] : 0.f);
   }
-  const long long n = p / HW, q = p - n * HW;
-#pragma unroll
-  for (int k = 0; k < OUTC_MAXK; ++k)
-    if (k < K) out[(n * K + k) * HW + q] = acc[k] + (b != nullptr ? b[k] : 0.f);
 }
 
 // ---- BatchNorm + ReLU (+ max-pool / output conv) backward, pass 1 ---------------------------------------------------
@@ -313,12 +326,16 @@ __global__ __launch_bounds__(256) void channel_sums_stage1(NhwcD t, int y0, int 
     }
   }
 }
-__global__ void channel_sums_stage2(const float* __restrict__ ws, int rows, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 64 channels x 4 row lanes (coalesced rows), fixed summation order
+__global__ __launch_bounds__(256) void channel_sums_stage2(const float* __restrict__ ws, int rows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)ws[(size_t)r * C + c];
-  out[c] = (float)s;
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) s += (double)ws[(size_t)r * C + c];
+  __shared__ double red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 int pick_pixb(int N, int HW) {
@@ -394,7 +411,7 @@ extern "C" int gsd_bf16_conv1x1_out(const gsd_nhwc* a, const float* w, const flo
   if (int e = check_c8(a, "gsd_bf16_conv1x1_out a")) return e;
   GSD_REQUIRE(w && out && K >= 1 && K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv1x1_out: n_classes must be in [1,%d]",
               OUTC_MAXK);
-  hipLaunchKernelGGL(conv1x1_out_bf16_kernel, dim3((unsigned)ceil_div64(npix_of(a), 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(conv1x1_out_bf16_kernel, dim3((unsigned)ceil_div64(npix_of(a) * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                      to_nhwc(*a), w, bias, K, out);
   GSD_LAUNCH_CHECK("gsd_bf16_conv1x1_out");
   return GSD_OK;
@@ -475,7 +492,7 @@ extern "C" int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, 
   hipLaunchKernelGGL(channel_sums_stage1, dim3(chunks, t->N), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream, to_nhwc(*t),
                      y0, x0, hh, ww, pixb, chunks, workspace);
   GSD_LAUNCH_CHECK("gsd_bf16_channel_sums stage1");
-  hipLaunchKernelGGL(channel_sums_stage2, dim3(ceil_div(t->C, 64)), dim3(64), 0, (hipStream_t)stream, workspace, t->N * chunks,
+  hipLaunchKernelGGL(channel_sums_stage2, dim3(ceil_div(t->C, 64)), dim3(256), 0, (hipStream_t)stream, workspace, t->N * chunks,
                      t->C, out);
   GSD_LAUNCH_CHECK("gsd_bf16_channel_sums stage2");
   return GSD_OK;

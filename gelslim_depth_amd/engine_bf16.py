@@ -198,12 +198,12 @@ class UNetEngineBF16:
             z = L.int_array([0])
             done = self._log("bf16_conv_dense", 2.0 * u.cout * src[2] * n * lh * lw)
             check(lib.gsd_bf16_conv_dense(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), src[2], u.cout, 1, 1, z, z, lh, lw, 0, 0, 0,
-                                          None, part, st), "conv_dense(first)")
+                                          None, part, None, st), "conv_dense(first)")
             done()
         else:
             check(lib.gsd_bf16_weight_image(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
             done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
-            check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, st), "conv3x3")
+            check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
         if train:
             rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
@@ -258,7 +258,7 @@ class UNetEngineBF16:
             dslice = L.make_nhwc(self.cat[lvl], self.dims[lvl], up.cout)
             done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * self.hs[lvl + 1] * self.ws[lvl + 1])
             check(lib.gsd_bf16_conv_dense(C.byref(cur.a), up.wt_f.data_ptr(), C.byref(dslice), up.cin, 4 * up.cout, 1, 1, z, z,
-                                          self.hs[lvl + 1], self.ws[lvl + 1], up.cout, oy, ox, P[up.bname].data_ptr(), None, st),
+                                          self.hs[lvl + 1], self.ws[lvl + 1], up.cout, oy, ox, P[up.bname].data_ptr(), None, None, st),
                   "convT")
             done()
             u0, u1 = self.dec[j]
@@ -282,11 +282,18 @@ class UNetEngineBF16:
                                          u.invstd.data_ptr(), C.byref(gsrc), C.byref(u.a), C.byref(dp), L.ptr(dout), L.ptr(wout),
                                          C.byref(dz), self.partials.data_ptr(), st), "bn_bwd_reduce")
 
-    def _tail(self, u: _Unit, G, st: int, dwout: Optional[torch.Tensor] = None) -> None:
-        """u.g holds dz and self.partials its sums: finish BatchNorm backward (dgamma, dbeta, dy in place), then dW."""
+    def _tail(self, u: _Unit, G, st: int, dwout: Optional[torch.Tensor] = None, fused: bool = False) -> None:
+        """u.g holds dz and self.partials its sums: finish BatchNorm backward (dgamma, dbeta, dy in place), then dW.
+        fused: the sums come from a dX launch's epilogue (conv partial layout) instead of gsd_bf16_bn_bwd_reduce."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
-        rows = lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
-        check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st), "bn_bwd_reduce_partials")
+        if fused:
+            rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
+            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
+                                             u.sums.data_ptr(), st), "bn_reduce_partials")
+        else:
+            rows = lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
+            check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
+                  "bn_bwd_reduce_partials")
         count = float(n * lh * lw)
         gsum = None
         if self.sync_fn is not None:
@@ -311,13 +318,28 @@ class UNetEngineBF16:
                                      u.cin, self.wspace.data_ptr(), self.wspace.numel(), st), "wgrad")
         done()
 
-    def _dgrad(self, u: _Unit, P, dst: torch.Tensor, st: int) -> None:
-        """dX of unit u (u.g holds dy) into the plain tensor dst (N,H,W,u.cin)."""
+    def _bnbwd(self, tgt: _Unit):
+        """gsd_bf16_bnbwd for fusing pass 1 of tgt's BatchNorm+ReLU backward into the dX launch that produces tgt.g."""
+        yv = L.make_nhwc(tgt.y)
+        bw = L.gsd_bf16_bnbwd()
+        bw.y = C.pointer(yv)
+        bw.scale, bw.shift, bw.mean, bw.invstd = (tgt.scale.data_ptr(), tgt.shift.data_ptr(), tgt.mean.data_ptr(),
+                                                  tgt.invstd.data_ptr())
+        return bw, yv
+
+    def _dgrad(self, u: _Unit, P, dst: torch.Tensor, st: int, fuse: Optional[_Unit] = None) -> None:
+        """dX of unit u (u.g holds dy) into the plain tensor dst (N,H,W,u.cin); with `fuse` (the unit whose activation is
+        u's input, dst == fuse.g) the epilogue also does pass 1 of that unit's BatchNorm+ReLU backward."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         check(lib.gsd_bf16_weight_image(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_image")
         din, dout = L.make_nhwc(u.g), L.make_nhwc(dst)
+        bw = keep = None
+        if fuse is not None:
+            bw, keep = self._bnbwd(fuse)
         done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
-        check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), u.cout, u.cin, None, st), "conv3x3 dgrad")
+        check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), u.cout, u.cin,
+                                   self.partials.data_ptr() if bw is not None else None, C.byref(bw) if bw is not None else None, st),
+              "conv3x3 dgrad")
         done()
 
     def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
@@ -331,15 +353,15 @@ class UNetEngineBF16:
         check(lib.gsd_sum_planes(dout.data_ptr(), n, self.n_classes, dout.shape[2] * dout.shape[3], G["outc.conv.bias"].data_ptr(),
                                  self.wspace.data_ptr(), st), "sum_planes")
         dwout = G["outc.conv.weight"]
+        prev_fused = None           # unit whose pass-1 sums came from the transposed convolution's dX epilogue
         for j in reversed(range(self.L)):
             u0, u1 = self.dec[j]
             up = self.ups[j]
             lvl = self.L - 1 - j
-            self._tail(u1, G, st, dwout)
+            self._tail(u1, G, st, dwout, fused=prev_fused is u1)
             dwout = None
-            self._dgrad(u1, P, u0.g, st)
-            self._reduce(0, u0, st)
-            self._tail(u0, G, st)
+            self._dgrad(u1, P, u0.g, st, fuse=u0)
+            self._tail(u0, G, st, fused=True)
             self._dgrad(u0, P, self.gcat[lvl], st)
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
@@ -355,10 +377,11 @@ class UNetEngineBF16:
             check(lib.gsd_bf16_weight_image(4, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_image")
             dprev = L.make_nhwc(prev.g)
             done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
+            bw, keep = self._bnbwd(prev)
             check(lib.gsd_bf16_conv_dense(C.byref(gup), up.wt_d.data_ptr(), C.byref(dprev), up.cout, up.cin, 4, 2, ty, tx, hi, wi, 0,
-                                          0, 0, None, None, st), "convT dgrad")
+                                          0, 0, None, self.partials.data_ptr(), C.byref(bw), st), "convT dgrad")
             done()
-            self._reduce(0, prev, st)
+            prev_fused = prev
             if self.block_done_cb is not None:
                 self.block_done_cb(f"dec{j}")
         for lvl in reversed(range(self.L + 1)):
@@ -366,11 +389,10 @@ class UNetEngineBF16:
             if lvl < self.L:
                 gskip = L.make_nhwc(self.gcat[lvl], 0, u1.cout)
                 self._reduce(1, u1, st, g=gskip, dpool=self.dpooled[lvl + 1])
-            self._tail(u1, G, st, dwout)
+            self._tail(u1, G, st, dwout, fused=prev_fused is u1)
             dwout = None
-            self._dgrad(u1, P, u0.g, st)
-            self._reduce(0, u0, st)
-            self._tail(u0, G, st)
+            self._dgrad(u1, P, u0.g, st, fuse=u0)
+            self._tail(u0, G, st, fused=True)
             if self.block_done_cb is not None:
                 self.block_done_cb(f"enc{lvl}")
             if lvl > 0:

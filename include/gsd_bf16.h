@@ -24,6 +24,18 @@ typedef struct {
   int32_t N, H, W, C;
 } gsd_nhwc;
 
+/* Optional fusion for dX launches: the output is the gradient w.r.t. the activation a = relu(bn(y)) of a conv+BN+ReLU
+ * unit, so pass 1 of that unit's BatchNorm+ReLU backward runs in the epilogue: out <- dz = dX where y*scale+shift > 0
+ * else 0, and `partials` receives [sum dz | sum dz*xhat] per block in the layout of the forward statistics (reduce with
+ * gsd_bn_reduce_partials, then gsd_bn_bwd_finalize).  Replaces gsd_bf16_bn_bwd_reduce(mode 0) and its 8 B/element. */
+typedef struct {
+  const gsd_nhwc* y;    /* raw conv output of the unit, same (N,H,W,C) as the launch's out */
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+} gsd_bf16_bnbwd;
+
 /* Row padding of the m (output channel) dimension in every bf16 weight image: gsd_bf16_conv_mpad(M) rows. */
 int gsd_bf16_conv_mpad(int M);
 
@@ -32,7 +44,8 @@ int gsd_bf16_conv_mpad(int M);
  * partials (or NULL): per-block BatchNorm partial sums of the STORED (rounded) values, gsd_bf16_conv_partial_rows rows of
  * 2*mpad(M) floats, to be reduced with gsd_bn_reduce_partials(partials, rows, mpad(M), M, ...) from gsd.h. */
 int gsd_bf16_conv_partial_rows(int N, int H, int W, int M);
-int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials, void* stream);
+int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
+                     const gsd_bf16_bnbwd* bw, void* stream);
 
 /* Taps without spatial reuse on an (N,H,W) pixel grid:
  *   acc[n,h,w,m] = sum_{t<ntaps} sum_k in[n, stride*h+ty[t], stride*w+tx[t], k] * wt[t][m][k]   (zeros outside in)
@@ -43,7 +56,7 @@ int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, in
  * With 4 taps at stride 2 and a dgrad weight image it is the dX of that ConvTranspose2d. */
 int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
                         const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
-                        float* partials, void* stream);
+                        float* partials, const gsd_bf16_bnbwd* bw, void* stream);
 
 /* ---- weight images (fp32 master -> bf16 GEMM layout [T][mpad(M)][round_up(K,32)], zero padded) ---------------------
  * mode 0 conv3x3 forward  from (Cout,Cin,3,3):  [t][co][ci]

@@ -24,7 +24,7 @@ for h, w, k, m in SHAPES:
     din, dout = L.make_nhwc(x), L.make_nhwc(out)
 
     def run():
-        L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), wt.data_ptr(), C.byref(dout), k, m, None if os.environ.get("NOSTATS") else part.data_ptr(), L.stream_ptr()), "conv")
+        L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), wt.data_ptr(), C.byref(dout), k, m, None if os.environ.get("NOSTATS") else part.data_ptr(), None, L.stream_ptr()), "conv")
     for _ in range(2):
         run()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -71,7 +71,7 @@ def test_conv3x3_bf16(n, h, w, k, m, in_tot, in_off, out_tot, out_off):
     mp = L.lib.gsd_bf16_conv_mpad(m)
     part = torch.zeros((rows, 2 * mp), dtype=torch.float32, device="cuda")
     din, dout = L.make_nhwc(xin, in_off, k), L.make_nhwc(out, out_off, m)
-    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), k, m, part.data_ptr(), L.stream_ptr()), "conv")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), k, m, part.data_ptr(), None, L.stream_ptr()), "conv")
     torch.cuda.synchronize()
     got = from_nhwc(out, out_off, m)
     assert_close_bf16(got, ref, "conv3x3")
@@ -100,7 +100,7 @@ def test_dense_1x1_and_convT_bf16():
     z = L.int_array([0])
     img1 = weight_image(wt[None])
     L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img1.data_ptr(), C.byref(dout), k, m, 1, 1, z, z, h, w, 0, 0,
-                                      0, None, None, L.stream_ptr()), "1x1")
+                                      0, None, None, None, L.stream_ptr()), "1x1")
     assert_close_bf16(from_nhwc(out, 0, m), ref, "1x1")
 
     # ConvTranspose2d(k2,s2)+bias scattered into the second half of a concat buffer, with the F.pad offset (0,1)
@@ -115,7 +115,7 @@ def test_dense_1x1_and_convT_bf16():
     din, dout = L.make_nhwc(xin), L.make_nhwc(cat, cout, cout)
     bias_d = bias.cuda()
     L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img.data_ptr(), C.byref(dout), cin, 4 * cout, 1, 1, z, z, h, w, cout, 0, 1,
-                                      bias_d.data_ptr(), None, L.stream_ptr()), "convT")
+                                      bias_d.data_ptr(), None, None, L.stream_ptr()), "convT")
     got = cat.float().cpu()
     assert_close_bf16(got[:, 0:2 * h, 1:2 * w + 1, cout:].permute(0, 3, 1, 2), ref, "convT")
     assert float(got[..., :cout].abs().max()) == 0.0 and float(got[:, 2 * h:].abs().max()) == 0.0
@@ -133,7 +133,7 @@ def test_dense_1x1_and_convT_bf16():
     din, dout = L.make_nhwc(gcat, cout, cout), L.make_nhwc(dx)
     ty, tx = L.int_array([0, 0, 1, 1]), L.int_array([1, 2, 1, 2])                            # (kh, kw + pad offset 1)
     L.check(L.lib.gsd_bf16_conv_dense(C.byref(din), img_d.data_ptr(), C.byref(dout), cout, cin, 4, 2, ty, tx, h, w, 0, 0, 0,
-                                      None, None, L.stream_ptr()), "convT dgrad")
+                                      None, None, None, L.stream_ptr()), "convT dgrad")
     assert_close_bf16(from_nhwc(dx, 0, cin), xd.grad, "convT dX")
 
 
@@ -327,7 +327,7 @@ def test_conv3x3_dgrad_through_weight_image_bf16():
     L.check(L.lib.gsd_bf16_weight_image(1, wd.data_ptr(), cout, cin, img.data_ptr(), L.stream_ptr()), "wimg")
     dyb, dx = to_nhwc(dy), torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device="cuda")
     din, dout = L.make_nhwc(dyb), L.make_nhwc(dx)
-    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), cout, cin, None, L.stream_ptr()), "dgrad")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), cout, cin, None, None, L.stream_ptr()), "dgrad")
     assert_close_bf16(from_nhwc(dx, 0, cin), xz.grad, "conv3x3 dX")
 
 
@@ -343,3 +343,47 @@ def test_channel_sums_bf16():
     L.check(L.lib.gsd_bf16_channel_sums(C.byref(view), 1, 0, 20, 26, out.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()), "sums")
     ref = t[:, :, 1:21, 0:26].double().sum(dim=(0, 2, 3))
     assert torch.allclose(out.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_conv3x3_dgrad_fused_bn_bwd_bf16():
+    """dX launch with pass 1 of the input unit's BatchNorm+ReLU backward in the epilogue == plain dX followed by
+    gsd_bf16_bn_bwd_reduce(mode 0): same dz (bit for bit) and the same per-channel sums."""
+    L = _lib()
+    g = torch.Generator().manual_seed(14)
+    n, h, w, cin, cout = 2, 19, 37, 96, 64          # dX has M = cin = 96 rows
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3.0 * cin ** 0.5)
+    dy = bf16r(torch.randn((n, cout, h, w), generator=g))
+    y = bf16r(torch.randn((n, cin, h, w), generator=g))
+    mean, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma, beta = torch.rand((cin,), generator=g) + 0.5, 0.3 * torch.randn((cin,), generator=g)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    dev = [t.cuda() for t in (scale, shift, mean, invstd)]
+    img = torch.empty((L.lib.gsd_bf16_weight_image_size(1, cout, cin),), dtype=torch.bfloat16, device="cuda")
+    wd = wt.cuda()
+    L.check(L.lib.gsd_bf16_weight_image(1, wd.data_ptr(), cout, cin, img.data_ptr(), L.stream_ptr()), "wimg")
+    dyb, yb = to_nhwc(dy), to_nhwc(y)
+    din, dyv = L.make_nhwc(dyb), L.make_nhwc(yb)
+    # (a) unfused
+    dx = torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(dx)), cout, cin, None, None, L.stream_ptr()), "dX")
+    rows_b = L.lib.gsd_bf16_bn_bwd_partial_rows(n, h, w)
+    part_b = torch.zeros((rows_b, 3 * cin), device="cuda")
+    L.check(L.lib.gsd_bf16_bn_bwd_reduce(0, C.byref(dyv), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(),
+                                         C.byref(L.make_nhwc(dx)), C.byref(dyv), C.byref(dyv), None, None, C.byref(L.make_nhwc(dx)),
+                                         part_b.data_ptr(), L.stream_ptr()), "reduce")
+    # (b) fused
+    dz = torch.zeros((n, h, w, cin), dtype=torch.bfloat16, device="cuda")
+    rows = L.lib.gsd_bf16_conv_partial_rows(n, h, w, cin)
+    mp = L.lib.gsd_bf16_conv_mpad(cin)
+    part = torch.zeros((rows, 2 * mp), device="cuda")
+    bw = L.gsd_bf16_bnbwd()
+    bw.y = C.pointer(dyv)
+    bw.scale, bw.shift, bw.mean, bw.invstd = (t.data_ptr() for t in dev)
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(dz)), cout, cin, part.data_ptr(), C.byref(bw),
+                                   L.stream_ptr()), "fused dX")
+    torch.cuda.synchronize()
+    assert torch.equal(dz.cpu(), dx.cpu())
+    sa, sb = part.double().sum(dim=0).cpu(), part_b.double().sum(dim=0).cpu()
+    assert torch.allclose(sa[:cin], sb[:cin], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(sa[mp:mp + cin], sb[cin:2 * cin], rtol=1e-5, atol=1e-4)
