@@ -30,7 +30,7 @@ struct GConvP {
   long long out_pitch;
   int Hob, Wob;   // output BUFFER extent
   int N, H, W;    // GEMM pixel grid
-  int K, M, Mpad, mblocks;
+  int K, M, Mpad, mblocks, nitems;
   int ntaps, stride;
   int ty[9], tx[9];
   int TH, TW, tiles_y, tiles_x, HC, HP;
@@ -64,17 +64,20 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, j = lane & 15;
 
+  // Persistent block: it walks work items (pixel tile, m-block) item = blockIdx.x, + gridDim.x, ...; gridDim.x is a
+  // multiple of mblocks, so the m-block (and with it every weight address and coefficient) is fixed per block.
   const int mb = blockIdx.x % P.mblocks;
-  const int pt = blockIdx.x / P.mblocks;
-  const int tpi = P.tiles_y * P.tiles_x;
-  const int n = pt / tpi;
-  const int trem = pt - n * tpi;
-  const int tyi = trem / P.tiles_x;
-  const int h0 = tyi * P.TH, w0 = (trem - tyi * P.tiles_x) * P.TW;
   const int m0 = mb * BM;
+  const int tpi = P.tiles_y * P.tiles_x;
   const int cbs = P.TW >> 4;  // 16-pixel column blocks per tile row
-
-  const u16* in_img = P.in + (long long)n * P.Hin * P.Win * P.in_pitch;
+  auto decode = [&](int item, int& n, int& h0, int& w0) {
+    const int pt = item / P.mblocks;
+    n = pt / tpi;
+    const int trem = pt - n * tpi;
+    const int tyi = trem / P.tiles_x;
+    h0 = tyi * P.TH;
+    w0 = (trem - tyi * P.tiles_x) * P.TW;
+  };
   if (P.bw_y != nullptr) {   // visible to everyone after the first barrier of the K loop
     for (int c = tid; c < BM; c += 256) {
       const int co = m0 + c < P.M ? m0 + c : 0;
@@ -95,31 +98,45 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
     woff[k] = (tapk * P.Mpad + m0 + row) * P.K + gg * 8;
   }
-  // activations: MODE 0 -> element offset inside the image of this lane's 16-byte piece (-1: zeros, -2: no transfer);
-  //              MODE 1 -> (r << 16 | c << 4 | slot) of the tile pixel, or -2
-  int xoff[MAXX];
+  // activations, tile-invariant part: (y << 16 | x << 4 | slot) of this lane's 16-byte piece -- halo position (MODE 0) or
+  // tile pixel (MODE 1) -- or -2: no transfer
+  int xpk[MAXX];
 #pragma unroll
   for (int k = 0; k < MAXX; ++k) {
     const int o = (k * 4 + wave) * 1024 + lane * 16;
     const int px = o / 96, slot = (o - px * 96) >> 4;
+    const int rowlen = MODE == 0 ? P.HC : P.TW;
     int v = -2;
-    if (MODE == 0) {
-      if (px < P.HP && slot < 4) {
-        const int hy = px / P.HC, hx = px - hy * P.HC;
-        const int hi = h0 - 1 + hy, wi = w0 - 1 + hx;
-        v = ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win) ? (int)((hi * P.Win + wi) * P.in_pitch) + slot * 8
-                                                                              : -1;
-      }
-    } else {
-      if (px < NPX && slot < 4) {
-        const int r = px / P.TW, c = px - r * P.TW;
-        v = (h0 + r < P.H && w0 + c < P.W) ? ((r << 16) | (c << 4) | slot) : -1;
-      }
+    if (px < (MODE == 0 ? P.HP : NPX) && slot < 4) {
+      const int y = px / rowlen, x = px - y * rowlen;
+      v = (y << 16) | (x << 4) | slot;
     }
-    xoff[k] = v;
+    xpk[k] = v;
   }
+  // per item: MODE 0 -> element offset inside the image of the piece (-1: zeros, -2: no transfer);
+  //           MODE 1 -> xpk when the tile pixel exists, else -1 / -2
+  int xoff[MAXX];
+  auto prep = [&](int h0, int w0) {
+#pragma unroll
+    for (int k = 0; k < MAXX; ++k) {
+      int v = -2;
+      if (xpk[k] != -2) {
+        const int y = xpk[k] >> 16, x = (xpk[k] >> 4) & 0xfff, slot = xpk[k] & 15;
+        if (MODE == 0) {
+          const int hi = h0 - 1 + y, wi = w0 - 1 + x;
+          v = ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win) ? (int)((hi * P.Win + wi) * P.in_pitch) + slot * 8 : -1;
+        } else {
+          v = (h0 + y < P.H && w0 + x < P.W) ? xpk[k] : -1;
+        }
+      }
+      xoff[k] = v;
+    }
+  };
 
-  auto issue = [&](int it) {
+  // DMA of iteration `it` of the item at (n, h0, w0) -- whose offsets are in xoff -- into the buffers of GLOBAL
+  // iteration git (the parity keeps alternating across items, so an item's first fill never hits a buffer in use)
+  auto issue = [&](int it, int git, int n, int h0, int w0) {
+    const u16* in_img = P.in + (long long)n * P.Hin * P.Win * P.in_pitch;
     int chunk, tap0;
     if (MODE == 0) {
       chunk = it / 3;
@@ -129,14 +146,14 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       tap0 = it / nch;
       chunk = it - tap0 * nch;
     }
-    unsigned char* wdst = Wl + (it & 1) * WBUF;
+    unsigned char* wdst = Wl + (git & 1) * WBUF;
     const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
 #pragma unroll
     for (int k = 0; k < NWI; ++k)
       __builtin_amdgcn_global_load_lds((const void*)(wsrc + woff[k]), wdst + (k * 4 + wave) * 1024, 16, 0, 0);
     if (MODE == 0) {
       if (tap0 != 0) return;   // the halo tile of a chunk arrives with its first kernel row
-      unsigned char* xdst = Xl + (chunk & 1) * XBUF;
+      unsigned char* xdst = Xl + ((git / 3) & 1) * XBUF;
       const u16* src = in_img + chunk * 32;
 #pragma unroll
       for (int k = 0; k < MAXX; ++k) {
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         }
       }
     } else {
-      unsigned char* xdst = Xl + (it & 1) * XBUF;
+      unsigned char* xdst = Xl + (git & 1) * XBUF;
       const u16* src = in_img + chunk * 32;
       const int ty = P.ty[tap0], tx = P.tx[tap0];
 #pragma unroll
@@ -178,6 +195,14 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
   }
 
+  const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * (P.K >> 5);
+  int item = blockIdx.x;
+  if (item >= P.nitems) return;
+  int n, h0, w0, git = 0;
+  decode(item, n, h0, w0);
+  prep(h0, w0);
+  issue(0, 0, n, h0, w0);
+  while (true) {
   // The accumulators start at the bias (MODE 1 only): no load is then left for the epilogue, where it would sit between
   // the stores -- loads and stores share vmcnt on gfx950, and hipcc answers a load of unknown age inside divergent
   // control flow with s_waitcnt vmcnt(0) in front of EVERY store (measured: 13 us per block).
@@ -196,18 +221,24 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     for (int t = 0; t < NT; ++t) acc[m][t] = init;
   }
 
-  const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * (P.K >> 5);
-  issue(0);
-  for (int it = 0; it < iters; ++it) {
-    __syncthreads();   // iteration it's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
-    if (it + 1 < iters) issue(it + 1);
-    const unsigned char* Wc = Wl + (it & 1) * WBUF + aoff;
+  const int next = item + gridDim.x;
+  int nn = 0, nh0 = 0, nw0 = 0;
+  for (int it = 0; it < iters; ++it, ++git) {
+    __syncthreads();   // iteration git's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
+    if (it + 1 < iters) {
+      issue(it + 1, git + 1, n, h0, w0);
+    } else if (next < P.nitems) {   // the next item's first fill flies during this item's last iteration and epilogue
+      decode(next, nn, nh0, nw0);
+      prep(nh0, nw0);
+      issue(0, git + 1, nn, nh0, nw0);
+    }
+    const unsigned char* Wc = Wl + (git & 1) * WBUF + aoff;
     const unsigned char* Xc;
     if (MODE == 0) {
-      const int chunk = it / 3, kh = it - chunk * 3;
-      Xc = Xl + (chunk & 1) * XBUF + kh * P.HC * 96;
+      const int kh = it % 3;
+      Xc = Xl + ((git / 3) & 1) * XBUF + kh * P.HC * 96;
     } else {
-      Xc = Xl + (it & 1) * XBUF;
+      Xc = Xl + (git & 1) * XBUF;
     }
     // software pipeline over the taps of this iteration: the 12 operand reads of tap kw+1 are interleaved with the 32
     // MFMAs of tap kw (1 ds_read : 2 MFMA; hipcc otherwise sinks every read to just before its first use and waits
@@ -346,18 +377,24 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   }
   }
   if (P.partials != nullptr) {
-    float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
+    float* row = P.partials + (size_t)((item / P.mblocks) * WN + wn) * (2 * P.Mpad);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float a1 = reduce16(s1[m][r]), a2 = reduce16(s2[m][r]);
+        const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
         const int mrow = m0 + wm * 64 + m * 16 + g * 4 + r;
-        if (j == 0 && mrow < P.Mpad) {
+        if (j == 15 && mrow < P.Mpad) {
           row[mrow] = a1;
           row[P.Mpad + mrow] = a2;
         }
       }
+  }
+  if (next >= P.nitems) break;
+  item = next;
+  n = nn;
+  h0 = nh0;
+  w0 = nw0;
   }
 }
 
@@ -393,8 +430,25 @@ Plan make_plan(int H, int W, int M) {
   return p;
 }
 
+int cu_count() {
+  static int n = 0;   // benign race: every thread computes the same value
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v;
+  }
+  return n;
+}
+
+// items = (pixel tile, m-block) pairs; one persistent block per CU (the LDS image allows one), a multiple of mblocks
 template <int MODE, int WM, int WN>
-int launch(const GConvP& P, long grid, size_t lds, hipStream_t st, const char* what) {
+int launch(GConvP& P, long items, size_t lds, hipStream_t st, const char* what) {
+  GSD_REQUIRE(items > 0 && items < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: %ld work items out of range", what, items);
+  P.nitems = (int)items;
+  long grid = cu_count() / P.mblocks * P.mblocks;
+  if (grid < P.mblocks) grid = P.mblocks;
+  if (grid > items) grid = items;
   static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>),

@@ -90,6 +90,16 @@ __device__ __forceinline__ float reduce16(float v) {
   v += __shfl_xor(v, 8, 64);
   return v;
 }
+// Same sum with DPP row shifts (4 VALU instructions, no LDS traffic; __shfl_xor lowers to ds_bpermute): the total of a
+// 16-lane row lands in its LAST lane (lane & 15 == 15); the other lanes hold partial sums.
+__device__ __forceinline__ float reduce16_to_lane15(float v) {
+  // row_shr:n = 0x110 + n; lanes shifted in from outside the row read 0 (bound_ctrl)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;

@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
           }
         }
         if (P.partials != nullptr) {
-          s1 = reduce16(s1);
-          s2 = reduce16(s2);
-          if (l16 == 0 && co < P.Mpad) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
             float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
             row[co] = s1;
             row[P.Mpad + co] = s2;
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
           }
         }
         if (P.partials != nullptr) {
-          s1 = reduce16(s1);
-          s2 = reduce16(s2);
-          if (l16 == 0 && co < P.Mpad) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
             float* row = P.partials + (size_t)(pt * WN + wn) * (2 * P.Mpad);
             row[co] = s1;
             row[P.Mpad + co] = s2;
