@@ -19,6 +19,8 @@
 // (weights are re-read per pixel tile), which is why the tile is wide in pixels.
 #include "gsd_bf16_common.h"
 
+#include <type_traits>
+
 __device__ const uint4 gsd_zero16[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
 struct GConvP {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   constexpr int MAXX = MODE == 0 ? (WN == 2 ? 10 : 16) : NPX * 3 / 32 / 4;   // activation DMA instructions per wave
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int XBUF = (MODE == 0 ? P.HP : NPX) * 96;
+  constexpr int XBUF = MAXX * 4096;   // every DMA instruction moves a whole 1 KiB piece (pad and slack lanes carry zeros)
   unsigned char* Wl = smem;
   unsigned char* Xl = smem + 2 * WBUF;
   float* sBw = reinterpret_cast<float*>(smem + 2 * WBUF + 2 * XBUF);   // [4][BM] output-side BatchNorm coefficients (fused dX)
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     woff[k] = (tapk * P.Mpad + m0 + row) * P.K + gg * 8;
   }
   // activations, tile-invariant part: (y << 16 | x << 4 | slot) of this lane's 16-byte piece -- halo position (MODE 0) or
-  // tile pixel (MODE 1) -- or -2: no transfer
+  // tile pixel (MODE 1) -- or -2: a pad / slack piece.  Those are filled from the zero line like out-of-image pixels:
+  // with no lane skipped the whole fill is straight-line code that can be interleaved with the MFMAs.
   int xpk[MAXX];
 #pragma unroll
   for (int k = 0; k < MAXX; ++k) {
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
     xpk[k] = v;
   }
-  // per item: MODE 0 -> element offset inside the image of the piece (-1: zeros, -2: no transfer);
-  //           MODE 1 -> xpk when the tile pixel exists, else -1 / -2
+  // per item: MODE 0 -> element offset inside the image of the piece, negative: zeros;
+  //           MODE 1 -> xpk when the tile pixel exists, negative: zeros
   int xoff[MAXX];
   auto prep = [&](int h0, int w0) {
 #pragma unroll
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   };
 
   // DMA of iteration `it` of the item at (n, h0, w0) -- whose offsets are in xoff -- into the buffers of GLOBAL
-  // iteration git (the parity keeps alternating across items, so an item's first fill never hits a buffer in use)
-  auto issue = [&](int it, int git, int n, int h0, int w0) {
-    const u16* in_img = P.in + (long long)n * P.Hin * P.Win * P.in_pitch;
+  // iteration git (the parity keeps alternating across items, so an item's first fill never hits a buffer in use).
+  // Slots [0, NWI) move the weights, slots [NWI, NWI + MAXX) the activations; every slot is one branch-free instruction.
+  auto dma_slot = [&](int slot, int it, int git, int n, int h0, int w0) {
     int chunk, tap0;
     if (MODE == 0) {
       chunk = it / 3;
@@ -146,39 +149,33 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       tap0 = it / nch;
       chunk = it - tap0 * nch;
     }
-    unsigned char* wdst = Wl + (git & 1) * WBUF;
-    const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
-#pragma unroll
-    for (int k = 0; k < NWI; ++k)
-      __builtin_amdgcn_global_load_lds((const void*)(wsrc + woff[k]), wdst + (k * 4 + wave) * 1024, 16, 0, 0);
-    if (MODE == 0) {
-      if (tap0 != 0) return;   // the halo tile of a chunk arrives with its first kernel row
-      unsigned char* xdst = Xl + ((git / 3) & 1) * XBUF;
-      const u16* src = in_img + chunk * 32;
-#pragma unroll
-      for (int k = 0; k < MAXX; ++k) {
-        if (xoff[k] != -2) {
-          const void* s = xoff[k] >= 0 ? (const void*)(src + xoff[k]) : (const void*)gsd_zero16;
-          __builtin_amdgcn_global_load_lds(s, xdst + (k * 4 + wave) * 1024, 16, 0, 0);
-        }
-      }
-    } else {
-      unsigned char* xdst = Xl + (git & 1) * XBUF;
-      const u16* src = in_img + chunk * 32;
-      const int ty = P.ty[tap0], tx = P.tx[tap0];
-#pragma unroll
-      for (int k = 0; k < MAXX; ++k) {
-        if (xoff[k] != -2) {
-          const void* s = (const void*)gsd_zero16;
-          if (xoff[k] >= 0) {
-            const int hi = P.stride * (h0 + (xoff[k] >> 16)) + ty, wi = P.stride * (w0 + ((xoff[k] >> 4) & 0xfff)) + tx;
-            if ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win)
-              s = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (xoff[k] & 15) * 8);
-          }
-          __builtin_amdgcn_global_load_lds(s, xdst + (k * 4 + wave) * 1024, 16, 0, 0);
-        }
-      }
+    if (slot < NWI) {
+      const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
+      __builtin_amdgcn_global_load_lds((const void*)(wsrc + woff[slot]), Wl + (git & 1) * WBUF + (slot * 4 + wave) * 1024, 16, 0, 0);
+      return;
     }
+    const int k = slot - NWI;
+    const u16* src = P.in + (long long)n * P.Hin * P.Win * P.in_pitch + chunk * 32;
+    const void* sp = (const void*)gsd_zero16;
+    if (MODE == 0) {
+      if (xoff[k] >= 0) sp = (const void*)(src + xoff[k]);
+      __builtin_amdgcn_global_load_lds(sp, Xl + ((git / 3) & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);
+    } else {
+      if (xoff[k] >= 0) {
+        const int hi = P.stride * (h0 + (xoff[k] >> 16)) + P.ty[tap0], wi = P.stride * (w0 + ((xoff[k] >> 4) & 0xfff)) + P.tx[tap0];
+        if ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win)
+          sp = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (xoff[k] & 15) * 8);
+      }
+      __builtin_amdgcn_global_load_lds(sp, Xl + (git & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);
+    }
+  };
+  // slots of one iteration: the weights always; the activations with every iteration (MODE 1) or with a chunk's first
+  // kernel row (MODE 0)
+  auto nslots = [&](int it) { return (MODE == 1 || it % 3 == 0) ? NWI + MAXX : NWI; };
+  auto issue = [&](int it, int git, int n, int h0, int w0) {
+#pragma unroll
+    for (int sl = 0; sl < NWI + MAXX; ++sl)
+      if (sl < nslots(it)) dma_slot(sl, it, git, n, h0, w0);
   };
 
   // ---- operand read offsets ------------------------------------------------------------------------------------
@@ -222,27 +219,26 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   }
 
   const int next = item + gridDim.x;
-  int nn = 0, nh0 = 0, nw0 = 0;
-  for (int it = 0; it < iters; ++it, ++git) {
-    __syncthreads();   // iteration git's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
-    if (it + 1 < iters) {
-      issue(it + 1, git + 1, n, h0, w0);
-    } else if (next < P.nitems) {   // the next item's first fill flies during this item's last iteration and epilogue
-      decode(next, nn, nh0, nw0);
+  int nn = n, nh0 = h0, nw0 = w0;
+  int it = 0;
+  // One iteration = one barrier = NTAPI taps.  KH (MODE 0: the kernel row, = it % 3) is a compile-time constant so that the
+  // iteration body is straight-line code: the fill of the NEXT iteration (weights; plus the next chunk's halo tile when
+  // KH == 2) is issued slot by slot BETWEEN the MFMAs, in the 8 of an MFMA's 16 cycles that leave the issue port free,
+  // instead of in front of them.
+  auto body = [&](auto khc) {
+    constexpr int KH = decltype(khc)::value;
+    constexpr int NS = (MODE == 1 || KH == 2) ? NWI + MAXX : NWI;     // DMA slots of this iteration
+    constexpr int SPT = (NS + NTAPI - 1) / NTAPI;                       // per tap
+    gsd_dma_barrier();   // iteration git's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
+    int f_it = it + 1, f_n = n, f_h0 = h0, f_w0 = w0;
+    if (it + 1 == iters) {   // the fill belongs to the next item: it flies during this item's last iteration and epilogue
+      f_it = 0;              // (after the last item it repeats this item's first fill, which nobody reads: no branch)
+      if (next < P.nitems) decode(next, nn, nh0, nw0);
       prep(nh0, nw0);
-      issue(0, git + 1, nn, nh0, nw0);
+      f_n = nn; f_h0 = nh0; f_w0 = nw0;
     }
     const unsigned char* Wc = Wl + (git & 1) * WBUF + aoff;
-    const unsigned char* Xc;
-    if (MODE == 0) {
-      const int kh = it % 3;
-      Xc = Xl + ((git / 3) & 1) * XBUF + kh * P.HC * 96;
-    } else {
-      Xc = Xl + (git & 1) * XBUF;
-    }
-    // software pipeline over the taps of this iteration: the 12 operand reads of tap kw+1 are interleaved with the 32
-    // MFMAs of tap kw (1 ds_read : 2 MFMA; hipcc otherwise sinks every read to just before its first use and waits
-    // lgkmcnt(0) in front of each MFMA group -- with one wave per SIMD nothing else hides that latency)
+    const unsigned char* Xc = MODE == 0 ? Xl + ((git / 3) & 1) * XBUF + KH * P.HC * 96 : Xl + (git & 1) * XBUF;
     u32x4 a[2][MT], b[2][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(Wc + m * 1024);
@@ -251,25 +247,32 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kw = 0; kw < NTAPI; ++kw) {
-      if (kw + 1 < NTAPI) {
+      // 16 micro-steps of {two MFMAs, one operand read for the next tap, one DMA slot}, pinned in this order: the
+      // LDS-touching instructions (ds_read, global_load_lds) keep their program order anyway, so the interleaving has to
+      // be written out -- a sched_group_barrier pattern over the whole tap leaves the reads bunched in front.
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[(kw + 1) & 1][m] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + m * 1024);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[(kw + 1) & 1][t] = *reinterpret_cast<const u32x4*>(Xc + boff[t] + (kw + 1) * 96);
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = mfma_bf16(a[kw & 1][m], b[kw & 1][t], acc[m][t]);
-      if (kw + 1 < NTAPI) {
-#pragma unroll
-        for (int i = 0; i < MT + NT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // two MFMAs (operands read during the previous tap)
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read for the next tap
+      for (int i = 0; i < MT * NT / 2; ++i) {
+        const int m = i / (NT / 2), t = 2 * (i % (NT / 2));
+        acc[m][t] = mfma_bf16(a[kw & 1][m], b[kw & 1][t], acc[m][t]);
+        acc[m][t + 1] = mfma_bf16(a[kw & 1][m], b[kw & 1][t + 1], acc[m][t + 1]);
+        if (kw + 1 < NTAPI) {
+          if (i < MT) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + i * 1024);
+          else if (i < MT + NT) b[(kw + 1) & 1][i - MT] = *reinterpret_cast<const u32x4*>(Xc + boff[i - MT] + (kw + 1) * 96);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * (MT + NT), 0);
+        if (i < SPT && kw * SPT + i < NS) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++it;
+    ++git;
+  };
+  while (it < iters) {
+    if (MODE == 0) {
+      body(std::integral_constant<int, 0>{});
+      body(std::integral_constant<int, 1>{});
+      body(std::integral_constant<int, 2>{});
+    } else {
+      body(std::integral_constant<int, 0>{});
     }
   }
 
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   h0 = nh0;
   w0 = nw0;
   }
+  gsd_dma_barrier();   // vmcnt(0): the last (unread) fill must have landed before the block gives its LDS back
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -511,7 +515,7 @@ extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nh
     P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
   }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * pl.HP * 96 + (size_t)4 * pl.BM * sizeof(float);
+  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * (pl.wide ? 16 : 10) * 4096 + (size_t)4 * pl.BM * sizeof(float);
   if (pl.wide) return launch<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
   return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
 }

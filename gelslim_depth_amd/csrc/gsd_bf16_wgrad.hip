@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
         __builtin_amdgcn_global_load_lds(s, Bl + (k * 4 + wave) * 1024, 16, 0, 0);
       }
     }
-    __syncthreads();   // vmcnt(0) + barrier: both images have landed
+    gsd_dma_barrier();   // vmcnt(0) + barrier: both images have landed
     // One flat, fully unrolled sequence of KS*TT steps (4 MFMAs each).  The B operand of step s+2 and, two steps before a
     // k-step ends, the A operands of the next k-step are read while step s multiplies: every ds_read_b64_tr_b16 has at
     // least one whole step (64 MFMA cycles, plus whatever the CU's other block interleaves) to land.

@@ -75,6 +75,16 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Barrier that PUBLISHES LDS-DMA fills: global_load_lds completes through vmcnt, and hipcc's own wait in front of
+// __syncthreads() / the following ds_read depends on its alias analysis of the DMA destination against the reads -- with
+// double-buffered images it can prove "different buffer" inside one loop body and then drops the wait across the
+// back-edge (observed: s_barrier with no s_waitcnt vmcnt(0) in gconv_bf16_kernel<1,..>, stale tile rows).  So the wait is
+// written out.  s_waitcnt immediate on gfx9: vmcnt = bits[3:0] | bits[15:14] << 4, expcnt = bits[6:4], lgkmcnt = bits[11:8].
+__device__ __forceinline__ void gsd_dma_barrier() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  __syncthreads();
+}
+
 // Logical block id such that every XCD (blocks b, b+8, b+16, ... share one) owns a contiguous id range.
 __device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7;

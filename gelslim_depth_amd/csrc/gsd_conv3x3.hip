@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
   for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
-    __syncthreads();  // this chunk's DMA has landed (vmcnt(0) + barrier); everyone has left the other buffer
+    gsd_dma_barrier();  // this chunk's DMA has landed (vmcnt(0) + barrier); everyone has left the other buffer
     const int kc = chunk * 4 + j;   // this lane's k row (input channel) in this chunk
     const float sc = sAff[kc], sh = sAff[Kpad + kc];
     const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());

@@ -336,23 +336,23 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
   const int nst = s_end - s_begin;
   if constexpr (SWAP) {
     if (grp == 1 && nst > 0) issue_dma(s_begin, 0);
-    __syncthreads();
+    gsd_dma_barrier();
     for (int it = 0; it < nst; ++it) {
       const int cur = it & 1;
       if (grp == cur) compute(cur);
       else if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
-      __syncthreads();  // the loaders' vmcnt(0) + barrier: image cur^1 is complete, image cur is free; roles swap
+      gsd_dma_barrier();  // the loaders' vmcnt(0) + barrier: image cur^1 is complete, image cur is free; roles swap
     }
   } else {
     if (NBUF == 2 && nst > 0) issue_dma(s_begin, 0);
     for (int it = 0; it < nst; ++it) {
       const int cur = NBUF == 2 ? it & 1 : 0;   // NBUF 1 and 4: one image
-      __syncthreads();  // NBUF 2: this stage's DMA has landed, everyone left the other image; NBUF 1: everyone left the image
+      gsd_dma_barrier();  // NBUF 2: this stage's DMA has landed, everyone left the other image; NBUF 1: everyone left the image
       if (NBUF == 2) {
         if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
       } else {
         issue_dma(s_begin + it, 0);
-        __syncthreads();  // vmcnt(0) + barrier: the image is complete
+        gsd_dma_barrier();  // vmcnt(0) + barrier: the image is complete
       }
       compute(cur);
     }
