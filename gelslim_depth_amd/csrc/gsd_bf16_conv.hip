@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   unsigned char* Wl = smem;
   unsigned char* Xl = smem + 2 * WBUF;
   float* sBw = reinterpret_cast<float*>(smem + 2 * WBUF + 2 * XBUF);   // [4][BM] output-side BatchNorm coefficients (fused dX)
+  float* sSt = sBw + 4 * BM;                                           // [4 waves][2][64] running partial sums of the block
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     h0 = tyi * P.TH;
     w0 = (trem - tyi * P.tiles_x) * P.TW;
   };
+  if (P.partials != nullptr) {   // each (wave, row) cell is only ever touched by one lane: no synchronisation needed
+    for (int c = tid; c < 4 * 2 * 64; c += 256) sSt[c] = 0.f;
+  }
   if (P.bw_y != nullptr) {   // visible to everyone after the first barrier of the K loop
     for (int c = tid; c < BM; c += 256) {
       const int co = m0 + c < P.M ? m0 + c : 0;
@@ -380,16 +384,18 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   }
   }
   if (P.partials != nullptr) {
-    float* row = P.partials + (size_t)((item / P.mblocks) * WN + wn) * (2 * P.Mpad);
+    // The block is persistent, so its statistics are too: per item the 16-lane rows are summed with DPP and the totals
+    // added into the block's LDS cells; ONE partial row per (block, wave) leaves for HBM at the very end (a few hundred
+    // rows per launch instead of one per pixel tile, so the column reduction behind it is nearly free).
+    float* cell = sSt + wave * 128 + g * 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
-        const int mrow = m0 + wm * 64 + m * 16 + g * 4 + r;
-        if (j == 15 && mrow < P.Mpad) {
-          row[mrow] = a1;
-          row[P.Mpad + mrow] = a2;
+        if (j == 15) {
+          cell[m * 16 + r] += a1;
+          cell[64 + m * 16 + r] += a2;
         }
       }
   }
@@ -400,6 +406,14 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   w0 = nw0;
   }
   gsd_dma_barrier();   // vmcnt(0): the last (unread) fill must have landed before the block gives its LDS back
+  if (P.partials != nullptr && lane < 64) {
+    float* row = P.partials + (size_t)((blockIdx.x / P.mblocks) * WN + wn) * (2 * P.Mpad);
+    const int mrow = m0 + wm * 64 + lane;
+    if (mrow < P.Mpad) {
+      row[mrow] = sSt[wave * 128 + lane];
+      row[P.Mpad + mrow] = sSt[wave * 128 + 64 + lane];
+    }
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -446,13 +460,17 @@ int cu_count() {
 }
 
 // items = (pixel tile, m-block) pairs; one persistent block per CU (the LDS image allows one), a multiple of mblocks
+long launch_grid(long items, int mblocks) {
+  long grid = cu_count() / mblocks * mblocks;
+  if (grid < mblocks) grid = mblocks;
+  return grid > items ? items : grid;
+}
+
 template <int MODE, int WM, int WN>
 int launch(GConvP& P, long items, size_t lds, hipStream_t st, const char* what) {
   GSD_REQUIRE(items > 0 && items < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: %ld work items out of range", what, items);
   P.nitems = (int)items;
-  long grid = cu_count() / P.mblocks * P.mblocks;
-  if (grid < P.mblocks) grid = P.mblocks;
-  if (grid > items) grid = items;
+  const long grid = launch_grid(items, P.mblocks);
   static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>),
@@ -477,7 +495,7 @@ extern "C" int gsd_bf16_conv_mpad(int M) { return M > 0 ? round_up(M, 128) : 0; 
 extern "C" int gsd_bf16_conv_partial_rows(int N, int H, int W, int M) {
   if (N <= 0 || H <= 0 || W <= 0 || M <= 0) return 0;
   const Plan p = make_plan(H, W, M);
-  return N * p.tiles_y * p.tiles_x * (p.wide ? 4 : 2);
+  return (int)(launch_grid((long)N * p.tiles_y * p.tiles_x * p.mblocks, p.mblocks) / p.mblocks) * (p.wide ? 4 : 2);
 }
 
 extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
@@ -515,7 +533,7 @@ extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nh
     P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
   }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * (pl.wide ? 16 : 10) * 4096 + (size_t)4 * pl.BM * sizeof(float);
+  const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * (pl.wide ? 16 : 10) * 4096 + (size_t)(4 * pl.BM + 512) * sizeof(float);
   if (pl.wide) return launch<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
   return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
 }
@@ -567,7 +585,7 @@ extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd
     P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
   }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96 + (size_t)4 * pl.BM * sizeof(float);
+  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96 + (size_t)(4 * pl.BM + 512) * sizeof(float);
   if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
   return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
 }

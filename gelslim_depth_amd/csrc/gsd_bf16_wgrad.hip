@@ -20,6 +20,8 @@
 // pixel tiles with fp32 slabs summed in a fixed order by gwgrad_reduce_kernel => bitwise reproducible.
 #include "gsd_bf16_common.h"
 
+#include <cstdlib>
+
 __device__ const uint4 gsd_zero16w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
 struct GWgradP {
@@ -274,7 +276,8 @@ WPlan make_wplan(bool halo, int T, int N, int H, int W, int M, int Ncols) {
   p.mblocks = ceil_div(M, p.BM);
   p.nblocks = ceil_div(Ncols, p.BNC);
   p.stages_total = N * p.tiles_y * p.tiles_x;
-  int splits = ceil_div(1024, p.mblocks * p.nblocks);   // ~2 resident blocks per CU x 256 CUs x 2 rounds
+  static const int target = getenv("GSD_BF16_WGRAD_BLOCKS") ? atoi(getenv("GSD_BF16_WGRAD_BLOCKS")) : 512;   // tuning knob
+  int splits = ceil_div(target, p.mblocks * p.nblocks);   // default: ONE round of 2 resident blocks per CU x 256 CUs (measured: 512 -> 866 TFLOP/s, 1024 -> 766, 256 -> 647 over the layer set; fewer splits also halve the slab traffic)
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits < 1) splits = 1;
   p.splits = splits;

@@ -493,7 +493,8 @@ WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
     p.stages_total = N * p.tiles_flat;
   }
   const int tiles = p.mblocks * p.nblocks;
-  int splits = ceil_div(mode == 0 ? 1024 : 1536, tiles);   // ~2 resident blocks per CU x 256 CUs x 2 rounds
+  static const int target3 = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;   // tuning knob (512: one round of 2 blocks/CU; 1024 measured 1 % slower end to end)
+  int splits = ceil_div(mode == 0 ? target3 : 1536, tiles);   // ~2 resident blocks per CU x 256 CUs x 2 rounds
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits > 2048) splits = 2048;
   if (splits < 1) splits = 1;

@@ -41,8 +41,9 @@ int gsd_bf16_conv_mpad(int M);
 
 /* conv3x3 p1 s1, no bias (unet.py:11,14; with a dgrad weight image the dX half of its backward):
  *   out[n,h,w,m] = sum_{t,k} in[n,h+t/3-1,w+t%3-1,k] * wt[t][m][k];  wt: [9][mpad(M)][K] bf16, K % 32 == 0, M % 16 == 0.
- * partials (or NULL): per-block BatchNorm partial sums of the STORED (rounded) values, gsd_bf16_conv_partial_rows rows of
- * 2*mpad(M) floats, to be reduced with gsd_bn_reduce_partials(partials, rows, mpad(M), M, ...) from gsd.h. */
+ * partials (or NULL): BatchNorm partial sums of the STORED (rounded) values, one row of 2*mpad(M) floats per (persistent
+ * block, wave): gsd_bf16_conv_partial_rows rows (a few hundred, it depends on the device's CU count), to be reduced
+ * with gsd_bn_reduce_partials(partials, rows, mpad(M), M, ...) from gsd.h. */
 int gsd_bf16_conv_partial_rows(int N, int H, int W, int M);
 int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
                      const gsd_bf16_bnbwd* bw, void* stream);
