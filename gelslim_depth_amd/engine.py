@@ -351,6 +351,8 @@ class UNetEngine:
             check(lib.gsd_convT2x2_dgrad(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
                   "convT2x2_dgrad")
             self._reduce(0, prev, st)
+            if self.block_done_cb is not None:
+                self.block_done_cb(f"dec{j}")      # up.{j}.* (and outc with the last decoder) are final
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
             if lvl < self.L:

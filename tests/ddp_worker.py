@@ -14,19 +14,20 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     outdir, mode = sys.argv[1], sys.argv[2]          # mode: "local_bn" | "sync_bn"
+    precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gelslim_depth_amd import synth
     from gelslim_depth_amd.models.unet import UNet
     from gelslim_depth_amd.train import TrainStep
-    dims = [16, 32, 64]
+    dims = [16, 32, 64] if precision == "fp32" else [32, 64, 128]
     # every rank starts from DIFFERENT weights: the rank-0 broadcast must fix that
     st = synth.make_state(3, 1, dims, 5 + 100 * rank, "conditioned")
     x, t = synth.make_batch(4, 37, 53, 6)            # global batch 4 -> 2 per rank
     per = 4 // world
     xs, ts = x[rank * per:(rank + 1) * per], t[rank * per:(rank + 1) * per]
-    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims)
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
     m = m.to("cuda:0").train()
     step = TrainStep(m, process_group=dist.group.WORLD, sync_bn=(mode == "sync_bn"), overlap_allreduce=True)

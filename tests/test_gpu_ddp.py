@@ -17,10 +17,10 @@ from gelslim_depth_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_two_ranks(tmp_path, mode):
+def run_two_ranks(tmp_path, mode, precision="fp32"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode]
+           "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode, precision]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
@@ -63,3 +63,27 @@ def test_two_rank_step_matches_oracle(tmp_path, mode):
     assert rel_l1(res[0]["g_sum"] / 2, g_exp) < 2e-2
     if p_exp is not None:
         assert rel_l1(res[0]["p1"], p_exp) < 1e-3
+
+
+def test_two_rank_bf16_step_is_the_sum_of_its_shards(tmp_path):
+    """bf16 engine under data parallelism (local BatchNorm statistics): every rank's kernels are deterministic, so the
+    all-reduced gradient arena must equal, bit for bit, the fp32 sum of two single-process bf16 steps on the two shards;
+    the replicas stay in lock-step and start from rank 0's weights."""
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    res = run_two_ranks(tmp_path, "local_bn", "bf16")
+    dims = [32, 64, 128]
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, t = synth.make_batch(4, 37, 53, 6)
+    assert np.array_equal(res[0]["g_sum"], res[1]["g_sum"]) and np.array_equal(res[0]["p1"], res[1]["p1"])
+    shards = []
+    for r in range(2):
+        m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision="bf16")
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st0.items()}, strict=True)
+        m = m.to("cuda").train()
+        step = TrainStep(m)
+        loss = float(step(torch.from_numpy(x[2 * r:2 * r + 2]).cuda(), torch.from_numpy(t[2 * r:2 * r + 2]).cuda()))
+        assert abs(loss - float(res[r]["loss"])) <= 1e-6 * abs(loss)
+        shards.append(step.g_flat.cpu().numpy())
+    assert np.array_equal(res[0]["g_sum"], shards[0] + shards[1])
