@@ -375,6 +375,111 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
     }
 }
 
+// ConvT2x2 dW, LDS-DMA form (default).  Same GEMM as convT_wgrad_kernel; both tiles go HBM/L2 -> LDS with
+// global_load_lds_dword (one instruction = one 64-pixel row of the image; the space-to-depth gather of dy and the
+// flat pixel -> (h, w) map live in the per-lane source address), one LDS image per block and two blocks per CU, so one
+// block's DMA issue + flight is covered by the other's MFMAs.  The deferred BatchNorm+ReLU of x is applied after the
+// ds_read (a lane owns four fixed input channels).  Measured against the register-staged kernel: see DESIGN.md.
+__global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradParams P) {
+  constexpr int MT = 4, NTB = 4, BMw = 128, BNw = 128, DS = 66;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Al = smem;
+  float* Bl = smem + BMw * DS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int per_split = P.mblocks * P.nblocks;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BMw, n0 = nb * BNw;
+  const int s_begin = (int)((long long)split * P.stages_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
+  const int HW = P.H * P.W;
+
+  float sc[NTB], sh[NTB], lo[NTB];
+#pragma unroll
+  for (int t = 0; t < NTB; ++t) {
+    const int c = n0 + wn * 64 + t * 16 + l16;
+    sc[t] = 1.f; sh[t] = 0.f; lo[t] = -__builtin_inff();
+    if (c < P.a0.C) {
+      if (P.a0.scale != nullptr) { sc[t] = P.a0.scale[c]; sh[t] = P.a0.shift[c]; }
+      if (P.a0.relu) lo[t] = 0.f;
+    }
+  }
+
+  f32x4 acc[MT][NTB];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = (wm * 64 + l16) * DS + j;
+  const int b_off = (wn * 64 + l16) * DS + j;
+  for (int stage = s_begin; stage < s_end; ++stage) {
+    const int n = stage / P.tiles_flat;
+    const int p = (stage - n * P.tiles_flat) * 64 + lane;
+    const bool pix_ok = p < HW;
+    const int h = pix_ok ? p / P.W : 0;
+    const int w = pix_ok ? p - h * P.W : 0;
+    __syncthreads();   // every wave has finished reading the previous stage's image
+    const float* abase = P.dy.p + (long long)n * P.dy.ns + (long long)(2 * h) * P.dy.W + 2 * w;
+#pragma unroll 4
+    for (int i = 0; i < BMw / 4; ++i) {
+      const int row = wave + 4 * i;           // m = (co, kh, kw)
+      const int m = m0 + row;
+      const float* gsrc = (pix_ok && m < P.M) ? abase + (long long)(m >> 2) * P.dy.cs + ((m >> 1) & 1) * P.dy.W + (m & 1) : &gsd_pad[0];
+      __builtin_amdgcn_global_load_lds(gsrc, Al + row * DS, 4, 0, 0);
+    }
+    const float* bbase = P.a0.p + (long long)n * P.a0.ns + p;
+#pragma unroll 4
+    for (int i = 0; i < BNw / 4; ++i) {
+      const int ch = wave + 4 * i;
+      const int c = n0 + ch;
+      const float* gsrc = (pix_ok && c < P.a0.C) ? bbase + (long long)c * P.a0.cs : &gsd_pad[0];
+      __builtin_amdgcn_global_load_lds(gsrc, Bl + ch * DS, 4, 0, 0);
+    }
+    gsd_dma_barrier();   // vmcnt(0) + barrier: the image is complete
+    float an[MT], bn[NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DS];
+    for (int s = 0; s < 16; ++s) {
+      float a[MT], b[NTB];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = an[m];
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) b[t] = fmaxf(fmaf(bn[t], sc[t], sh[t]), lo[t]);
+      const int sn = s + 1 < 16 ? s + 1 : s;   // next k-step's operands before this k-step's MFMAs
+#pragma unroll
+      for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS + 4 * sn];
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DS + 4 * sn];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int mr = m0 + wm * 64 + m * 16 + j * 4 + reg;
+      if (mr < P.M) {
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+          const int col = n0 + wn * 64 + t * 16 + l16;
+          if (col < P.Ncols) P.slabs[((size_t)split * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
+        }
+      }
+    }
+}
+
 // Sum the slabs in split order and write the reference layout.
 //   MODE 0: slab[split][tap][co][ci] -> dW[co][ci][tap]
 //   MODE 1: slab[split][m][ci]       -> dW[ci][m]          (m = co*4+kh*2+kw)
@@ -494,7 +599,7 @@ WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
   }
   const int tiles = p.mblocks * p.nblocks;
   static const int target3 = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;   // tuning knob (512: one round of 2 blocks/CU; 1024 measured 1 % slower end to end)
-  int splits = ceil_div(mode == 0 ? target3 : 1536, tiles);   // ~2 resident blocks per CU x 256 CUs x 2 rounds
+  int splits = ceil_div(target3, tiles);   // one round of 2 resident blocks per CU x 256 CUs
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits > 2048) splits = 2048;
   if (splits < 1) splits = 1;
@@ -648,8 +753,24 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   const size_t lds = (size_t)(pl.BMw * 66 + pl.BNw * 66) * sizeof(float);
-  int rc = pl.wide ? launch_convT_wgrad<1, 4>(P, grid, lds, (hipStream_t)stream)
-                   : launch_convT_wgrad<2, 2>(P, grid, lds, (hipStream_t)stream);
+  int rc;
+  if (pl.wide) {   // M = 4*Cout <= 64: never the case for this network; the register-staged kernel keeps it working
+    rc = launch_convT_wgrad<1, 4>(P, grid, lds, (hipStream_t)stream);
+  } else {
+    static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wgrad_dma_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return GSD_ERR_HIP;
+      }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(convT_wgrad_dma_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");
+    rc = GSD_OK;
+  }
   if (rc) return rc;
   const long long per = (long long)M * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
