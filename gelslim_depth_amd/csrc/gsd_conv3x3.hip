@@ -194,23 +194,37 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
     const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
     const bool more = chunk + 1 < P.nchunks;
     const float* Wc = smem + cur * BUF;
+    // Software pipeline over the 9 k-steps of the chunk: the operands of k-step s+1 are read while k-step s multiplies,
+    // and the order is PINNED (sched_barrier): left alone, hipcc sinks every ds_read to just before its first use and puts
+    // s_waitcnt lgkmcnt(0) in front of each k-step's MFMAs, i.e. every wave eats the LDS latency once per 16 MFMAs.
+    f32x4 av[2];
+    float br[2][NT];
+    av[0] = *reinterpret_cast<const f32x4*>(&Wc[(j * 9) * WS + a_lane]);   // out channels m*16+l16, m = 0..3
+#pragma unroll
+    for (int t = 0; t < NT; ++t) br[0][t] = Wc[baddr[t]];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
-      const int koff = (s / 3) * P.WC + (s % 3);
-      const int arow = j * 9 + s;
-      float a[MT], b[NT];
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&Wc[arow * WS + a_lane]);   // out channels m*16+l16, m = 0..3
+      const int cs = s & 1, ns = cs ^ 1;
+      const int koff_n = ((s + 1) / 3) * P.WC + ((s + 1) % 3);
+      float b[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = av[m];
+      for (int t = 0; t < NT; ++t) b[t] = fmaxf(fmaf(br[cs][t], sc, sh), lo);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = fmaxf(fmaf(Wc[baddr[t] + koff], sc, sh), lo);
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(av[cs][m], b[t], acc[m][t]);
+        if (s + 1 < 9) {
+          if (m == 0) av[ns] = *reinterpret_cast<const f32x4*>(&Wc[(j * 9 + s + 1) * WS + a_lane]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(a[m], b[t], acc[m][t]);
-      if (more && s < 5) {   // two slots behind each of the first five k-steps: the last four cover the DMA's flight
-        dma_slot(2 * s, chunk + 1, cur ^ 1);
-        dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+          for (int t = 0; t < NT; ++t)
+            if (m >= 1 && (t * 3) / NT == m - 1) br[ns][t] = Wc[baddr[t] + koff_n];
+        }
+        if (m == MT - 1 && more && s < 5) {   // two DMA slots behind each of the first five k-steps: the last four cover the flight
+          dma_slot(2 * s, chunk + 1, cur ^ 1);
+          dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
