@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the metric's arithmetic (BASELINE configs[1-3], default); bf16: mixed precision, configs[4]")
+    ap.add_argument("--graph", action="store_true", help="--workload infer only: replay the forward as one hipGraph")
     ap.add_argument("--workload", choices=["train", "infer"], default="train",
                     help="train: BASELINE configs[2] (the metric, default); infer: configs[1], eval-mode forward only")
     args = ap.parse_args()
@@ -132,10 +133,16 @@ def main():
 
     if args.workload == "infer":
         model.eval()
+        if args.graph:
+            from gelslim_depth_amd.graph import GraphedInference
+            graphed = GraphedInference(model, x)
 
-        def one_step():
-            with torch.no_grad():
-                model(x=x)
+            def one_step():
+                graphed(x)
+        else:
+            def one_step():
+                with torch.no_grad():
+                    model(x=x)
     else:
         def one_step():
             step(x, tgt)

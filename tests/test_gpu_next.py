@@ -88,3 +88,27 @@ def test_predict_depth_pipeline_and_ema_eval_and_checkpoint(tmp_path):
     st_ema = dict(net.s)
     st_ema.update(shadow)
     assert rel_l1(y_ema.cpu().numpy(), on.UNetOracle(st_ema).forward(xb, train=False)) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_inference_equals_eager_and_follows_weight_updates(precision):
+    """hipGraph replay of the eval forward: bit-identical to the eager schedule, and it re-reads the parameters."""
+    from gelslim_depth_amd.graph import GraphedInference
+    from gelslim_depth_amd.models.unet import UNet
+    dims = [32, 64, 128]
+    st = synth.make_state(3, 1, dims, 31, "conditioned")
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").eval()
+    rng = np.random.default_rng(2)
+    x1 = torch.from_numpy(rng.random((2, 3, 40, 53)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.random((2, 3, 40, 53)).astype(np.float32)).cuda()
+    fn = GraphedInference(m, x1)
+    with torch.no_grad():
+        for x in (x1, x2, x1):
+            assert torch.equal(fn(x), m(x=x))
+        for p in m.parameters():                      # in-place update, as an optimiser step does
+            p.mul_(1.01)
+        assert torch.equal(fn(x2), m(x=x2))
+    with pytest.raises(RuntimeError):
+        fn(torch.zeros((1, 3, 40, 53), device="cuda"))
