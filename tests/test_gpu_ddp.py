@@ -87,3 +87,29 @@ def test_two_rank_bf16_step_is_the_sum_of_its_shards(tmp_path):
         assert abs(loss - float(res[r]["loss"])) <= 1e-6 * abs(loss)
         shards.append(step.g_flat.cpu().numpy())
     assert np.array_equal(res[0]["g_sum"], shards[0] + shards[1])
+
+
+def test_two_rank_bf16_syncbn_matches_single_process_global_batch(tmp_path):
+    """bf16 + SyncBN: two ranks with all-reduced BatchNorm sums == one process on the whole batch, up to the rounding
+    noise of a different summation split (statistics agree to fp64 round-off, so only isolated bf16 roundings flip)."""
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    res = run_two_ranks(tmp_path, "sync_bn", "bf16")
+    dims = [32, 64, 128]
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, t = synth.make_batch(4, 37, 53, 6)
+    assert np.array_equal(res[0]["p1"], res[1]["p1"])
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st0.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m)
+    loss = float(step(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()))
+    g1 = step.g_flat.cpu().numpy()
+    g2 = res[0]["g_sum"] / 2.0          # each rank's loss is the mean over ITS half: the sum is twice the global-mean gradient
+    assert abs(0.5 * (float(res[0]["loss"]) + float(res[1]["loss"])) - loss) <= 2e-3 * abs(loss)
+    cos = float(g1.astype(np.float64) @ g2.astype(np.float64) / np.sqrt((g1.astype(np.float64) ** 2).sum() * (g2.astype(np.float64) ** 2).sum()))
+    assert cos > 0.995, cos
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_l1(res[0]["buf/" + k], v.cpu().numpy()) < 1e-3, k
