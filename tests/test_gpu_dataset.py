@@ -119,3 +119,46 @@ def test_train_epoch_from_device_dataset():
         ref_total += float(tr.step(xs, ts))
     assert nb == 3
     assert abs(total - ref_total) <= 1e-3 * abs(ref_total)
+
+
+def test_fit_two_epochs_end_to_end(tmp_path):
+    """harness.fit on the device-resident dataset: train pass, EMA-weights validation/test passes, best-validation
+    checkpoint in the reference layout, reference log lines; the validation loss equals the oracle's evaluation of the
+    saved checkpoint on the same batches."""
+    from gelslim_depth_amd import harness
+    from gelslim_depth_amd.dataset import DeviceDataset, DeviceLoader
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    from oracle import dataset_ref as dr
+    from oracle import torch_cpu_path as ot
+    kw = dict(use_difference_image=True, image_normalization_method="0_255_to_0_1",
+              depth_normalization_method="min_max_to_0_-1", norm_scale=0.9)
+    dims = [8, 16, 32]
+    st = synth.make_state(3, 1, dims, 4, "conditioned")
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse")
+    train_ds = DeviceDataset(objects=dr.synthetic_objects(41, [3, 3], h=42, w=54), device="cuda", **kw)
+    val_objs = dr.synthetic_objects(42, [2], h=42, w=54)
+    val_ds = DeviceDataset(objects=val_objs, device="cuda", depth_normalization_parameters=train_ds.depth_normalization_parameters, **kw)
+    lines = []
+    torch.manual_seed(0)
+    H = harness.fit(step, DeviceLoader(train_ds, 4, shuffle=True), DeviceLoader(val_ds, 4), DeviceLoader(val_ds, 2),
+                    str(tmp_path / "weights"), "unet_t", loss_values_path=str(tmp_path / "loss.txt"), train_indefinitely=True,
+                    max_epochs=2, echo=lines.append)
+    assert len(H["train_loss"]) == 2 and all(np.isfinite(v) for k in H for v in H[k])
+    assert lines[0] == "Validation loss is at a minimum. Saving the model" and lines[1] == "[INFO] EPOCH: 1"
+    assert lines[2] == "Train loss: {:.6f},  Validation loss: {:.6f}, Test loss: {:.6f}".format(
+        H["train_loss"][0], H["validation_loss"][0], H["test_loss"][0])
+    assert lines[-2] == "Training complete"
+    # the checkpoint is the EMA-swapped reference layout: evaluate it with the oracle on the validation set
+    sd = torch.load(tmp_path / "weights" / "unet_t.pth")
+    assert len(sd) == len(m.state_dict())
+    ref_ds = dr.DatasetOracle(val_objs, depth_normalization_parameters=train_ds.depth_normalization_parameters, **kw)
+    xs = torch.stack([ref_ds[i]["tactile_image"] for i in range(len(ref_ds))])
+    ts = torch.stack([ref_ds[i]["depth_image"] for i in range(len(ref_ds))])
+    with torch.no_grad():
+        out = ot.forward({k: v.clone() for k, v in sd.items()}, xs, train=False)
+    best = int(np.argmin(H["validation_loss"]))
+    assert abs(float(((out - ts) ** 2).mean()) - H["validation_loss"][best]) <= 1e-4 * H["validation_loss"][best]
