@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void channel_sums_stage2(const float* __restri
   if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-int pick_pixb(int N, int HW) {
-  long long pixb = ((long long)N * HW + 2047) / 2048;
+int pick_pixb(int N, int HW, int target_blocks = 2048) {
+  long long pixb = ((long long)N * HW + target_blocks - 1) / target_blocks;
   pixb = (pixb + 31) / 32 * 32;
   return (int)(pixb < 32 ? 32 : pixb);
 }
@@ -477,7 +477,7 @@ extern "C" int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, cons
 
 extern "C" int64_t gsd_bf16_channel_sums_workspace(int N, int hh, int ww, int C) {
   if (N <= 0 || hh <= 0 || ww <= 0 || C <= 0) return 0;
-  return (int64_t)N * ceil_div(hh * ww, pick_pixb(N, hh * ww)) * C;
+  return (int64_t)N * ceil_div(hh * ww, pick_pixb(N, hh * ww, 512)) * C;
 }
 
 extern "C" int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, int ww, float* out, float* workspace,
@@ -487,7 +487,7 @@ extern "C" int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, 
               "gsd_bf16_channel_sums: window (%d,%d)+(%d,%d) outside (%d,%d)", y0, x0, hh, ww, t->H, t->W);
   GSD_REQUIRE(t->N <= 65535 && (t->C <= 2048 || t->C % 2048 == 0), GSD_ERR_UNSUPPORTED,
               "gsd_bf16_channel_sums: N must be <= 65535 and C <= 2048 or a multiple of 2048");
-  const int pixb = pick_pixb(t->N, hh * ww), chunks = ceil_div(hh * ww, pixb);
+  const int pixb = pick_pixb(t->N, hh * ww, 512), chunks = ceil_div(hh * ww, pixb);   // 512 partial rows: stage 2 stays short
   GSD_REQUIRE(workspace_elems >= (int64_t)t->N * chunks * t->C, GSD_ERR_WORKSPACE, "gsd_bf16_channel_sums: workspace too small");
   hipLaunchKernelGGL(channel_sums_stage1, dim3(chunks, t->N), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream, to_nhwc(*t),
                      y0, x0, hh, ww, pixb, chunks, workspace);
