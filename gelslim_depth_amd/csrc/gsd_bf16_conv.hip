@@ -50,10 +50,15 @@ template <int MODE, int WM, int WN>
 __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   constexpr int BM = WM * 64, NPX = WN * 128;
   constexpr int MT = 4, NT = 8;
-  constexpr int NTAPI = MODE == 0 ? 3 : 1;          // taps (k-steps) per barrier
+  // k-steps per barrier: MODE 0 the 3 taps of a kernel row; MODE 1 NSUB consecutive 32-channel sub-chunks of one tap
+  // (two for the 128 x 256 tile: half the barriers and twice the lead time of every fill; the 64 x 512 tile has no LDS
+  // for a second activation plane and is only used by the first layer, K = 32)
+  constexpr int NSUB = (MODE == 1 && WN == 2) ? 2 : 1;
+  constexpr int NTAPI = MODE == 0 ? 3 : NSUB;
   constexpr int WBUF = NTAPI * BM * 64;             // bytes of one weight image
   constexpr int NWI = NTAPI * BM / 16 / 4;          // weight DMA instructions per wave per iteration
-  constexpr int MAXX = MODE == 0 ? (WN == 2 ? 10 : 16) : NPX * 3 / 32 / 4;   // activation DMA instructions per wave
+  constexpr int XPP = NPX * 3 / 32 / 4;             // MODE 1: activation DMA instructions per wave and plane
+  constexpr int MAXX = MODE == 0 ? (WN == 2 ? 10 : 16) : NSUB * XPP;   // activation DMA instructions per wave
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int XBUF = MAXX * 4096;   // every DMA instruction moves a whole 1 KiB piece (pad and slack lanes carry zeros)
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     const int tapk = idx / (BM * 4);
     const int row = (idx >> 2) % BM;
     const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
-    woff[k] = (tapk * P.Mpad + m0 + row) * P.K + gg * 8;
+    woff[k] = MODE == 0 ? (tapk * P.Mpad + m0 + row) * P.K + gg * 8 : (m0 + row) * P.K + tapk * 32 + gg * 8;
   }
   // activations, tile-invariant part: (y << 16 | x << 4 | slot) of this lane's 16-byte piece -- halo position (MODE 0) or
   // tile pixel (MODE 1) -- or -2: a pad / slack piece.  Those are filled from the zero line like out-of-image pixels:
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   int xpk[MAXX];
 #pragma unroll
   for (int k = 0; k < MAXX; ++k) {
-    const int o = (k * 4 + wave) * 1024 + lane * 16;
+    const int o = ((MODE == 0 ? k : k % XPP) * 4 + wave) * 1024 + lane * 16;
     const int px = o / 96, slot = (o - px * 96) >> 4;
     const int rowlen = MODE == 0 ? P.HC : P.TW;
     int v = -2;
@@ -149,9 +154,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       chunk = it / 3;
       tap0 = (it - chunk * 3) * 3;
     } else {
-      const int nch = P.K >> 5;
+      const int nch = (P.K >> 5) / NSUB;      // iterations per tap
       tap0 = it / nch;
-      chunk = it - tap0 * nch;
+      chunk = (it - tap0 * nch) * NSUB;       // first 32-channel chunk of the iteration
     }
     if (slot < NWI) {
       const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
@@ -168,9 +173,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       if (xoff[k] >= 0) {
         const int hi = P.stride * (h0 + (xoff[k] >> 16)) + P.ty[tap0], wi = P.stride * (w0 + ((xoff[k] >> 4) & 0xfff)) + P.tx[tap0];
         if ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win)
-          sp = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (xoff[k] & 15) * 8);
+          sp = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (k / XPP) * 32 + (xoff[k] & 15) * 8);
       }
-      __builtin_amdgcn_global_load_lds(sp, Xl + (git & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(sp, Xl + (git & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);   // plane k / XPP
     }
   };
   // slots of one iteration: the weights always; the activations with every iteration (MODE 1) or with a chunk's first
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
   }
 
-  const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * (P.K >> 5);
+  const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * ((P.K >> 5) / NSUB);
   int item = blockIdx.x;
   if (item >= P.nitems) return;
   int n, h0, w0, git = 0;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         acc[m][t + 1] = mfma_bf16(a[kw & 1][m], b[kw & 1][t + 1], acc[m][t + 1]);
         if (kw + 1 < NTAPI) {
           if (i < MT) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + i * 1024);
-          else if (i < MT + NT) b[(kw + 1) & 1][i - MT] = *reinterpret_cast<const u32x4*>(Xc + boff[i - MT] + (kw + 1) * 96);
+          else if (i < MT + NT) b[(kw + 1) & 1][i - MT] = *reinterpret_cast<const u32x4*>(Xc + boff[i - MT] + (kw + 1) * (MODE == 0 ? 96 : NPX * 96));
         }
         if (i < SPT && kw * SPT + i < NS) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
         __builtin_amdgcn_sched_barrier(0);
@@ -585,7 +590,9 @@ extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd
     P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
   }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
-  const size_t lds = (size_t)2 * pl.BM * 64 + (size_t)2 * pl.NPX * 96 + (size_t)(4 * pl.BM + 512) * sizeof(float);
+  const int nsub = pl.wide ? 1 : 2;   // k-steps per barrier (kernel: NSUB)
+  GSD_REQUIRE(K % (32 * nsub) == 0, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv_dense: K=%d must be a multiple of 64 when M > 64", K);
+  const size_t lds = (size_t)2 * nsub * pl.BM * 64 + (size_t)2 * nsub * pl.NPX * 96 + (size_t)(4 * pl.BM + 512) * sizeof(float);
   if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
   return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
 }
