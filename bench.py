@@ -97,8 +97,11 @@ def main():
     pg = None
     if world > 1 or os.environ.get("GSD_FORCE_SYNC"):
         import torch.distributed as dist
+        # keep stdout to the ONE JSON line: RCCL writes its version banner (NCCL_DEBUG=VERSION is exported in this image) and
+        # its warnings to stdout; send whatever it has to say to stderr instead
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"      # keep stdout to the ONE JSON line (RCCL prints its version banner there)
+            del os.environ["NCCL_DEBUG"]
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0")
