@@ -92,6 +92,8 @@ SIGNATURES = {
     "gsd_bf16_conv_partial_rows": (_I, [_I, _I, _I, _I]),
     "gsd_bf16_conv3x3": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _BNBWD, _P]),
     "gsd_bf16_conv_dense": (_I, [_NHWC, _P, _NHWC, _I, _I, _I, _I, _IP, _IP, _I, _I, _I, _I, _I, _P, _P, _BNBWD, _P]),
+    "gsd_bf16_conv3x3_bnrelu": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P, _P]),
+    "gsd_bf16_conv1x1_bnrelu": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P, _P]),
     "gsd_bf16_weight_image_size": (_L, [_I, _I, _I]),
     "gsd_bf16_weight_image": (_I, [_I, _P, _I, _I, _P, _P]),
     "gsd_bf16_im2col3x3": (_I, [_P, _I, _I, _I, _I, _NHWC, _P]),

@@ -41,6 +41,9 @@ struct GConvP {
   float* partials;
   // fused BatchNorm+ReLU backward pass 1 (dX launches): out receives dz = dX where relu(bn(bw_y)) > 0, partials the sums
   // of dz and dz*xhat.  bw_y has out's geometry (pitch bw_pitch).
+  // eval-mode fusion: out = relu(acc * ep_scale[m] + ep_shift[m]) (BatchNorm with running statistics folded into the
+  // coefficients + ReLU in the epilogue: the raw convolution output is never stored)
+  const float* ep_scale; const float* ep_shift;
   const u16* bw_y;
   long long bw_pitch;
   const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_invstd;
@@ -88,6 +91,13 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   };
   if (P.partials != nullptr) {   // each (wave, row) cell is only ever touched by one lane: no synchronisation needed
     for (int c = tid; c < 4 * 2 * 64; c += 256) sSt[c] = 0.f;
+  }
+  if (P.ep_scale != nullptr) {   // shares the coefficient cells with the fused dX mode (they exclude each other)
+    for (int c = tid; c < BM; c += 256) {
+      const int co = m0 + c < P.M ? m0 + c : 0;
+      sBw[c] = P.ep_scale[co];
+      sBw[BM + c] = P.ep_shift[co];
+    }
   }
   if (P.bw_y != nullptr) {   // visible to everyone after the first barrier of the K loop
     for (int c = tid; c < BM; c += 256) {
@@ -370,8 +380,15 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       const int mrow = m0 + wm * 64 + m * 16 + g * 4;
       if (mrow < P.M) {
         const int ho = sm * h + qy[m], wo = sm * w + qx[m];
-        const unsigned lo = pack_bf16(acc[m][t][0], acc[m][t][1]);
-        const unsigned hi = pack_bf16(acc[m][t][2], acc[m][t][3]);
+        f32x4 v = acc[m][t];
+        if (P.ep_scale != nullptr) {
+          const int cl = wm * 64 + m * 16 + g * 4;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+        }
+        const unsigned lo = pack_bf16(v[0], v[1]);
+        const unsigned hi = pack_bf16(v[2], v[3]);
         if (pix_ok) {
           u16* o = P.out + ((long long)(n * P.Hob + ho) * P.Wob + wo) * P.out_pitch + co_m[m];
           *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
@@ -503,8 +520,8 @@ extern "C" int gsd_bf16_conv_partial_rows(int N, int H, int W, int M) {
   return (int)(launch_grid((long)N * p.tiles_y * p.tiles_x * p.mblocks, p.mblocks) / p.mblocks) * (p.wide ? 4 : 2);
 }
 
-extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
-                                const gsd_bf16_bnbwd* bw, void* stream) {
+static int conv3x3_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
+                        const gsd_bf16_bnbwd* bw, const float* ep_scale, const float* ep_shift, void* stream) {
   if (int e = gsd_check_nhwc(in, "gsd_bf16_conv3x3 in")) return e;
   if (int e = gsd_check_nhwc(out, "gsd_bf16_conv3x3 out")) return e;
   GSD_REQUIRE(wt != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3: null weights");
@@ -527,6 +544,7 @@ extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nh
   P.Cs = 0; P.oy = P.ox = 0;
   P.bias = nullptr;
   P.partials = partials;
+  P.ep_scale = ep_scale; P.ep_shift = ep_shift;
   P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
   if (bw != nullptr) {
     if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv3x3 bw.y")) return e;
@@ -543,9 +561,9 @@ extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nh
   return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
 }
 
-extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
-                                   const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
-                                   float* partials, const gsd_bf16_bnbwd* bw, void* stream) {
+static int conv_dense_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
+                           const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
+                           float* partials, const gsd_bf16_bnbwd* bw, const float* ep_scale, const float* ep_shift, void* stream) {
   if (int e = gsd_check_nhwc(in, "gsd_bf16_conv_dense in")) return e;
   if (int e = gsd_check_nhwc(out, "gsd_bf16_conv_dense out")) return e;
   GSD_REQUIRE(wt != nullptr && ty != nullptr && tx != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: null argument");
@@ -578,6 +596,7 @@ extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd
   P.Cs = scatter_cs; P.oy = oy; P.ox = ox;
   P.bias = bias;
   P.partials = partials;
+  P.ep_scale = ep_scale; P.ep_shift = ep_shift;
   P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
   if (bw != nullptr) {
     if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv_dense bw.y")) return e;
@@ -595,4 +614,28 @@ extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd
   const size_t lds = (size_t)2 * nsub * pl.BM * 64 + (size_t)2 * nsub * pl.NPX * 96 + (size_t)(4 * pl.BM + 512) * sizeof(float);
   if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
   return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
+}
+
+extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
+                                const gsd_bf16_bnbwd* bw, void* stream) {
+  return conv3x3_impl(in, wt, out, K, M, partials, bw, nullptr, nullptr, stream);
+}
+
+extern "C" int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
+                                   const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
+                                   float* partials, const gsd_bf16_bnbwd* bw, void* stream) {
+  return conv_dense_impl(in, wt, out, K, M, ntaps, stride, ty, tx, H, W, scatter_cs, oy, ox, bias, partials, bw, nullptr, nullptr, stream);
+}
+
+extern "C" int gsd_bf16_conv3x3_bnrelu(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, const float* scale,
+                                       const float* shift, void* stream) {
+  GSD_REQUIRE(scale && shift, GSD_ERR_BAD_ARG, "gsd_bf16_conv3x3_bnrelu: null coefficients");
+  return conv3x3_impl(in, wt, out, K, M, nullptr, nullptr, scale, shift, stream);
+}
+
+extern "C" int gsd_bf16_conv1x1_bnrelu(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, const float* scale,
+                                       const float* shift, void* stream) {
+  GSD_REQUIRE(scale && shift && in && out, GSD_ERR_BAD_ARG, "gsd_bf16_conv1x1_bnrelu: null argument");
+  const int z = 0;
+  return conv_dense_impl(in, wt, out, K, M, 1, 1, &z, &z, out->H, out->W, 0, 0, 0, nullptr, nullptr, nullptr, scale, shift, stream);
 }

@@ -192,7 +192,24 @@ class UNetEngineBF16:
         u.src = src
         din = L.make_nhwc(*src)
         dy = L.make_nhwc(u.y)
-        part = self.partials.data_ptr() if train else None
+        part = self.partials.data_ptr()
+        if not train:
+            # eval: BatchNorm uses the running statistics, known before the convolution -> conv + BN + ReLU in ONE kernel,
+            # straight into the activation (no raw output, no separate apply pass)
+            check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
+                                         P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_eval_coeffs")
+            if u.first:
+                check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                check(lib.gsd_bf16_conv1x1_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), src[2], u.cout, u.scale.data_ptr(),
+                                                  u.shift.data_ptr(), st), "conv1x1_bnrelu")
+            else:
+                check(lib.gsd_bf16_weight_image(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+                check(lib.gsd_bf16_conv3x3_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), u.cin, u.cout, u.scale.data_ptr(),
+                                                  u.shift.data_ptr(), st), "conv3x3_bnrelu")
+                done()
+            return
         if u.first:
             check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
             z = L.int_array([0])
@@ -205,23 +222,18 @@ class UNetEngineBF16:
             done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
             check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
-        if train:
-            rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
-            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
-                                             u.sums.data_ptr(), st), "bn_reduce_partials")
-            count = float(n * lh * lw)
-            if self.sync_fn is not None:
-                self.sync_fn(u.sums[:2 * u.cout])
-                count *= self.world
-            check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
-                                      BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
-                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
-                  "bn_finalize")
-            P[u.nbtname].add_(1)
-        else:
-            check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
-                                         P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
-                  "bn_eval_coeffs")
+        rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
+        check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
+                                         u.sums.data_ptr(), st), "bn_reduce_partials")
+        count = float(n * lh * lw)
+        if self.sync_fn is not None:
+            self.sync_fn(u.sums[:2 * u.cout])
+            count *= self.world
+        check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
+                                  BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
+                                  u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+              "bn_finalize")
+        P[u.nbtname].add_(1)
         check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
 
     # ------------------------------------------------------------------ forward

@@ -48,6 +48,15 @@ int gsd_bf16_conv_partial_rows(int N, int H, int W, int M);
 int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,
                      const gsd_bf16_bnbwd* bw, void* stream);
 
+/* Eval-mode "3x3 conv + BatchNorm + ReLU" in one kernel (unet.py:11-13 / :14-16 under model.eval()): scale/shift are the
+ * running-statistics coefficients from gsd_bn_eval_coeffs; out = relu(conv3x3(in) * scale[m] + shift[m]) is written
+ * directly (the raw convolution output is never stored).  gsd_bf16_conv1x1_bnrelu is the same for the first layer on
+ * the im2col'd input. */
+int gsd_bf16_conv3x3_bnrelu(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, const float* scale,
+                            const float* shift, void* stream);
+int gsd_bf16_conv1x1_bnrelu(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, const float* scale,
+                            const float* shift, void* stream);
+
 /* Taps without spatial reuse on an (N,H,W) pixel grid:
  *   acc[n,h,w,m] = sum_{t<ntaps} sum_k in[n, stride*h+ty[t], stride*w+tx[t], k] * wt[t][m][k]   (zeros outside in)
  * scatter_cs == 0: out[n,h,w,m] = acc (+ bias[m]).   -- 1x1 convolution (first layer after gsd_bf16_im2col3x3)

@@ -387,3 +387,21 @@ def test_conv3x3_dgrad_fused_bn_bwd_bf16():
     sa, sb = part.double().sum(dim=0).cpu(), part_b.double().sum(dim=0).cpu()
     assert torch.allclose(sa[:cin], sb[:cin], rtol=1e-5, atol=1e-4)
     assert torch.allclose(sa[mp:mp + cin], sb[cin:2 * cin], rtol=1e-5, atol=1e-4)
+
+
+def test_conv3x3_bnrelu_fused_eval_bf16():
+    """Eval-mode conv + BatchNorm + ReLU in one kernel == conv, then gsd_bf16_bn_apply, up to one rounding (the fused
+    form never rounds the raw conv output to bf16)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(15)
+    n, h, w, k, m = 2, 18, 29, 64, 96
+    x = bf16r(torch.randn((n, k, h, w), generator=g))
+    wt = bf16r(torch.randn((m, k, 3, 3), generator=g) / (3.0 * k ** 0.5))
+    scale, shift = torch.rand((m,), generator=g) + 0.5, 0.3 * torch.randn((m,), generator=g)
+    ref = torch.relu(F.conv2d(x.double(), wt.double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    xin, out = to_nhwc(x), torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    img = weight_image(wt.permute(2, 3, 0, 1).reshape(9, m, k))
+    sc_d, sh_d = scale.cuda(), shift.cuda()
+    L.check(L.lib.gsd_bf16_conv3x3_bnrelu(C.byref(L.make_nhwc(xin)), img.data_ptr(), C.byref(L.make_nhwc(out)), k, m, sc_d.data_ptr(),
+                                          sh_d.data_ptr(), L.stream_ptr()), "conv_bnrelu")
+    assert_close_bf16(from_nhwc(out, 0, m), ref, "conv3x3+bn+relu")
