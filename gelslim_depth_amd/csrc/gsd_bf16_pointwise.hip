@@ -270,6 +270,101 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const BnBwdB P)
   }
 }
 
+// Pool mode, one 2x2 window per (thread, 8-channel group): the four activations of a window are read ONCE (the per-pixel
+// form above reads each window four times), the arg-max is taken once, and the four dz are written from the same
+// thread.  With odd H / W the last row / column belongs to no window (floor pooling): the threads of the last window
+// row / column also carry those pixels, which only see the direct gradient g.
+// grid (chunks over the Hp*Wp windows, N); same partial-row layout and count as bn_bwd_reduce_bf16_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_bf16_kernel(const BnBwdB P) {
+  extern __shared__ float red[];   // [256][16]
+  const int C = P.y.C, groups = C >> 3;
+  const int tpp = groups < 256 ? groups : 256, ppi = 256 / tpp;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int H = P.y.H, W = P.y.W, Hp = P.dpool.H, Wp = P.dpool.W;
+  const int pl = threadIdx.x / tpp, gl = threadIdx.x - pl * tpp;
+  const int p_end = min((chunk + 1) * P.pixb, Hp * Wp);
+  for (int gk = gl; gk < groups; gk += tpp) {
+    float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = P.scale[gk * 8 + i]; sh[i] = P.shift[gk * 8 + i]; mu[i] = P.mean[gk * 8 + i]; is[i] = P.invstd[gk * 8 + i];
+      s1[i] = s2[i] = 0.f;
+    }
+    auto one_pixel = [&](int h, int w, const float* add) {   // dz of pixel (h, w); add: pooled gradient routed here, or null
+      const long long pix = ((long long)n * H + h) * W + w;
+      float yv[8], gv[8], dzv[8];
+      unpack8(ld16(P.y.p + pix * P.y.pitch + gk * 8), yv);
+      unpack8(ld16(P.g.p + pix * P.g.pitch + gk * 8), gv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float gsum = add != nullptr ? gv[i] + add[i] : gv[i];
+        dzv[i] = fmaf(yv[i], sc[i], sh[i]) > 0.f ? gsum : 0.f;
+      }
+      const uint4 packed = pack8(dzv);
+      st16(P.dz.p + pix * P.dz.pitch + gk * 8, packed);
+      float dq[8];
+      unpack8(packed, dq);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s1[i] += dq[i];
+        s2[i] = fmaf(dq[i], (yv[i] - mu[i]) * is[i], s2[i]);
+      }
+    };
+    for (int p = chunk * P.pixb + pl; p < p_end && pl < ppi; p += ppi) {
+      const int hp = p / Wp, wp = p - hp * Wp;
+      const u16* wb = P.a.p + (((long long)n * P.a.H + 2 * hp) * P.a.W + 2 * wp) * P.a.pitch + gk * 8;
+      float a0[8], a1[8], a2[8], a3[8], dp[8], r0[8], r1[8], r2[8], r3[8];
+      unpack8(ld16(wb), a0);
+      unpack8(ld16(wb + P.a.pitch), a1);
+      unpack8(ld16(wb + (long long)P.a.W * P.a.pitch), a2);
+      unpack8(ld16(wb + (long long)(P.a.W + 1) * P.a.pitch), a3);
+      unpack8(ld16(P.dpool.p + (((long long)n * Hp + hp) * Wp + wp) * P.dpool.pitch + gk * 8), dp);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // first maximum in (0,0),(0,1),(1,0),(1,1) order wins
+        float best = a0[i];
+        int bi = 0;
+        if (a1[i] > best) { best = a1[i]; bi = 1; }
+        if (a2[i] > best) { best = a2[i]; bi = 2; }
+        if (a3[i] > best) { best = a3[i]; bi = 3; }
+        r0[i] = bi == 0 ? dp[i] : 0.f;
+        r1[i] = bi == 1 ? dp[i] : 0.f;
+        r2[i] = bi == 2 ? dp[i] : 0.f;
+        r3[i] = bi == 3 ? dp[i] : 0.f;
+      }
+      one_pixel(2 * hp, 2 * wp, r0);
+      one_pixel(2 * hp, 2 * wp + 1, r1);
+      one_pixel(2 * hp + 1, 2 * wp, r2);
+      one_pixel(2 * hp + 1, 2 * wp + 1, r3);
+      const bool xcol = wp == Wp - 1 && (W & 1), xrow = hp == Hp - 1 && (H & 1);
+      if (xcol) {
+        one_pixel(2 * hp, W - 1, nullptr);
+        one_pixel(2 * hp + 1, W - 1, nullptr);
+      }
+      if (xrow) {
+        one_pixel(H - 1, 2 * wp, nullptr);
+        one_pixel(H - 1, 2 * wp + 1, nullptr);
+        if (xcol) one_pixel(H - 1, W - 1, nullptr);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[threadIdx.x * 16 + i] = s1[i];
+      red[threadIdx.x * 16 + 8 + i] = s2[i];
+    }
+    __syncthreads();
+    if (pl == 0) {
+      float* row = P.partials + (size_t)(n * P.chunks + chunk) * 3 * C;
+      for (int q = 0; q < 16; ++q) {
+        float s = 0.f;
+        for (int r = 0; r < ppi; ++r) s += red[(r * tpp + gl) * 16 + q];
+        row[(q >> 3) * C + gk * 8 + (q & 7)] = s;
+      }
+      for (int i = 0; i < 8; ++i) row[2 * C + gk * 8 + i] = 0.f;   // third column block: unused in pool mode
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(NhwcD dz, NhwcD y, const float* __restrict__ scale,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ c1, const float* __restrict__ c2,
@@ -457,8 +552,11 @@ extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* 
   const dim3 grid(P.chunks, y->N);
   const size_t lds = 256 * 24 * sizeof(float);
   if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, P);
-  else if (mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, P);
-  else hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, P);
+  else if (mode == 1) {
+    // one thread per 2x2 window; SAME number of partial rows as the per-pixel form (the chunks now split the windows)
+    P.pixb = ceil_div(P.dpool.H * P.dpool.W, P.chunks);
+    hipLaunchKernelGGL(bn_bwd_reduce_pool_bf16_kernel, grid, dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream, P);
+  } else hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, P);
   GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_reduce");
   return GSD_OK;
 }
