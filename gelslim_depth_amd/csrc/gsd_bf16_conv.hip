@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
 
   // per-lane output rows are the same for every pixel tile: resolve channel / scatter quadrant once
-  int co_m[MT], qy[MT], qx[MT];
+  long long ooff_m[MT];   // element offset of the m-tile's 4 channels relative to the (scaled) pixel: channel + scatter shift
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int mrow = m0 + wm * 64 + m * 16 + g * 4;
@@ -312,99 +312,101 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       q = mrow / P.Cs;
       co = mrow - q * P.Cs;
     }
-    co_m[m] = co;
-    qy[m] = (q >> 1) + P.oy;
-    qx[m] = (q & 1) + P.ox;
+    ooff_m[m] = ((long long)((q >> 1) + P.oy) * P.Wob + (q & 1) + P.ox) * P.out_pitch + co;
   }
   const int sm = P.Cs > 0 ? 2 : 1;
-  if (P.bw_y != nullptr) {
-    // Fused pass 1 of BatchNorm+ReLU backward.  The raw outputs are loaded half a wave tile at a time IN FRONT of that
-    // half's stores (loads and stores share vmcnt: a load between two stores serialises them); coefficients from LDS.
+  // Interior tiles (all 256 / 512 pixels inside the image) and full m-tiles take a store path WITHOUT per-store branches:
+  // `guard` is a compile-time constant in each instantiation of the lambda, the m-tile test is wave-uniform.
+  bool mt_ok[MT];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      uint2 yr[NT / 2][MT];
+  for (int m = 0; m < MT; ++m) mt_ok[m] = m0 + wm * 64 + m * 16 < P.M;
+  const bool interior = h0 + P.TH <= P.H && w0 + P.TW <= P.W;
+  auto epilogue = [&](auto guard_c) {
+    constexpr bool GUARD = decltype(guard_c)::value;
+    if (P.bw_y != nullptr) {
+      // Fused pass 1 of BatchNorm+ReLU backward.  The raw outputs are loaded half a wave tile at a time IN FRONT of that
+      // half's stores (loads and stores share vmcnt: a load between two stores serialises them); coefficients from LDS.
 #pragma unroll
-      for (int tt = 0; tt < NT / 2; ++tt) {
-        const int t = half * (NT / 2) + tt, nt = wn * NT + t;
-        const int r = nt / cbs, cb = nt - r * cbs;
-        const int h = min(h0 + r, P.H - 1), w = min(w0 + cb * 16 + j, P.W - 1);
-        const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch;
+      for (int half = 0; half < 2; ++half) {
+        uint2 yr[NT / 2][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int mrow = m0 + wm * 64 + m * 16 + g * 4;
-          yr[tt][m] = *reinterpret_cast<const uint2*>(yp + (mrow < P.M ? mrow : 0));
+        for (int tt = 0; tt < NT / 2; ++tt) {
+          const int t = half * (NT / 2) + tt, nt = wn * NT + t;
+          const int r = nt / cbs, cb = nt - r * cbs;
+          const int h = GUARD ? min(h0 + r, P.H - 1) : h0 + r, w = GUARD ? min(w0 + cb * 16 + j, P.W - 1) : w0 + cb * 16 + j;
+          const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch + m0 + wm * 64 + g * 4;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) yr[tt][m] = *reinterpret_cast<const uint2*>(yp + (mt_ok[m] ? m * 16 : 0));
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tt = 0; tt < NT / 2; ++tt) {
-        const int t = half * (NT / 2) + tt, nt = wn * NT + t;
+        for (int tt = 0; tt < NT / 2; ++tt) {
+          const int t = half * (NT / 2) + tt, nt = wn * NT + t;
+          const int r = nt / cbs, cb = nt - r * cbs;
+          const int h = h0 + r, w = w0 + cb * 16 + j;
+          const bool pix_ok = !GUARD || (h < P.H && w < P.W);
+          u16* ot = P.out + ((long long)(n * P.Hob + h) * P.Wob + w) * P.out_pitch + m0 + wm * 64 + g * 4;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int cl = wm * 64 + m * 16 + g * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(sBw + 2 * BM + cl), is = *reinterpret_cast<const f32x4*>(sBw + 3 * BM + cl);
+            float yv[4] = {__uint_as_float(yr[tt][m].x << 16), __uint_as_float(yr[tt][m].x & 0xffff0000u),
+                           __uint_as_float(yr[tt][m].y << 16), __uint_as_float(yr[tt][m].y & 0xffff0000u)};
+            float dz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = fmaf(yv[e], sc[e], sh[e]) > 0.f ? acc[m][t][e] : 0.f;
+            const unsigned lo = pack_bf16(dz[0], dz[1]), hi = pack_bf16(dz[2], dz[3]);
+            if (mt_ok[m] && pix_ok) {
+              *reinterpret_cast<uint2*>(ot + m * 16) = make_uint2(lo, hi);
+              const float q[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                                  __uint_as_float(hi & 0xffff0000u)};   // sums of the values as stored
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                s1[m][e] += q[e];
+                s2[m][e] = fmaf(q[e], (yv[e] - mu[e]) * is[e], s2[m][e]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int nt = wn * NT + t;
         const int r = nt / cbs, cb = nt - r * cbs;
         const int h = h0 + r, w = w0 + cb * 16 + j;
-        const bool pix_ok = h < P.H && w < P.W;
+        const bool pix_ok = !GUARD || (h < P.H && w < P.W);
+        u16* ot = P.out + ((long long)(n * P.Hob + sm * h) * P.Wob + sm * w) * P.out_pitch;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const int mrow = m0 + wm * 64 + m * 16 + g * 4;
-          const int cl = wm * 64 + m * 16 + g * 4;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
-          const f32x4 mu = *reinterpret_cast<const f32x4*>(sBw + 2 * BM + cl), is = *reinterpret_cast<const f32x4*>(sBw + 3 * BM + cl);
-          float yv[4] = {__uint_as_float(yr[tt][m].x << 16), __uint_as_float(yr[tt][m].x & 0xffff0000u),
-                         __uint_as_float(yr[tt][m].y << 16), __uint_as_float(yr[tt][m].y & 0xffff0000u)};
-          float dz[4];
+          f32x4 v = acc[m][t];
+          if (P.ep_scale != nullptr) {
+            const int cl = wm * 64 + m * 16 + g * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dz[e] = fmaf(yv[e], sc[e], sh[e]) > 0.f ? acc[m][t][e] : 0.f;
-          const unsigned lo = pack_bf16(dz[0], dz[1]), hi = pack_bf16(dz[2], dz[3]);
-          if (pix_ok && mrow < P.M) {
-            u16* o = P.out + ((long long)(n * P.Hob + h) * P.Wob + w) * P.out_pitch + mrow;
-            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
-            const float q[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
-                                __uint_as_float(hi & 0xffff0000u)};   // sums of the values as stored
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              s1[m][e] += q[e];
-              s2[m][e] = fmaf(q[e], (yv[e] - mu[e]) * is[e], s2[m][e]);
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+          }
+          const unsigned lo = pack_bf16(v[0], v[1]);
+          const unsigned hi = pack_bf16(v[2], v[3]);
+          if (mt_ok[m] && pix_ok) {
+            *reinterpret_cast<uint2*>(ot + ooff_m[m]) = make_uint2(lo, hi);
+            if (P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
+              const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
+              const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
+              s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
+              s1[m][1] += q1; s2[m][1] = fmaf(q1, q1, s2[m][1]);
+              s1[m][2] += q2; s2[m][2] = fmaf(q2, q2, s2[m][2]);
+              s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
             }
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {    const int nt = wn * NT + t;
-    const int r = nt / cbs, cb = nt - r * cbs;
-    const int h = h0 + r, w = w0 + cb * 16 + j;
-    const bool pix_ok = h < P.H && w < P.W;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int mrow = m0 + wm * 64 + m * 16 + g * 4;
-      if (mrow < P.M) {
-        const int ho = sm * h + qy[m], wo = sm * w + qx[m];
-        f32x4 v = acc[m][t];
-        if (P.ep_scale != nullptr) {
-          const int cl = wm * 64 + m * 16 + g * 4;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-        }
-        const unsigned lo = pack_bf16(v[0], v[1]);
-        const unsigned hi = pack_bf16(v[2], v[3]);
-        if (pix_ok) {
-          u16* o = P.out + ((long long)(n * P.Hob + ho) * P.Wob + wo) * P.out_pitch + co_m[m];
-          *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
-          if (P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
-            const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
-            const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
-            s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
-            s1[m][1] += q1; s2[m][1] = fmaf(q1, q1, s2[m][1]);
-            s1[m][2] += q2; s2[m][2] = fmaf(q2, q2, s2[m][2]);
-            s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
-          }
-        }
-      }
-    }
-  }
-  }
+  };
+  if (interior) epilogue(std::integral_constant<bool, false>{});
+  else epilogue(std::integral_constant<bool, true>{});
   if (P.partials != nullptr) {
     // The block is persistent, so its statistics are too: per item the 16-lane rows are summed with DPP and the totals
     // added into the block's LDS cells; ONE partial row per (block, wave) leaves for HBM at the very end (a few hundred
