@@ -5,7 +5,7 @@ flow (/root/reference/gelslim_depth/models/unet.py:79-88), different data layout
 
   * activations and their gradients: bfloat16, NHWC.  Per conv unit u:
         y[u]  raw convolution output           a[u]  relu(bn(y)) -- materialised (2 B/element, one extra HBM pass that
-        g[u]  gradient: da -> dz -> dy in place       costs <2 % of the step and lets every GEMM operand go HBM -> LDS by DMA)
+        g[u]  gradient: da -> dz -> dy in place       costs ~4 % of the step and lets every GEMM operand go HBM -> LDS by DMA)
   * torch.cat([skip, up]) (unet.py:48) is ONE buffer cat[l] of C_skip + C_up channels per level: the encoder's BatchNorm
     apply writes a[skip] into channels [0, C_skip), the transposed convolution scatters its output (+bias) into channels
     [C_skip, ..) at its F.pad offset (unet.py:43-47; the padding border is zeroed once), the decoder conv reads the
@@ -13,6 +13,10 @@ flow (/root/reference/gelslim_depth/models/unet.py:79-88), different data layout
     BatchNorm backward and the transposed convolution's dX / dW.
   * fp32: master parameters (the module's own tensors), every accumulation, BatchNorm statistics, gradients, Adam/EMA.
     Per step each weight is re-laid-out to its bf16 GEMM image (gsd_bf16_weight_image).
+  * eval mode: BatchNorm (running statistics) + ReLU ride in the conv epilogue (gsd_bf16_conv3x3_bnrelu): y is not stored.
+  * backward: pass 1 of BatchNorm+ReLU backward (mask, per-channel sums) is fused into the dX launch that produces the
+    gradient (conv3x3 and transposed-conv dX); only skip units (gradient = dX slice + max-pool routing) and the last unit
+    (gradient = OutConv backward) use the stand-alone reduce kernels.
 """
 from __future__ import annotations
 
