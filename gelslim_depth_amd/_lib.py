@@ -82,6 +82,8 @@ SIGNATURES = {
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
     "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _P]),
     "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "gsd_bn_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gsd_bn_bwd_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _P, _P, _P, _P]),
     "gsd_area_resize_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _F, _F, _P]),
     "gsd_ingest_images": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _I, _F, _F, _P]),
     "gsd_channel_stats_workspace": (_L, [_I]),

@@ -179,6 +179,113 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
   }
 }
+// One-launch forms for a FEW partial rows (the persistent bf16 kernels write one row per block and wave: a few hundred):
+// a block owns 64 channels, its 16 row lanes sum the rows in a fixed order in fp64, then the same thread finalises.
+constexpr int RF_LANES = 16;
+// `sums` still receives the per-channel totals (SyncBN and the tests read them).
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ part, int rows, int ld, int off2, int C,
+                                                                 double* __restrict__ sums, double count, const float* gamma,
+                                                                 const float* beta, float eps, float momentum, float* running_mean,
+                                                                 float* running_var, float* mean, float* invstd, float* scale,
+                                                                 float* shift) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += RF_LANES) {
+      s += (double)part[(size_t)r * ld + c];
+      q += (double)part[(size_t)r * ld + off2 + c];
+    }
+  __shared__ double red[2][RF_LANES][64];
+  red[0][rl][threadIdx.x & 63] = s;
+  red[1][rl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  const int l = threadIdx.x;
+  s = q = 0.0;
+  for (int i = 0; i < RF_LANES; ++i) {
+    s += red[0][i][l];
+    q += red[1][i][l];
+  }
+  sums[c] = s;
+  sums[C + c] = q;
+  const double mu = s / count;
+  double var = q / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  mean[c] = (float)mu;
+  invstd[c] = (float)is;
+  scale[c] = (float)((double)gamma[c] * is);
+  shift[c] = (float)((double)beta[c] - mu * (double)gamma[c] * is);
+  if (running_mean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+
+extern "C" int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad, int C, double* sums, double count,
+                                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  GSD_REQUIRE(partials && sums && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && Mpad >= C && count > 0,
+              GSD_ERR_BAD_ARG, "gsd_bn_reduce_finalize: bad argument");
+  GSD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GSD_ERR_BAD_ARG,
+              "gsd_bn_reduce_finalize: running stats must come together");
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * RF_LANES), 0, (hipStream_t)stream, partials, rows, 2 * Mpad,
+                     Mpad, C, sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  GSD_LAUNCH_CHECK("gsd_bn_reduce_finalize");
+  return GSD_OK;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* __restrict__ part, int rows, int ld, int off2,
+                                                                     int off3, int C, double* __restrict__ sums, double count,
+                                                                     float* dgamma, float* dbeta, float* dwout, float* c1,
+                                                                     float* c2) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s = 0.0, q = 0.0, w = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += RF_LANES) {
+      s += (double)part[(size_t)r * ld + c];
+      q += (double)part[(size_t)r * ld + off2 + c];
+      if (off3 >= 0) w += (double)part[(size_t)r * ld + off3 + c];
+    }
+  __shared__ double red[3][RF_LANES][64];
+  red[0][rl][threadIdx.x & 63] = s;
+  red[1][rl][threadIdx.x & 63] = q;
+  red[2][rl][threadIdx.x & 63] = w;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  const int l = threadIdx.x;
+  s = q = w = 0.0;
+  for (int i = 0; i < RF_LANES; ++i) {
+    s += red[0][i][l];
+    q += red[1][i][l];
+    w += red[2][i][l];
+  }
+  sums[c] = s;
+  sums[C + c] = q;
+  sums[2 * C + c] = w;
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+  if (dwout != nullptr) dwout[c] = (float)w;
+  c1[c] = (float)(s / count);
+  c2[c] = (float)(q / count);
+}
+
+extern "C" int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int layout_mpad, int C, double* sums, double count,
+                                          float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream) {
+  GSD_REQUIRE(partials && sums && dgamma && dbeta && c1 && c2 && rows > 0 && C > 0 && count > 0, GSD_ERR_BAD_ARG,
+              "gsd_bn_bwd_reduce_finalize: bad argument");
+  GSD_REQUIRE(layout_mpad == 0 || (layout_mpad >= C && dwout == nullptr), GSD_ERR_BAD_ARG,
+              "gsd_bn_bwd_reduce_finalize: the conv-epilogue layout has no third column block");
+  // layout_mpad == 0: rows of [sum dz | sum dz*xhat | third] (3*C) from the stand-alone reduce kernels;
+  // layout_mpad  > 0: rows of 2*mpad from a dX epilogue (gsd_conv3x3_dgrad_bnrelu / gsd_bf16_bnbwd)
+  const int ld = layout_mpad > 0 ? 2 * layout_mpad : 3 * C, off2 = layout_mpad > 0 ? layout_mpad : C;
+  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * RF_LANES), 0, (hipStream_t)stream, partials, rows, ld,
+                     off2, layout_mpad > 0 ? -1 : 2 * C, C, sums, count, dgamma, dbeta, dwout, c1, c2);
+  GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_finalize");
+  return GSD_OK;
+}
+
 extern "C" int gsd_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                                float* scale, float* shift, void* stream) {

@@ -227,16 +227,21 @@ class UNetEngineBF16:
             check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
         rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
-        check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
-                                         u.sums.data_ptr(), st), "bn_reduce_partials")
         count = float(n * lh * lw)
-        if self.sync_fn is not None:
+        if self.sync_fn is None:     # a few hundred partial rows: column sums and finalize in ONE launch
+            check(lib.gsd_bn_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout, u.sums.data_ptr(),
+                                             count, P[u.gname].data_ptr(), P[u.bname].data_ptr(), BN_EPS, BN_MOMENTUM,
+                                             P[u.rmname].data_ptr(), P[u.rvname].data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
+                                             u.scale.data_ptr(), u.shift.data_ptr(), st), "bn_reduce_finalize")
+        else:                        # SyncBN: the fp64 sums are all-reduced between the two halves
+            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
+                                             u.sums.data_ptr(), st), "bn_reduce_partials")
             self.sync_fn(u.sums[:2 * u.cout])
             count *= self.world
-        check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
-                                  BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
-                                  u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
-              "bn_finalize")
+            check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
+                                      BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
+                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+                  "bn_finalize")
         P[u.nbtname].add_(1)
         check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
 
@@ -302,23 +307,25 @@ class UNetEngineBF16:
         """u.g holds dz and self.partials its sums: finish BatchNorm backward (dgamma, dbeta, dy in place), then dW.
         fused: the sums come from a dX launch's epilogue (conv partial layout) instead of gsd_bf16_bn_bwd_reduce."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
-        if fused:
-            rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
-            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
-                                             u.sums.data_ptr(), st), "bn_reduce_partials")
-        else:
-            rows = lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
-            check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
-                  "bn_bwd_reduce_partials")
         count = float(n * lh * lw)
-        gsum = None
-        if self.sync_fn is not None:
+        rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout) if fused else lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
+        dw_ptr = None if dwout is None else dwout.data_ptr()
+        if self.sync_fn is None:
+            check(lib.gsd_bn_bwd_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout) if fused else 0, u.cout,
+                                                 u.sums.data_ptr(), count, G[u.gname].data_ptr(), G[u.bname].data_ptr(), dw_ptr,
+                                                 u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_reduce_finalize")
+        else:
+            if fused:
+                check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
+                                                 u.sums.data_ptr(), st), "bn_reduce_partials")
+            else:
+                check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
+                      "bn_bwd_reduce_partials")
             gsum = u.sums[:2 * u.cout].clone()
             self.sync_fn(gsum)
             count *= self.world
-        check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), L.ptr(gsum), u.cout, count, G[u.gname].data_ptr(), G[u.bname].data_ptr(),
-                                      None if dwout is None else dwout.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), st),
-              "bn_bwd_finalize")
+            check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), gsum.data_ptr(), u.cout, count, G[u.gname].data_ptr(),
+                                          G[u.bname].data_ptr(), dw_ptr, u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_finalize")
         dz, dy = L.make_nhwc(u.g), L.make_nhwc(u.y)
         check(lib.gsd_bf16_bn_bwd_apply(C.byref(dz), C.byref(dy), u.scale.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
                                         u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_apply")

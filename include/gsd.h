@@ -162,6 +162,16 @@ int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale, const floa
 int gsd_bn_bwd_reduce_partials(const float* partials, int rows, int C, double* sums, void* stream);
 int gsd_bn_bwd_finalize(const double* sums_local, const double* sums_global, int C, double count,
                         float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream);
+
+/* One-launch forms of (gsd_bn_reduce_partials + gsd_bn_finalize) and (gsd_bn_[bwd_]reduce_partials +
+ * gsd_bn_bwd_finalize) for launches that leave only a few hundred partial rows (the persistent bf16 kernels; no SyncBN
+ * exchange in between).  `sums` (3*C doubles) still receives the totals.  layout_mpad: 0 for rows of 3*C floats from
+ * the stand-alone backward reduce kernels, mpad for rows of 2*mpad floats from a dX epilogue. */
+int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad, int C, double* sums, double count, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* invstd, float* scale, float* shift, void* stream);
+int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int layout_mpad, int C, double* sums, double count,
+                               float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream);
 /* pass 3: d_raw = scale_g * (dz - c1 - xhat*c2), in place on dz; scale_g = gamma*invstd = scale. */
 int gsd_bn_bwd_apply(float* dz, const float* raw, const float* scale, const float* mean,
                      const float* invstd, const float* c1, const float* c2,

@@ -380,3 +380,69 @@ def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, n, ci, co, h, w):
     got = sums[:2 * ci].cpu().numpy()
     np.testing.assert_allclose(got[:ci], s1_ref, rtol=2e-4, atol=2e-3)
     np.testing.assert_allclose(got[ci:], s2_ref, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("rows,c,mpad", [(1, 3, 16), (37, 64, 64), (1024, 200, 256), (515, 1024, 1024)])
+def test_bn_one_launch_reduce_finalize(gsd, rows, c, mpad):
+    """gsd_bn_reduce_finalize / gsd_bn_bwd_reduce_finalize == the two-launch forms (fp64 sums in another order:
+    identical after rounding to fp32 up to 1 ulp) and a float64 torch column sum."""
+    rng = np.random.default_rng(rows + c)
+    count = 1234.0
+    # forward layout: rows of [sum | sum of squares] with ld = 2*mpad
+    y = rng.standard_normal((rows, mpad)).astype(np.float32)
+    part = dev(np.concatenate([y, y * y + 1.0], axis=1))
+    gamma, beta = dev(rnd(rng, c)), dev(rnd(rng, c))
+    rm0, rv0 = rnd(rng, c), np.abs(rnd(rng, c)) + 0.5
+
+    def fwd(one):
+        sums = torch.zeros(65 * 3 * c, dtype=torch.float64, device="cuda")
+        rm, rv = dev(rm0), dev(rv0)
+        outs = [torch.zeros(c, device="cuda") for _ in range(4)]
+        tail = [gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr()] + [o.data_ptr() for o in outs]
+        if one:
+            gsd.check(gsd.lib.gsd_bn_reduce_finalize(part.data_ptr(), rows, mpad, c, sums.data_ptr(), count, *tail,
+                                                     gsd.stream_ptr()))
+        else:
+            gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, c, sums.data_ptr(), gsd.stream_ptr()))
+            gsd.check(gsd.lib.gsd_bn_finalize(sums.data_ptr(), c, count, *tail, gsd.stream_ptr()))
+        torch.cuda.synchronize()
+        return sums[:2 * c].cpu().numpy(), [o.cpu().numpy() for o in outs + [rm, rv]]
+
+    s1, o1 = fwd(True)
+    s2, o2 = fwd(False)
+    ref = part.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(s1, np.concatenate([ref[:c], ref[mpad:mpad + c]]), rtol=1e-13, atol=1e-10)
+    np.testing.assert_allclose(s1, s2, rtol=1e-13, atol=1e-10)
+    for a, b in zip(o1, o2):
+        np.testing.assert_allclose(a, b, rtol=3e-7, atol=1e-7)
+
+    # backward, both layouts
+    for layout_mpad in (0, mpad):
+        ld = 2 * mpad if layout_mpad else 3 * c
+        bp = dev(rnd(rng, rows, ld))
+
+        def bwd(one):
+            sums = torch.zeros(65 * 3 * c, dtype=torch.float64, device="cuda")
+            outs = [torch.zeros(c, device="cuda") for _ in range(5)]   # dgamma dbeta dwout c1 c2
+            ptrs = [o.data_ptr() for o in outs]
+            if layout_mpad:
+                ptrs[2] = None
+            if one:
+                gsd.check(gsd.lib.gsd_bn_bwd_reduce_finalize(bp.data_ptr(), rows, layout_mpad, c, sums.data_ptr(), count, *ptrs,
+                                                             gsd.stream_ptr()))
+            else:
+                if layout_mpad:
+                    gsd.check(gsd.lib.gsd_bn_reduce_partials(bp.data_ptr(), rows, mpad, c, sums.data_ptr(), gsd.stream_ptr()))
+                else:
+                    gsd.check(gsd.lib.gsd_bn_bwd_reduce_partials(bp.data_ptr(), rows, c, sums.data_ptr(), gsd.stream_ptr()))
+                gsd.check(gsd.lib.gsd_bn_bwd_finalize(sums.data_ptr(), None, c, count, *ptrs, gsd.stream_ptr()))
+            torch.cuda.synchronize()
+            return [o.cpu().numpy() for o in outs]
+
+        b1, b2 = bwd(True), bwd(False)
+        col = bp.double().sum(0).cpu().numpy()
+        off2 = mpad if layout_mpad else c
+        np.testing.assert_allclose(b1[1], col[:c], rtol=3e-7, atol=1e-6)            # dbeta
+        np.testing.assert_allclose(b1[0], col[off2:off2 + c], rtol=3e-7, atol=1e-6)  # dgamma
+        for a, b in zip(b1, b2):
+            np.testing.assert_allclose(a, b, rtol=3e-7, atol=1e-7)
