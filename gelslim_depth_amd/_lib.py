@@ -63,6 +63,11 @@ SIGNATURES = {
     "gsd_conv3x3_partial_rows": (_I, [_I, _I, _I, _I]),
     "gsd_conv3x3": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _I, _I, _I, _P]),
     "gsd_conv3x3_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "gsd_conv3x3_algo": (_I, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_w43_partial_rows": (_I, [_I, _I, _I, _I]),
+    "gsd_conv3x3_w43_mfma_count": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_w43": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _I, _I, _I, _P]),
+    "gsd_conv3x3_w43_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "gsd_convT2x2": (_I, [_SRC, _P, _P, _I, _I, _DST, _I, _I, _I, _P]),
     "gsd_convT2x2_dgrad": (_I, [_SRC, _P, _I, _I, _DST, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),

@@ -410,6 +410,21 @@ extern "C" int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout) {
   return N * p.tiles_y * p.tiles_x * p.WN;
 }
 
+// Which conv3x3 kernel serves this shape: 0 = direct taps (this file), 1 = Winograd F(4,3) along rows (gsd_conv3x3_w43.hip).
+// Both count MFMA instructions per launch including tile padding; the Winograd form wins when it needs clearly fewer
+// (ideal: half; measured x1.3-1.7 on the U-Net's layers, profiles/bench_conv_forms.py).  GSD_CONV_ALGO=0|1 forces one.
+extern "C" int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int Cout);
+extern "C" int gsd_conv3x3_algo(int N, int H, int W, int Cin, int Cout) {
+  static const int forced = getenv("GSD_CONV_ALGO") ? atoi(getenv("GSD_CONV_ALGO")) : -1;
+  if (forced == 0 || forced == 1) return forced;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if (Cin < 16) return 0;   // a K loop of 1-3 chunks is all prologue + epilogue, and the Winograd epilogue is the longer one
+  const ConvPlan p = plan_conv3x3(H, W, Cout);
+  const int64_t direct = (int64_t)N * p.tiles_y * p.tiles_x * p.mblocks * ceil_div(Cin, 4) * (p.big ? 1152 : 576);
+  const int64_t wino = gsd_conv3x3_w43_mfma_count(N, H, W, Cin, Cout);
+  return wino > 0 && wino * 10 <= direct * 8 ? 1 : 0;
+}
+
 static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
                         float* partials, const float* bw_raw, const float* bw_scale, const float* bw_shift,
                         const float* bw_mean, const float* bw_invstd, int N, int H, int W, void* stream) {

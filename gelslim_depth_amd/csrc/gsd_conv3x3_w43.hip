@@ -1,0 +1,499 @@
+// gsd_conv3x3_w43.hip -- conv3x3 (pad 1, stride 1, no bias) forward and dX with the Winograd minimal-filtering
+// identity F(4,3) applied ALONG THE IMAGE ROWS, on v_mfma_f32_16x16x4_f32 (gfx950).
+//
+// Same operator as gsd_conv3x3.hip (aten::convolution at /root/reference/gelslim_depth/models/unet.py:11,14 and the dX
+// half of aten::convolution_backward), same fp32 storage and fp32 accumulation, half the multiplications: four
+// horizontally adjacent outputs of one kernel row need 6 products instead of 12,
+//
+//   y[0..3] = A^T [ (G g) .* (B^T d) ],   d = 6 consecutive inputs of the row, g = the 3 taps of one kernel row,
+//
+// and the three kernel rows and the input channels are the contraction that stays on the MFMA:
+//
+//   M_f[m][tile] = sum_{ci, r} U_f[(ci,r)][m] * V_f[(ci,r)][tile],   f = 0..5
+//
+// i.e. six GEMMs with K = 3*Cin instead of one with K = 9*Cin, over N = pixels/4 "tiles".  Accumulators: 6 per 4
+// pixels (1.5x the direct form).  U = G g is computed once per optimiser step by gsd_weight_layout (modes 4/5), V = B^T d
+// by the consumer lanes between the ds_read and the MFMA (13 VALU operations per 6 values, next to the deferred
+// BatchNorm+ReLU that is already applied there), y = A^T M in the epilogue.  F(4,3) in one dimension is numerically
+// benign in fp32 (largest transform constants 8 and 1/24): the op-level tests bound it at 1e-5 relative L1 against
+// the fp64 oracle, two orders below the 1e-3 north-star tolerance.
+//
+// Block = 4 waves, all on the same 64 output channels; each wave owns 16 tiles = 64 pixels: block tile 64 (m) x 256
+// pixels.  Per 4-channel chunk a wave issues 18 k-steps (3 kernel rows x 6 frequencies) x 4 MFMAs; the weight image
+// of a chunk is 72 x 64 floats = 18 KiB, exactly the direct kernel's (36 x 128), and it is amortised over 256 pixels
+// so the L2 -> LDS rate per MFMA-second equals the direct 128 x 128 kernel's although the MFMA time halves.
+// Data movement, deferred BatchNorm, NaN-sentinel padding, concat sources, two cropped destinations, BatchNorm
+// partial sums and the fused BatchNorm-backward dX epilogue are those of gsd_conv3x3.hip.
+#include "gsd_common.h"
+
+#include <cstdlib>
+
+__device__ const float gsd_pad_w43[2] = {0.f, __builtin_nanf("")};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct W43Params {
+  SrcD src0, src1;
+  DstD dst0, dst1;
+  const float* wt;   // [mblocks][nchunks*72][64]: row (ci_local*18 + r*6 + f), columns permuted (slot l*4+t = column t*16+l)
+  float* partials;
+  const float* bw_raw;
+  const float* bw_scale;
+  const float* bw_shift;
+  const float* bw_mean;
+  const float* bw_invstd;
+  int Cin, Cout, Mpad, nchunks, mblocks;
+  int N, H, W;
+  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
+};
+
+namespace {
+constexpr int W43_BM = 64;
+constexpr int W43_WTILE = 72 * W43_BM;      // floats per weight chunk
+constexpr int W43_W4 = W43_WTILE / 4;       // float4s
+constexpr int W43_NWI = (W43_W4 + 255) / 256;
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) {
+  constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4, NWI = W43_NWI;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PS = P.PS;
+  const int BUF = WTILE + 4 * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int mb = blockIdx.x % P.mblocks;
+  const int pt = blockIdx.x / P.mblocks;
+  const int m0 = mb * BM;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = pt / tpi;
+  const int rt = pt - n * tpi;
+  const int ty = rt / P.tiles_x;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+
+  // ---- this lane's Winograd tile: 4 pixels (tr, 4*tq .. 4*tq+3) of the block's TH x TW output tile ----------------------
+  const int q = wave * 16 + l16;
+  const bool q_ok = q < P.TH * P.TWq;
+  const int tr = q_ok ? q / P.TWq : 0;
+  const int tq = q_ok ? q - tr * P.TWq : 0;
+  const int baddr = WTILE + j * PS + tr * P.WCp + 4 * tq;   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
+  int vmask = 0;                                            // pixels of the tile that exist in the image
+  if (q_ok && h0 + tr < P.H) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (w0 + 4 * tq + i < P.W) vmask |= 1 << i;
+  }
+
+  // ---- DMA lane geometry (as gsd_conv3x3.hip, window rows padded to WCp floats) ------------------------------------------
+  int xo0[2], xo1[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int pos = (wave + 4 * pp) * 64 + lane;
+    xo0[pp] = xo1[pp] = -2;
+    const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
+    if (rr < P.WR && cc < P.WC) {
+      const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
+      int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.W + ws : -1;
+      hs = gh - P.src1.oh;
+      ws = gw - P.src1.ow;
+      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.W + ws : -1;
+    }
+  }
+  const float* wsrc0 = P.wt + (size_t)mb * P.nchunks * WTILE;
+  const bool p_on[2] = {wave < P.NPV, wave + 4 < P.NPV};
+
+  int d_seg = 0, d_left = P.src0.C;
+  const float* d_base = P.src0.p + (long long)n * P.src0.ns;
+  long long d_cs = P.src0.cs;
+  const float* d_sent = P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
+  int d_xo[2] = {xo0[0], xo0[1]};
+
+  // slots 0..NWI-1: the weight chunk (16 B per lane); slot NWI+ch: input channel ch of the chunk
+  auto dma_slot = [&](int slot, int chunk, int buf) {
+    float* Wb = smem + buf * BUF;
+    if (slot < NWI) {
+      const float* wsrc = wsrc0 + (size_t)chunk * WTILE + tid * 4;
+      if (tid + slot * 256 < W4)
+        __builtin_amdgcn_global_load_lds(wsrc + slot * 1024, Wb + (slot * 256 + wave * 64) * 4, 16, 0, 0);
+    } else if (slot < NWI + 4) {
+      const int ch = slot - NWI;
+      float* Xb = Wb + WTILE;
+      if (d_left == 0 && d_seg == 0) {
+        d_seg = 1;
+        d_left = P.src1.C;
+        d_base = P.src1.p + (long long)n * P.src1.ns;
+        d_cs = P.src1.cs;
+        d_sent = P.src1.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
+        d_xo[0] = xo1[0];
+        d_xo[1] = xo1[1];
+      }
+      const bool c_ok = d_left > 0;
+      const float* sentinel = c_ok ? d_sent : &gsd_pad_w43[0];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        if (p_on[pp] && d_xo[pp] != -2) {
+          const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : sentinel;
+          __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave + 4 * pp) * 64, 4, 0, 0);
+        }
+      }
+      if (c_ok) {
+        d_base += d_cs;
+        --d_left;
+      }
+    }
+  };
+
+  const int Kpad = P.nchunks * 4;
+  float* sAff = smem + 2 * BUF;
+  for (int c = tid; c < Kpad; c += 256) {
+    const bool first = c < P.src0.C;
+    const SrcD& S = first ? P.src0 : P.src1;
+    const int cc = first ? c : c - P.src0.C;
+    float sc = 1.f, sh = 0.f;
+    if (c < P.Cin && cc < S.C && S.scale != nullptr) {
+      sc = S.scale[cc];
+      sh = S.shift[cc];
+    }
+    sAff[c] = sc;
+    sAff[Kpad + c] = sh;
+  }
+  float* sBw = sAff + 2 * Kpad;   // [4][BM]: scale, shift, mean, invstd of the fused BatchNorm-backward epilogue
+  if (P.bw_raw != nullptr) {
+    for (int c = tid; c < BM; c += 256) {
+      const int co = m0 + c < P.Cout ? m0 + c : 0;
+      sBw[c] = P.bw_scale[co];
+      sBw[BM + c] = P.bw_shift[co];
+      sBw[2 * BM + c] = P.bw_mean[co];
+      sBw[3 * BM + c] = P.bw_invstd[co];
+    }
+  }
+  const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
+
+  f32x4 acc[MT][6];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // V = B^T d of one kernel row: raw halo values -> deferred BatchNorm+ReLU -> the 6 frequency operands
+  auto transform = [&](const f32x4& ra, const f32x2& rb, float sc, float sh, float lo, float (&v)[6]) {
+    const float d0 = fmaxf(fmaf(ra[0], sc, sh), lo), d1 = fmaxf(fmaf(ra[1], sc, sh), lo);
+    const float d2 = fmaxf(fmaf(ra[2], sc, sh), lo), d3 = fmaxf(fmaf(ra[3], sc, sh), lo);
+    const float d4 = fmaxf(fmaf(rb[0], sc, sh), lo), d5 = fmaxf(fmaf(rb[1], sc, sh), lo);
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = 2.f * (d3 - d1);
+    v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    v[1] = a + b;
+    v[2] = a - b;
+    v[3] = c + e;
+    v[4] = c - e;
+    v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  };
+
+  const int a_lane = l16 * 4;
+#pragma unroll
+  for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    gsd_dma_barrier();
+    const int kc = chunk * 4 + j;
+    const float sc = sAff[kc], sh = sAff[Kpad + kc];
+    const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
+    const bool more = chunk + 1 < P.nchunks;
+    const float* Wc = smem + cur * BUF;
+    f32x4 av[2];
+    f32x4 ra[2];
+    f32x2 rb[2];
+    float v[6];
+    ra[0] = *reinterpret_cast<const f32x4*>(&Wc[baddr]);
+    rb[0] = *reinterpret_cast<const f32x2*>(&Wc[baddr + 4]);
+    av[0] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18) * WS + a_lane]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      transform(ra[r & 1], rb[r & 1], sc, sh, lo, v);
+      if (r < 2) {   // the next kernel row's raw values fly during this row's 24 MFMAs
+        ra[(r + 1) & 1] = *reinterpret_cast<const f32x4*>(&Wc[baddr + (r + 1) * P.WCp]);
+        rb[(r + 1) & 1] = *reinterpret_cast<const f32x2*>(&Wc[baddr + (r + 1) * P.WCp + 4]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        const int s = r * 6 + f, cs = s & 1;
+        if (s + 1 < 18) av[cs ^ 1] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18 + s + 1) * WS + a_lane]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][f] = mfma16(av[cs][m], v[f], acc[m][f]);
+        if (more && s < 5) {
+          dma_slot(2 * s, chunk + 1, cur ^ 1);
+          dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue: y = A^T M, NCHW stores (two destination segments with crop), BatchNorm partial sums ----------------------
+  // per destination: element offset of the tile's first pixel inside a plane, and the mask of its pixels that are stored
+  int off0 = 0, off1 = 0, sm0 = 0, sm1 = 0;
+  {
+    const int h = h0 + tr, w = w0 + 4 * tq;
+    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
+    if ((unsigned)hd < (unsigned)P.dst0.H) {
+      off0 = hd * P.dst0.W + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0 |= 1 << i;
+    }
+    hd = h - P.dst1.oh;
+    wd = w - P.dst1.ow;
+    if ((unsigned)hd < (unsigned)P.dst1.H) {
+      off1 = hd * P.dst1.W + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1 |= 1 << i;
+    }
+  }
+  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
+  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * 4 + wave) * (2 * P.Mpad) : nullptr;
+
+  auto out_transform = [&](int m, int reg, float (&y)[4]) {
+    const float M0 = acc[m][0][reg], M1 = acc[m][1][reg], M2 = acc[m][2][reg];
+    const float M3 = acc[m][3][reg], M4 = acc[m][4][reg], M5 = acc[m][5][reg];
+    const float p12 = M1 + M2, m12 = M1 - M2, p34 = M3 + M4, m34 = M3 - M4;
+    y[0] = M0 + p12 + p34;
+    y[1] = fmaf(2.f, m34, m12);
+    y[2] = fmaf(4.f, p34, p12);
+    y[3] = fmaf(8.f, m34, m12) + M5;
+  };
+
+  if (P.bw_raw == nullptr) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        const bool first = co < P.dst0.C;
+        const int cd = first ? co : co - P.dst0.C;
+        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+        float* const px = (first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs) + (first ? off0 : off1);
+        const int sm = co_ok ? (first ? sm0 : sm1) : 0;
+        float y[4];
+        out_transform(m, reg, y);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (vmask >> i & 1) {
+            s1 += y[i];
+            s2 = fmaf(y[i], y[i], s2);
+          }
+        }
+        if (sm == 15) {
+          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (sm >> i & 1) px[i] = y[i];
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  } else {
+    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX.
+    // Loads and stores share vmcnt: the raw values of one m-tile (4 rows x 4 pixels) are loaded together in front of its
+    // stores, the coefficients come from LDS.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float xr[4][4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        const float* const rp = P.bw_raw + (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs + off0;
+        if (sm0 == 15) {
+          const f32x4 t = *reinterpret_cast<const f32x4u*>(rp);
+          xr[reg][0] = t[0]; xr[reg][1] = t[1]; xr[reg][2] = t[2]; xr[reg][3] = t[3];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xr[reg][i] = (sm0 >> i & 1) ? rp[i] : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        float* const px = d0 + (long long)co * P.dst0.cs + off0;
+        const int cl = m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        const int sm = co < P.Cout ? sm0 : 0;
+        float y[4];
+        out_transform(m, reg, y);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = xr[reg][i];
+          const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[i] : 0.f;
+          y[i] = dz;
+          s1 += dz;
+          s2 = fmaf(dz, (x - bmu) * bis, s2);
+        }
+        if (sm == 15) {
+          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (sm >> i & 1) px[i] = y[i];
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct W43Plan {
+  int TH, TW, TWq, tiles_y, tiles_x, mblocks, WR, WC, WCp;
+};
+
+// TH x TW output tile of 64 Winograd tiles (TW a multiple of 4, TH*TW <= 256) whose padded halo window fits the 512 DMA
+// positions: fewest blocks first, then the widest rows (longer coalesced row segments).
+bool plan_w43(int H, int W, int M, W43Plan* best) {
+  long best_tiles = -1;
+  for (int tw = 4; tw <= 64; tw += 4) {
+    int th = 256 / tw;
+    const int wcp = round_up(tw + 2, 4);
+    while (th > 1 && (th + 2) * wcp > 512) --th;
+    if ((th + 2) * wcp > 512) continue;
+    if (th > H) th = H;
+    const int ty = ceil_div(H, th);
+    th = ceil_div(H, ty);
+    const long tiles = (long)ty * ceil_div(W, tw);
+    if (best_tiles < 0 || tiles <= best_tiles) {
+      best_tiles = tiles;
+      best->TH = th; best->TW = tw; best->TWq = tw / 4;
+      best->tiles_y = ty; best->tiles_x = ceil_div(W, tw);
+      best->WR = th + 2; best->WC = tw + 2; best->WCp = wcp;
+    }
+  }
+  best->mblocks = ceil_div(M, W43_BM);
+  return best_tiles > 0;
+}
+
+int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_w43_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv3x3_w43_kernel, dim3(grid), dim3(256), lds, st, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_w43");
+  return GSD_OK;
+}
+
+}  // namespace
+
+extern "C" int gsd_conv3x3_w43_partial_rows(int N, int H, int W, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  W43Plan p;
+  if (!plan_w43(H, W, Cout, &p)) return 0;
+  return N * p.tiles_y * p.tiles_x * 4;
+}
+
+// MFMA instructions of one launch (all blocks, padding included), for gsd_conv3x3_algo
+extern "C" int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int Cout) {
+  W43Plan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w43(H, W, Cout, &p)) return 0;
+  return (int64_t)N * p.tiles_y * p.tiles_x * p.mblocks * ceil_div(Cin, 4) * (4 * 72);
+}
+
+static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                    float* partials, const float* bw_raw, const float* bw_scale, const float* bw_shift, const float* bw_mean,
+                    const float* bw_invstd, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: null argument");
+  GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: nsrc/ndst must be 1 or 2");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: bad sizes");
+  GSD_REQUIRE(H < 32768 && W < 32768, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: H, W must be < 32768");
+  GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: weight layout must be 16-byte aligned");
+  int csum = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (int e = gsd_check_src(src[i], "gsd_conv3x3_w43 src")) return e;
+    GSD_REQUIRE(src[i].scale == nullptr || src[i].relu != 0, GSD_ERR_UNSUPPORTED,
+                "gsd_conv3x3_w43: an affine source segment must also have relu (zero padding uses a NaN sentinel)");
+    GSD_REQUIRE((int64_t)src[i].H * src[i].W < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: plane too large");
+    csum += src[i].C;
+  }
+  GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: source segments hold %d channels, Cin=%d", csum, Cin);
+  csum = 0;
+  for (int i = 0; i < ndst; ++i) {
+    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3_w43 dst")) return e;
+    csum += dst[i].C;
+  }
+  GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: destination segments hold %d channels, Cout=%d", csum, Cout);
+
+  W43Plan pl;
+  GSD_REQUIRE(plan_w43(H, W, Cout, &pl), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: no tile shape");
+  W43Params P;
+  P.src0 = to_srcd(src[0]);
+  P.src1 = nsrc > 1 ? to_srcd(src[1]) : null_srcd();
+  P.dst0 = to_dstd(dst[0]);
+  P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
+  P.wt = wt;
+  P.partials = partials;
+  P.bw_raw = bw_raw; P.bw_scale = bw_scale; P.bw_shift = bw_shift; P.bw_mean = bw_mean; P.bw_invstd = bw_invstd;
+  P.Cin = Cin;
+  P.Cout = Cout;
+  P.Mpad = round_up(Cout, 64);
+  P.nchunks = ceil_div(Cin, 4);
+  P.mblocks = pl.mblocks;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp;
+  P.PS = round_up(P.WR * P.WCp, 4) + 4;   // + one bank group: the four channel planes of a k-step start 16 B apart (mod 4)
+  P.NPV = ceil_div(P.WR * P.WCp, 64);
+  GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: halo window too large");
+  const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
+  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
+  const size_t lds = (size_t)(2 * (W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W43_BM) * sizeof(float);
+  return launch_w43(P, (int)grid, lds, (hipStream_t)stream);
+}
+
+extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                               float* partials, int N, int H, int W, void* stream) {
+  return w43_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, stream);
+}
+
+extern "C" int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                            const float* raw, const float* scale, const float* shift, const float* mean,
+                                            const float* invstd, float* partials, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(dst && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w43_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w43_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
+  return w43_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream);
+}

@@ -52,9 +52,15 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
     case 0: *rows = round_up(Ci, 4) * 9; *M = Co; break;        // k = ci*9+t        m = co
     case 1: *rows = round_up(Co, 4) * 9; *M = Ci; break;        // k = co*9+t (flip) m = ci
     case 2: *rows = round_up(Ci, 16); *M = Co * 4; break;       // k = ci            m = co*4+khkw
-    default: *rows = round_up(Co, 4) * 4; *M = Ci; break;       // k = co*4+khkw     m = ci
+    case 3: *rows = round_up(Co, 4) * 4; *M = Ci; break;        // k = co*4+khkw     m = ci
+    case 4: *rows = round_up(Ci, 4) * 18; *M = Co; break;       // k = ci*18+r*6+f   m = co   (Winograd F(4,3) rows)
+    default: *rows = round_up(Co, 4) * 18; *M = Ci; break;      // k = co*18+r*6+f (flip) m = ci
   }
-  if (mode <= 1) {
+  if (mode >= 4) {
+    *BM = 64;
+    *pitch = 64;
+    *mblocks = ceil_div(*M, 64);
+  } else if (mode <= 1) {
     *BM = *M <= 64 ? 64 : 128;
     *pitch = *BM;
     *mblocks = ceil_div(*M, *BM);
@@ -65,7 +71,7 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
   }
 }
 extern "C" int64_t gsd_weight_layout_size(int mode, int Co, int Ci) {
-  if (mode < 0 || mode > 3 || Co <= 0 || Ci <= 0) return 0;
+  if (mode < 0 || mode > 5 || Co <= 0 || Ci <= 0) return 0;
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
   return (int64_t)mblocks * rows * pitch;
@@ -79,7 +85,7 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
     const int k = (int)(t % rows);
     const int mb = (int)(t / rows);
     int m = mb * BM + col;
-    if (mode <= 1) {  // un-permute: slot (l*4 + t) of a 64-column group holds column t*16 + l
+    if (mode <= 1 || mode >= 4) {  // un-permute: slot (l*4 + t) of a 64-column group holds column t*16 + l
       const int slot = col & 63;
       m = mb * BM + (col & ~63) + (slot & 3) * 16 + (slot >> 2);
     }
@@ -91,6 +97,22 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
       } else if (mode == 1) {
         const int co = k / 9, tp = k % 9;
         if (co < Co) v = w[((size_t)co * Ci + m) * 9 + (8 - tp)];
+      } else if (mode >= 4) {
+        // U = G g for the 3 taps g of kernel row r (dX: the flipped kernel, channels swapped), G of F(4,3):
+        // rows (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
+        const int kch = k / 18, rem = k % 18, r = rem / 6, f = rem % 6;
+        if (kch < (mode == 4 ? Ci : Co)) {
+          const float* g = mode == 4 ? w + ((size_t)m * Ci + kch) * 9 + r * 3 : w + ((size_t)kch * Ci + m) * 9 + (2 - r) * 3;
+          const float g0 = mode == 4 ? g[0] : g[2], g1 = g[1], g2 = mode == 4 ? g[2] : g[0];
+          switch (f) {
+            case 0: v = g0 * 0.25f; break;
+            case 1: v = -(g0 + g1 + g2) * (1.f / 6.f); break;
+            case 2: v = -(g0 - g1 + g2) * (1.f / 6.f); break;
+            case 3: v = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+            case 4: v = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+            default: v = g2; break;
+          }
+        }
       } else if (mode == 2) {
         if (k < Ci) v = w[(size_t)k * M + m];  // (Ci, Co*4) is already [k][m]
       } else {
@@ -102,7 +124,7 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
   }
 }
 extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
-  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 3 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
+  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 5 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
   const long long total = (long long)mblocks * rows * pitch;
@@ -179,33 +201,50 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
   }
 }
-// One-launch forms for a FEW partial rows (the persistent bf16 kernels write one row per block and wave: a few hundred):
-// a block owns 64 channels, its 16 row lanes sum the rows in a fixed order in fp64, then the same thread finalises.
-constexpr int RF_LANES = 16;
+// One-launch forms: a block owns 16 channels; its 64 row lanes (4 per wave x 16 waves) sum the partial rows in fp64 in a
+// fixed order (strided rows -> xor-shuffle inside the wave -> wave order in LDS), then 16 threads finalise.
 // `sums` still receives the per-channel totals (SyncBN and the tests read them).
+constexpr int RF_CH = 16, RF_LANES = 64;
+template <int NV>
+__device__ __forceinline__ bool rf_block_sums(const float* __restrict__ part, int rows, int ld, const int (&off)[NV], int C,
+                                              double (&v)[NV]) {
+  const int c = blockIdx.x * RF_CH + (threadIdx.x & (RF_CH - 1)), rl = threadIdx.x / RF_CH;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += RF_LANES) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (off[i] >= 0) v[i] += (double)part[(size_t)r * ld + off[i] + c];
+    }
+  __shared__ double red[NV][RF_LANES / 4][RF_CH];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] += __shfl_xor(v[i], 16);
+    v[i] += __shfl_xor(v[i], 32);
+    if ((threadIdx.x & 63) < RF_CH) red[i][threadIdx.x >> 6][threadIdx.x & 63] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x >= RF_CH || c >= C) return false;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double t = 0.0;
+    for (int w = 0; w < RF_LANES / 4; ++w) t += red[i][w][threadIdx.x];
+    v[i] = t;
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ part, int rows, int ld, int off2, int C,
                                                                  double* __restrict__ sums, double count, const float* gamma,
                                                                  const float* beta, float eps, float momentum, float* running_mean,
                                                                  float* running_var, float* mean, float* invstd, float* scale,
                                                                  float* shift) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += RF_LANES) {
-      s += (double)part[(size_t)r * ld + c];
-      q += (double)part[(size_t)r * ld + off2 + c];
-    }
-  __shared__ double red[2][RF_LANES][64];
-  red[0][rl][threadIdx.x & 63] = s;
-  red[1][rl][threadIdx.x & 63] = q;
-  __syncthreads();
-  if (rl != 0 || c >= C) return;
-  const int l = threadIdx.x;
-  s = q = 0.0;
-  for (int i = 0; i < RF_LANES; ++i) {
-    s += red[0][i][l];
-    q += red[1][i][l];
-  }
+  const int off[2] = {0, off2};
+  double v[2];
+  if (!rf_block_sums<2>(part, rows, ld, off, C, v)) return;
+  const int c = blockIdx.x * RF_CH + threadIdx.x;
+  const double s = v[0], q = v[1];
   sums[c] = s;
   sums[C + c] = q;
   const double mu = s / count;
@@ -230,7 +269,7 @@ extern "C" int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad,
               GSD_ERR_BAD_ARG, "gsd_bn_reduce_finalize: bad argument");
   GSD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GSD_ERR_BAD_ARG,
               "gsd_bn_reduce_finalize: running stats must come together");
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * RF_LANES), 0, (hipStream_t)stream, partials, rows, 2 * Mpad,
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, RF_CH)), dim3(RF_CH * RF_LANES), 0, (hipStream_t)stream, partials, rows, 2 * Mpad,
                      Mpad, C, sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   GSD_LAUNCH_CHECK("gsd_bn_reduce_finalize");
   return GSD_OK;
@@ -240,35 +279,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const floa
                                                                      int off3, int C, double* __restrict__ sums, double count,
                                                                      float* dgamma, float* dbeta, float* dwout, float* c1,
                                                                      float* c2) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  double s = 0.0, q = 0.0, w = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += RF_LANES) {
-      s += (double)part[(size_t)r * ld + c];
-      q += (double)part[(size_t)r * ld + off2 + c];
-      if (off3 >= 0) w += (double)part[(size_t)r * ld + off3 + c];
-    }
-  __shared__ double red[3][RF_LANES][64];
-  red[0][rl][threadIdx.x & 63] = s;
-  red[1][rl][threadIdx.x & 63] = q;
-  red[2][rl][threadIdx.x & 63] = w;
-  __syncthreads();
-  if (rl != 0 || c >= C) return;
-  const int l = threadIdx.x;
-  s = q = w = 0.0;
-  for (int i = 0; i < RF_LANES; ++i) {
-    s += red[0][i][l];
-    q += red[1][i][l];
-    w += red[2][i][l];
-  }
-  sums[c] = s;
-  sums[C + c] = q;
-  sums[2 * C + c] = w;
-  dbeta[c] = (float)s;
-  dgamma[c] = (float)q;
-  if (dwout != nullptr) dwout[c] = (float)w;
-  c1[c] = (float)(s / count);
-  c2[c] = (float)(q / count);
+  const int off[3] = {0, off2, off3};
+  double v[3];
+  if (!rf_block_sums<3>(part, rows, ld, off, C, v)) return;
+  const int c = blockIdx.x * RF_CH + threadIdx.x;
+  sums[c] = v[0];
+  sums[C + c] = v[1];
+  sums[2 * C + c] = v[2];
+  dbeta[c] = (float)v[0];
+  dgamma[c] = (float)v[1];
+  if (dwout != nullptr) dwout[c] = (float)v[2];
+  c1[c] = (float)(v[0] / count);
+  c2[c] = (float)(v[1] / count);
 }
 
 extern "C" int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int layout_mpad, int C, double* sums, double count,
@@ -280,7 +302,7 @@ extern "C" int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int l
   // layout_mpad == 0: rows of [sum dz | sum dz*xhat | third] (3*C) from the stand-alone reduce kernels;
   // layout_mpad  > 0: rows of 2*mpad from a dX epilogue (gsd_conv3x3_dgrad_bnrelu / gsd_bf16_bnbwd)
   const int ld = layout_mpad > 0 ? 2 * layout_mpad : 3 * C, off2 = layout_mpad > 0 ? layout_mpad : C;
-  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * RF_LANES), 0, (hipStream_t)stream, partials, rows, ld,
+  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(ceil_div(C, RF_CH)), dim3(RF_CH * RF_LANES), 0, (hipStream_t)stream, partials, rows, ld,
                      off2, layout_mpad > 0 ? -1 : 2 * C, C, sums, count, dgamma, dbeta, dwout, c1, c2);
   GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_finalize");
   return GSD_OK;

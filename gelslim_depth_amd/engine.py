@@ -32,6 +32,17 @@ def _r64(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
+class _ConvForm:
+    """Entry points and weight-layout modes of one of the two conv3x3 forms: 0 direct taps, 1 Winograd F(4,3) along rows."""
+
+    def __init__(self, algo: int):
+        self.algo = algo
+        self.conv = lib.gsd_conv3x3_w43 if algo else lib.gsd_conv3x3
+        self.dgrad_bnrelu = lib.gsd_conv3x3_w43_dgrad_bnrelu if algo else lib.gsd_conv3x3_dgrad_bnrelu
+        self.partial_rows = lib.gsd_conv3x3_w43_partial_rows if algo else lib.gsd_conv3x3_partial_rows
+        self.mode_f, self.mode_d = (4, 5) if algo else (0, 1)
+
+
 class _Unit:
     """conv3x3(no bias) + BatchNorm2d + ReLU (unet.py:11-13 / :14-16)."""
 
@@ -49,6 +60,8 @@ class _Unit:
         self.sums = None
         self.raw = self.g = None
         self.srcs = None  # gsd_src array kept for wgrad
+        self.form_f = self.form_d = None   # _ConvForm of the forward / dX launch for the current shape
+        self.fused_rows = 0                # partial rows written by the dX launch that produced this unit's dz
 
 
 class _Up:
@@ -126,9 +139,18 @@ class UNetEngine:
                 for nm in ("scale", "shift", "mean", "invstd", "c1", "c2"):
                     setattr(u, nm, torch.empty((u.cout,), **f32))
                 u.sums = torch.empty((65 * 3 * u.cout,), device=dev, dtype=torch.float64)
-                u.wt_f = torch.empty((lib.gsd_weight_layout_size(0, u.cout, u.cin),), **f32)
-                u.wt_d = torch.empty((lib.gsd_weight_layout_size(1, u.cout, u.cin),), **f32) if u.need_dgrad else None
-            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            # direct taps or Winograd F(4,3) rows, per layer shape and per direction (include/gsd.h: gsd_conv3x3_algo)
+            u.form_f = _ConvForm(lib.gsd_conv3x3_algo(n, lh, lw, u.cin, u.cout))
+            u.form_d = _ConvForm(lib.gsd_conv3x3_algo(n, lh, lw, u.cout, u.cin)) if u.need_dgrad else None
+            need = lib.gsd_weight_layout_size(u.form_f.mode_f, u.cout, u.cin)
+            if u.wt_f is None or u.wt_f.numel() != need or u.wt_f.device != dev:
+                u.wt_f = torch.empty((need,), **f32)
+            if u.need_dgrad:
+                need = lib.gsd_weight_layout_size(u.form_d.mode_d, u.cout, u.cin)
+                if u.wt_d is None or u.wt_d.numel() != need or u.wt_d.device != dev:
+                    u.wt_d = torch.empty((need,), **f32)
+                max_part = max(max_part, u.form_d.partial_rows(n, lh, lw, u.cin) * 2 * _r64(u.cin))
+            rows = u.form_f.partial_rows(n, lh, lw, u.cout)
             max_part = max(max_part, rows * 2 * _r64(u.cout))
             if train:
                 max_part = max(max_part, lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw) * 3 * u.cout)
@@ -158,16 +180,16 @@ class UNetEngine:
     def _run_unit(self, u: _Unit, srcs: List[L.gsd_src], P: Dict[str, torch.Tensor], train: bool, st: int) -> None:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_weight_layout(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
+        check(lib.gsd_weight_layout(u.form_f.mode_f, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
         arr = L.src_array(srcs)
         u.srcs = arr
         dst = L.dst_array([L.make_dst(u.raw)])
         part = self.partials.data_ptr() if train else None
         ev = self._log_begin()
-        check(lib.gsd_conv3x3(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
+        check(u.form_f.conv(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
         self._log_end(ev, u.cout, u.cin, n, lh, lw)
         if train:
-            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            rows = u.form_f.partial_rows(n, lh, lw, u.cout)
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
                   "bn_reduce_partials")
             count = float(n * lh * lw)
@@ -258,7 +280,7 @@ class UNetEngine:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
         if fused:
-            rows = lib.gsd_conv3x3_partial_rows(n, lh, lw, u.cout)
+            rows = u.fused_rows   # of the dX launch that wrote them (_dgrad_fused)
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
                   "bn_reduce_partials")
         else:
@@ -295,10 +317,10 @@ class UNetEngine:
     def _dgrad(self, u: _Unit, P, dsts: List[L.gsd_dst], st: int) -> None:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_weight_layout(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.src_array([L.make_src(u.g)])
         ev = self._log_begin()
-        check(lib.gsd_conv3x3(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
+        check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
               "conv3x3 dgrad")
         self._log_end(ev, u.cin, u.cout, n, lh, lw)
 
@@ -306,11 +328,12 @@ class UNetEngine:
         """dX of unit u straight into prev.g as dz of prev's relu(bn(.)) (+ partial sums): u's input is prev's output."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_weight_layout(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.make_src(u.g)
         d = L.make_dst(prev.g)
+        prev.fused_rows = u.form_d.partial_rows(n, lh, lw, u.cin)
         ev = self._log_begin()
-        check(lib.gsd_conv3x3_dgrad_bnrelu(C.byref(s), u.wt_d.data_ptr(), u.cout, u.cin, C.byref(d), prev.raw.data_ptr(),
+        check(u.form_d.dgrad_bnrelu(C.byref(s), u.wt_d.data_ptr(), u.cout, u.cin, C.byref(d), prev.raw.data_ptr(),
                                            prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
                                            prev.invstd.data_ptr(), self.partials.data_ptr(), n, lh, lw, st),
               "conv3x3_dgrad_bnrelu")

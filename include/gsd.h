@@ -76,6 +76,8 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * mode 1: conv3x3 dgrad     W[Co][Ci][3][3]  -> k = co*9+(8-t) flipped, m = ci
  * mode 2: convT   forward   W[Ci][Co][2][2]  -> k = ci,               m = co*4+kh*2+kw
  * mode 3: convT   dgrad     W[Ci][Co][2][2]  -> k = co*4+kh*2+kw,     m = ci
+ * mode 4: conv3x3 forward, Winograd F(4,3) rows: k = ci*18+r*6+f, m = co   (see gsd_conv3x3_w43)
+ * mode 5: conv3x3 dgrad,   Winograd F(4,3) rows: k = co*18+r*6+f (flipped kernel), m = ci
  * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM] with BM = 64 (M <= 64) or 128, columns
  * permuted inside each 64-group (slot l*4+t = column t*16+l), so one K-chunk of one m-block is a contiguous LDS
  * image whose A operands are aligned float4s; modes 2/3 are [k row][M rounded up to 64].
@@ -102,6 +104,20 @@ int gsd_conv3x3(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout
 int gsd_conv3x3_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
                              const float* raw, const float* scale, const float* shift, const float* mean,
                              const float* invstd, float* partials, int N, int H, int W, void* stream);
+
+/* The same two operators with the Winograd F(4,3) minimal-filtering identity along image rows (half the MFMA work,
+ * same fp32 storage and accumulation; weights from gsd_weight_layout modes 4 (forward) / 5 (dX):
+ * [m-block of 64][k row = ci*18 + r*6 + f][64], U = G g per kernel row r).  gsd_conv3x3_algo says which form the
+ * library prefers for a shape (0 direct, 1 Winograd: tile padding can eat the gain on small images); the caller
+ * lays the weights out for the form it calls.  Partial-row layout as gsd_conv3x3, its own row count. */
+int gsd_conv3x3_algo(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_w43_partial_rows(int N, int H, int W, int Cout);
+int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout,
+                    const gsd_dst* dst, int ndst, float* partials, int N, int H, int W, void* stream);
+int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                 const float* raw, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, float* partials, int N, int H, int W, void* stream);
 
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 2. */

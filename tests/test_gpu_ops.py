@@ -37,6 +37,21 @@ def layout(gsd, mode, w, co, ci):
     return wt
 
 
+class ConvForm:
+    """The two forms of the conv3x3 entry points: direct taps (gsd_conv3x3*) and Winograd F(4,3) rows (gsd_conv3x3_w43*)."""
+    def __init__(self, gsd, algo):
+        L = gsd.lib
+        self.conv = L.gsd_conv3x3_w43 if algo else L.gsd_conv3x3
+        self.dgrad_bnrelu = L.gsd_conv3x3_w43_dgrad_bnrelu if algo else L.gsd_conv3x3_dgrad_bnrelu
+        self.partial_rows = L.gsd_conv3x3_w43_partial_rows if algo else L.gsd_conv3x3_partial_rows
+        self.mode_f, self.mode_d = (4, 5) if algo else (0, 1)
+        # F(4,3) adds two roundings per operand in the transforms (constants up to 8 and 1/24)
+        self.tol = 1e-5 if algo else TOL
+
+
+ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["direct", "w43"])
+
+
 def test_mfma_lane_maps(gsd):
     rng = np.random.default_rng(0)
     a = rng.integers(-8, 9, (16, 4)).astype(np.float32)       # asymmetric integer operands: exact in fp32
@@ -48,24 +63,26 @@ def test_mfma_lane_maps(gsd):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 3, 64, 20, 33), (2, 8, 130, 13, 17), (1, 64, 64, 40, 53),
-                                         (3, 16, 200, 5, 4)])
-def test_conv3x3_plain(gsd, n, ci, co, h, w):
+                                         (3, 16, 200, 5, 4), (2, 12, 64, 33, 70)])
+@ALGOS
+def test_conv3x3_plain(gsd, algo, n, ci, co, h, w):
     from oracle import unet_numpy as on
+    F = ConvForm(gsd, algo)
     rng = np.random.default_rng(n * 1000 + ci)
     x, wt_ = rnd(rng, n, ci, h, w), rnd(rng, co, ci, 3, 3, scale=0.2)
     xd, wd = dev(x), dev(wt_)
     y = torch.full((n, co, h, w), float("nan"), device="cuda")
-    rows = gsd.lib.gsd_conv3x3_partial_rows(n, h, w, co)
+    rows = F.partial_rows(n, h, w, co)
     mpad = (co + 63) // 64 * 64
     part = torch.zeros(rows * 2 * mpad, device="cuda")
     src = gsd.src_array([gsd.make_src(xd)])
     dst = gsd.dst_array([gsd.make_dst(y)])
-    gsd.check(gsd.lib.gsd_conv3x3(src, 1, layout(gsd, 0, wd, co, ci).data_ptr(), ci, co, dst, 1, part.data_ptr(), n, h, w,
-                                  gsd.stream_ptr()))
+    gsd.check(F.conv(src, 1, layout(gsd, F.mode_f, wd, co, ci).data_ptr(), ci, co, dst, 1, part.data_ptr(), n, h, w,
+                     gsd.stream_ptr()))
     ref = on.conv3x3_fwd(x, wt_)
     got = y.cpu().numpy()
     assert np.isfinite(got).all(), "every output element must be written"
-    assert rel_l1(got, ref) < TOL
+    assert rel_l1(got, ref) < F.tol
     # BatchNorm partial sums -> (sum, sumsq) per channel
     sums = torch.zeros(65 * 2 * co, device="cuda", dtype=torch.float64)
     gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, co, sums.data_ptr(), gsd.stream_ptr()))
@@ -75,10 +92,12 @@ def test_conv3x3_plain(gsd, n, ci, co, h, w):
     np.testing.assert_allclose(s[co:], (r64 * r64).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
-def test_conv3x3_deferred_bn_two_segments_and_crop(gsd):
+@ALGOS
+def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo):
     """Consumer-side fusion: relu(bn(.)) on load, channel concat of two segments, F.pad offsets (unet.py:46-48);
     producer-side: two destinations with the crop that is F.pad's backward."""
     from oracle import unet_numpy as on
+    F = ConvForm(gsd, algo)
     rng = np.random.default_rng(7)
     n, c0, c1, co, h, w = 2, 6, 5, 9, 9, 11
     skip_raw = rnd(rng, n, c0, h, w)
@@ -93,20 +112,20 @@ def test_conv3x3_deferred_bn_two_segments_and_crop(gsd):
     scd, shd = dev(sc), dev(sh)
     y = torch.zeros((n, co, h, w), device="cuda")
     src = gsd.src_array([gsd.make_src(srd, scd, shd, relu=True), gsd.make_src(upd, off=(top, left))])
-    gsd.check(gsd.lib.gsd_conv3x3(src, 2, layout(gsd, 0, dev(wt_), co, c0 + c1).data_ptr(), c0 + c1, co,
-                                  gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
-    assert rel_l1(y.cpu().numpy(), ref) < TOL
+    gsd.check(F.conv(src, 2, layout(gsd, F.mode_f, dev(wt_), co, c0 + c1).data_ptr(), c0 + c1, co,
+                     gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
+    assert rel_l1(y.cpu().numpy(), ref) < F.tol
     # dgrad with split destinations: dX of the same conv, routed to (skip grad | cropped up grad)
     dy = rnd(rng, n, co, h, w)
     dxr, _ = on.conv3x3_bwd(np.concatenate([a0, upp], 1), wt_, dy)
     g_skip = torch.zeros((n, c0, h, w), device="cuda")
     g_up = torch.full((n, c1, 6, 8), float("nan"), device="cuda")
     dyd = dev(dy)
-    gsd.check(gsd.lib.gsd_conv3x3(gsd.src_array([gsd.make_src(dyd)]), 1, layout(gsd, 1, dev(wt_), co, c0 + c1).data_ptr(),
-                                  co, c0 + c1, gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))]), 2,
-                                  None, n, h, w, gsd.stream_ptr()))
-    assert rel_l1(g_skip.cpu().numpy(), dxr[:, :c0]) < TOL
-    assert rel_l1(g_up.cpu().numpy(), dxr[:, c0:, top:top + 6, left:left + 8]) < TOL
+    gsd.check(F.conv(gsd.src_array([gsd.make_src(dyd)]), 1, layout(gsd, F.mode_d, dev(wt_), co, c0 + c1).data_ptr(),
+                     co, c0 + c1, gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))]), 2,
+                     None, n, h, w, gsd.stream_ptr()))
+    assert rel_l1(g_skip.cpu().numpy(), dxr[:, :c0]) < F.tol
+    assert rel_l1(g_up.cpu().numpy(), dxr[:, c0:, top:top + 6, left:left + 8]) < F.tol
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 64, 64, 21, 29), (2, 20, 130, 6, 70), (1, 3, 16, 40, 53)])
@@ -352,9 +371,11 @@ def test_bad_arguments_are_refused(gsd):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 6, 9, 9, 11), (1, 64, 130, 21, 29)])
-def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, n, ci, co, h, w):
+@ALGOS
+def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, algo, n, ci, co, h, w):
     """gsd_conv3x3_dgrad_bnrelu == conv dX followed by gsd_bn_bwd_reduce(mode PLAIN): dz and (sum dz, sum dz*xhat)."""
     from oracle import unet_numpy as on
+    F = ConvForm(gsd, algo)
     rng = np.random.default_rng(co)
     # forward unit "prev": raw (n, ci, h, w) with its BN; this conv maps ci -> co
     raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, ci, h, w)
@@ -367,14 +388,14 @@ def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, n, ci, co, h, w):
     dyd, rawd = dev(dy), dev(raw)
     vecs = [dev(v) for v in (scale, shift, mean, invstd)]
     dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
-    rows = gsd.lib.gsd_conv3x3_partial_rows(n, h, w, ci)
+    rows = F.partial_rows(n, h, w, ci)
     mpad = (ci + 63) // 64 * 64
     part = torch.zeros(rows * 2 * mpad, device="cuda")
-    wl = layout(gsd, 1, dev(wt_), co, ci)
+    wl = layout(gsd, F.mode_d, dev(wt_), co, ci)
     s, d = gsd.make_src(dyd), gsd.make_dst(dz)
-    gsd.check(gsd.lib.gsd_conv3x3_dgrad_bnrelu(C.byref(s), wl.data_ptr(), co, ci, C.byref(d), rawd.data_ptr(),
-                                               *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, gsd.stream_ptr()))
-    assert rel_l1(dz.cpu().numpy(), dz_ref) < TOL
+    gsd.check(F.dgrad_bnrelu(C.byref(s), wl.data_ptr(), co, ci, C.byref(d), rawd.data_ptr(),
+                             *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, gsd.stream_ptr()))
+    assert rel_l1(dz.cpu().numpy(), dz_ref) < F.tol
     sums = torch.zeros(65 * 2 * ci, device="cuda", dtype=torch.float64)
     gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, ci, sums.data_ptr(), gsd.stream_ptr()))
     got = sums[:2 * ci].cpu().numpy()
