@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["gsd_conv3x3.hip", "gsd_conv3x3_w43.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_pointwise.hip", "gsd_dataset.hip", "gsd_bf16_conv.hip", "gsd_bf16_pointwise.hip", "gsd_bf16_wgrad.hip"]
+SOURCES = ["gsd_conv3x3.hip", "gsd_conv3x3_w43.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_wgrad_w43.hip", "gsd_pointwise.hip", "gsd_dataset.hip", "gsd_bf16_conv.hip", "gsd_bf16_pointwise.hip", "gsd_bf16_wgrad.hip"]
 OUT = os.path.join(CSRC, "libgsd.so")
 
 

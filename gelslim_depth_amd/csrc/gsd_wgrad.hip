@@ -655,9 +655,16 @@ int launch_dma(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+// Winograd F(4,3) form (gsd_wgrad_w43.hip): same arguments, same result layout; chosen per shape
+int gsd_wgrad_w43_use(int N, int H, int W, int Cin, int Cout);
+int64_t gsd_wgrad_w43_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw, float* workspace,
+                      int64_t workspace_elems, int N, int H, int W, void* stream);
+
 extern "C" int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  return plan_wgrad(0, N, H, W, Cout, Cin).slab_elems;
+  const int64_t direct = plan_wgrad(0, N, H, W, Cout, Cin).slab_elems, wino = gsd_wgrad_w43_workspace(N, H, W, Cin, Cout);
+  return direct > wino ? direct : wino;   // either form may serve the call (GSD_WGRAD_ALGO)
 }
 
 extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw,
@@ -676,6 +683,14 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
   GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: activation segments hold %d channels, Cin=%d", csum, Cin);
   if (int e = check_plain(*dy, "gsd_conv3x3_wgrad dy")) return e;
   GSD_REQUIRE(dy->C == Cout && dy->H == H && dy->W == W, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: dy must be (Cout,H,W)");
+  for (int i = 0; i < nsrc; ++i)
+    GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
+                "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
+  GSD_REQUIRE(workspace_elems >= gsd_conv3x3_wgrad_workspace(N, H, W, Cin, Cout), GSD_ERR_WORKSPACE,
+              "gsd_conv3x3_wgrad: workspace %lld < %lld elements", (long long)workspace_elems,
+              (long long)gsd_conv3x3_wgrad_workspace(N, H, W, Cin, Cout));
+  if (gsd_wgrad_w43_use(N, H, W, Cin, Cout))
+    return gsd_wgrad_w43_run(a, nsrc, dy, Cin, Cout, dw, workspace, workspace_elems, N, H, W, stream);
   WgradPlan pl = plan_wgrad(0, N, H, W, Cout, Cin);
   GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_conv3x3_wgrad: workspace %lld < %lld elements",
               (long long)workspace_elems, (long long)pl.slab_elems);

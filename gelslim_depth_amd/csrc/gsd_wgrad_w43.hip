@@ -1,0 +1,385 @@
+// gsd_wgrad_w43.hip -- dW of conv3x3 with the transposed Winograd F(4,3) identity along image rows (gfx950).
+//
+//   dW[co][ci][r][s] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+r-1,w+s-1]
+//
+// (the dW half of aten::convolution_backward for /root/reference/gelslim_depth/models/unet.py:11,14).  The forward
+// identity y = A^T[(G g) .* (B^T d)] is linear in g, so for every tile of 4 horizontally adjacent outputs
+//
+//   dg = G^T [ (A dy) .* (B^T d) ]
+//
+// with the SAME input transform B^T d as the forward kernel (gsd_conv3x3_w43.hip), dy transformed by A (4 -> 6 values)
+// and G^T applied once at the very end.  Per (co, ci, kernel row r) and tile that is 6 products instead of 12:
+//
+//   D_{f,r}[co][ci] = sum_tiles U_f[co][tile] * V_{f,r}[tile][ci]          (18 accumulators per (co,ci) instead of 9)
+//   dW[co][ci][r][s] = sum_f G[f][s] * D_{f,r}[co][ci]                      (wgrad_w43_reduce_kernel, after the split sum)
+//
+// GEMM view: M = co, N = ci, K = tiles (4 per v_mfma_f32_16x16x4_f32).  Block = 4 waves, tile 64 co x 32 ci; wave tile
+// 32 co x 16 ci x 18 = 144 accumulator registers.  A stage is 16 tiles (64 pixels, TH rows x TW columns): dy rows
+// [co][64 px, tile-major] and the activation halo windows [ci][(TH+2) x (TW+2)] reach LDS by global_load_lds (dword
+// gathers, zero padding / out-of-segment positions from a sentinel: NaN under a ReLU, else 0), double buffered, two
+// blocks per CU.  The deferred BatchNorm+ReLU of the activation is applied after the ds_read (a lane's input channel is
+// fixed), then B^T; A dy needs 9 VALU operations per 4 values.  Split-K over stages with ordered slab reduction as in
+// gsd_wgrad.hip: bitwise reproducible.
+#include "gsd_common.h"
+
+#include <cstdlib>
+
+__device__ const float gsd_pad_wg43[2] = {0.f, __builtin_nanf("")};
+
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+struct WgW43Params {
+  SrcD a0, a1;  // activation (B operand), up to two concatenated segments
+  SrcD dy;      // gradient w.r.t. the raw conv output (plain)
+  float* slabs; // [split][18 = r*6+f][M][Ncols]
+  int M, Ncols;
+  int N, H, W;
+  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS;
+  int stages_total, splits, mblocks, nblocks;
+};
+
+namespace {
+constexpr int WG_BM = 64, WG_BN = 32, WG_DS = 68;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_w43_kernel(const WgW43Params P) {
+  constexpr int BM = WG_BM, BN = WG_BN, DS = WG_DS, MT = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XS = P.XS;
+  const int BUF = BM * DS + BN * XS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int per_split = P.mblocks * P.nblocks;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const int s_begin = (int)((long long)split * P.stages_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
+
+  // ---- DMA lane geometry -------------------------------------------------------------------------------------------------
+  // A: lane = pixel (tile t = lane>>2, element lane&3) of the stage in tile-major order
+  const int a_t = lane >> 2;
+  const int a_r = a_t / P.TWq;
+  const int a_c = (a_t - a_r * P.TWq) * 4 + (lane & 3);
+  // B: window positions p*64 + lane -> (row, column) of the padded window
+  int b_rr[4], b_cc[4];
+  bool b_ok[4];
+  const int npv = (P.WR * P.WCp + 63) >> 6;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int pos = p * 64 + lane;
+    b_rr[p] = pos / P.WCp;
+    b_cc[p] = pos - b_rr[p] * P.WCp;
+    b_ok[p] = p < npv && b_rr[p] < P.WR && b_cc[p] < P.WC;
+  }
+
+  // deferred BatchNorm+ReLU of this lane's input channel
+  float sc = 1.f, sh = 0.f, lo = -__builtin_inff();
+  {
+    const int c = n0 + wn * 16 + l16;
+    const bool first = c < P.a0.C;
+    const SrcD& S = first ? P.a0 : P.a1;
+    const int cc = first ? c : c - P.a0.C;
+    if (c < P.Ncols && cc < S.C) {
+      if (S.scale != nullptr) {
+        sc = S.scale[cc];
+        sh = S.shift[cc];
+      }
+      if (S.relu) lo = 0.f;
+    }
+  }
+
+  // Address arithmetic is kept out of the per-instruction path (the kernel is VALU-bound next to 144 MFMAs per stage): per
+  // stage one scalar window origin per segment, per lane the constants above; a stage whose window lies inside the
+  // segment ("interior", the common case) needs no per-lane validity at all, a border stage computes it once per segment.
+  auto issue_dma = [&](int stage, int buf) {
+    const int tpi = P.tiles_y * P.tiles_x;
+    const int n = stage / tpi;
+    const int rs = stage - n * tpi;
+    const int ty = rs / P.tiles_x;
+    const int h0 = ty * P.TH, w0 = (rs - ty * P.tiles_x) * P.TW;
+    float* Ab = smem + buf * BUF;
+    float* Bb = Ab + BM * DS;
+#ifdef WG43_ABL
+    const bool skipA = ((WG43_ABL) & 1) && stage > s_begin + 1, skipB = ((WG43_ABL) & 2) && stage > s_begin + 1;
+#else
+    const bool skipA = false, skipB = false;
+#endif
+    // ---- A: dy rows ----
+    {
+      const bool inside = h0 + P.TH <= P.H && w0 + P.TW <= P.W;
+      const bool pix_ok = (h0 + a_r) < P.H && (w0 + a_c) < P.W;
+      const int aoff = (h0 + a_r) * P.dy.W + (w0 + a_c);
+      const float* rbase = P.dy.p + (long long)n * P.dy.ns + (long long)(m0 + wave) * P.dy.cs;
+      const long long rstep = 4 * P.dy.cs;
+      const int nrows = skipA ? 0 : BM / 4;
+      if (inside && m0 + BM <= P.M) {
+#pragma unroll 4
+        for (int i = 0; i < nrows; ++i) {
+          __builtin_amdgcn_global_load_lds(rbase + aoff, Ab + (wave + 4 * i) * DS, 4, 0, 0);
+          rbase += rstep;
+        }
+      } else {
+#pragma unroll 4
+        for (int i = 0; i < nrows; ++i) {
+          const float* g = (pix_ok && m0 + wave + 4 * i < P.M) ? rbase + aoff : &gsd_pad_wg43[0];
+          __builtin_amdgcn_global_load_lds(g, Ab + (wave + 4 * i) * DS, 4, 0, 0);
+          rbase += rstep;
+        }
+      }
+    }
+    // ---- B: activation windows ----
+    // (named scalars, not arrays: an array indexed by the segment lands in scratch memory, with a vmcnt(0) per access)
+    const int hsA = h0 - 1 - P.a0.oh, wsA = w0 - 1 - P.a0.ow, hsB = h0 - 1 - P.a1.oh, wsB = w0 - 1 - P.a1.ow;
+    const int woA = hsA * P.a0.W + wsA, woB = hsB * P.a1.W + wsB;
+    const bool inA = hsA >= 0 && hsA + P.WR <= P.a0.H && wsA >= 0 && wsA + P.WC <= P.a0.W;
+    const bool inB = hsB >= 0 && hsB + P.WR <= P.a1.H && wsB >= 0 && wsB + P.WC <= P.a1.W;
+    int vmA = 0, vmB = 0;   // border stages: bit p = position p*64+lane exists in the segment
+    if (!inA) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if ((unsigned)(hsA + b_rr[p]) < (unsigned)P.a0.H && (unsigned)(wsA + b_cc[p]) < (unsigned)P.a0.W) vmA |= 1 << p;
+    }
+    if (!inB && P.a1.C > 0) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if ((unsigned)(hsB + b_rr[p]) < (unsigned)P.a1.H && (unsigned)(wsB + b_cc[p]) < (unsigned)P.a1.W) vmB |= 1 << p;
+    }
+    const int nch = skipB ? 0 : BN / 4;
+#pragma unroll 2
+    for (int i = 0; i < nch; ++i) {
+      const int ch = wave + 4 * i;
+      const int c = n0 + ch;
+      const bool first = c < P.a0.C;
+      const SrcD& S = first ? P.a0 : P.a1;
+      const int cc = first ? c : c - P.a0.C;
+      const bool c_ok = c < P.Ncols && cc < S.C;
+      const int Wd = first ? P.a0.W : P.a1.W;
+      float* Xd = Bb + ch * XS;
+      const float* cbase = S.p + (long long)n * S.ns + (long long)(c_ok ? cc : 0) * S.cs + (first ? woA : woB);
+      if (c_ok && (first ? inA : inB)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (b_ok[p]) __builtin_amdgcn_global_load_lds(cbase + (b_rr[p] * Wd + b_cc[p]), Xd + p * 64, 4, 0, 0);
+      } else {
+        const float* sentinel = (c_ok && S.relu) ? &gsd_pad_wg43[1] : &gsd_pad_wg43[0];
+        const int m = c_ok ? (first ? vmA : vmB) : 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (b_ok[p])
+            __builtin_amdgcn_global_load_lds((m >> p & 1) ? cbase + (b_rr[p] * Wd + b_cc[p]) : sentinel, Xd + p * 64, 4, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][18];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 18; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operand addresses of the 4 k-steps of a stage: k-step ks multiplies tiles 4*ks + j
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int t = 4 * ks + j;
+    const int trow = t / P.TWq, tq = t - trow * P.TWq;
+    a_off[ks] = (wm * 32 + l16) * DS + 4 * t;
+    b_off[ks] = BM * DS + (wn * 16 + l16) * XS + trow * P.WCp + 4 * tq;
+  }
+
+  auto compute = [&](int cur) {
+    const float* Sb = smem + cur * BUF;
+    f32x4 ya[2][MT];
+    f32x4 ra[2][3];
+    f32x2w rb[2][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ya[0][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[0] + m * 16 * DS]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ra[0][r] = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + r * P.WCp]);
+      rb[0][r] = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + r * P.WCp + 4]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cb = ks & 1, nb2 = cb ^ 1;
+      if (ks + 1 < 4) {   // the next k-step's raw operands fly during this one's transforms and MFMAs
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ya[nb2][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[ks + 1] + m * 16 * DS]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          ra[nb2][r] = *reinterpret_cast<const f32x4*>(&Sb[b_off[ks + 1] + r * P.WCp]);
+          rb[nb2][r] = *reinterpret_cast<const f32x2w*>(&Sb[b_off[ks + 1] + r * P.WCp + 4]);
+        }
+      }
+      float U[MT][6], V[3][6];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {   // U = A dy
+        const float y0 = ya[cb][m][0], y1 = ya[cb][m][1], y2 = ya[cb][m][2], y3 = ya[cb][m][3];
+        const float p = y0 + y2, q = y1 + y3;
+        const float a = fmaf(4.f, y2, y0), b = 2.f * fmaf(4.f, y3, y1);
+        U[m][0] = y0;
+        U[m][1] = p + q;
+        U[m][2] = p - q;
+        U[m][3] = a + b;
+        U[m][4] = a - b;
+        U[m][5] = y3;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {    // V = B^T relu(bn(raw))
+        const float d0 = fmaxf(fmaf(ra[cb][r][0], sc, sh), lo), d1 = fmaxf(fmaf(ra[cb][r][1], sc, sh), lo);
+        const float d2 = fmaxf(fmaf(ra[cb][r][2], sc, sh), lo), d3 = fmaxf(fmaf(ra[cb][r][3], sc, sh), lo);
+        const float d4 = fmaxf(fmaf(rb[cb][r][0], sc, sh), lo), d5 = fmaxf(fmaf(rb[cb][r][1], sc, sh), lo);
+        const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+        const float c = d4 - d2, e = 2.f * (d3 - d1);
+        V[r][0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+        V[r][1] = a + b;
+        V[r][2] = a - b;
+        V[r][3] = c + e;
+        V[r][4] = c - e;
+        V[r][5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[r][f], acc[m][r * 6 + f]);
+    }
+  };
+
+  const int nst = s_end - s_begin;
+  if (nst > 0) issue_dma(s_begin, 0);
+  for (int it = 0; it < nst; ++it) {
+    const int cur = it & 1;
+    gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
+    if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+    compute(cur);
+  }
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int mr = m0 + wm * 32 + m * 16 + j * 4 + reg;
+      const int col = n0 + wn * 16 + l16;
+      if (mr < P.M && col < P.Ncols) {
+#pragma unroll
+        for (int t = 0; t < 18; ++t) P.slabs[(((size_t)split * 18 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
+      }
+    }
+}
+
+// slab[split][r*6+f][co][ci] -> dW[co][ci][r][s] = sum_f G[f][s] * (sum over splits, in split order)
+__global__ void wgrad_w43_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int M, int Ncols) {
+  const long long plane = (long long)M * Ncols;
+  const long long total = 3 * plane;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / plane);
+    const long long mc = e - r * plane;
+    float D[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += slabs[((size_t)k * 18 + r * 6 + f) * plane + mc];
+      D[f] = s;
+    }
+    float* o = dw + (size_t)mc * 9 + r * 3;
+    o[0] = 0.25f * D[0] - (1.f / 6.f) * (D[1] + D[2]) + (1.f / 24.f) * (D[3] + D[4]);
+    o[1] = (1.f / 6.f) * (D[2] - D[1]) + (1.f / 12.f) * (D[3] - D[4]);
+    o[2] = (1.f / 6.f) * (D[3] + D[4] - D[1] - D[2]) + D[5];
+  }
+}
+
+namespace {
+
+struct WgW43Plan {
+  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS, mblocks, nblocks, stages_total, splits;
+  int64_t slab_elems;
+};
+
+WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
+  WgW43Plan p;
+  long best = -1;
+  for (int tw = 4; tw <= 64; tw *= 2) {   // 16 tiles = TH rows x TW/4 tiles
+    const int th = 64 / tw;
+    const long tiles = (long)ceil_div(H, th) * ceil_div(W, tw);
+    const long cost = tiles * 1000 + (th + 2) * round_up(tw + 2, 4);   // fewest stages, then the smallest halo window
+    if (best < 0 || cost < best) {
+      best = cost;
+      p.TH = th; p.TW = tw;
+    }
+  }
+  p.TWq = p.TW / 4;
+  p.tiles_y = ceil_div(H, p.TH);
+  p.tiles_x = ceil_div(W, p.TW);
+  p.WR = p.TH + 2; p.WC = p.TW + 2; p.WCp = round_up(p.WC, 4);
+  p.XS = round_up(p.WR * p.WCp, 8) + 4;   // channel stride = 4 mod 8 floats: the 16 channels of a ds_read_b128 hit 16 different bank groups
+  p.mblocks = ceil_div(M, WG_BM);
+  p.nblocks = ceil_div(Ncols, WG_BN);
+  p.stages_total = N * p.tiles_y * p.tiles_x;
+  static const int target = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;
+  int splits = ceil_div(target, p.mblocks * p.nblocks);
+  if (splits > p.stages_total) splits = p.stages_total;
+  if (splits > 2048) splits = 2048;
+  if (splits < 1) splits = 1;
+  p.splits = splits;
+  p.slab_elems = (int64_t)splits * 18 * M * Ncols;
+  return p;
+}
+
+}  // namespace
+
+// 1: gsd_conv3x3_wgrad serves this shape with the Winograd form.  GSD_WGRAD_ALGO=0|1 forces one (tuning, A/B runs).
+int gsd_wgrad_w43_use(int N, int H, int W, int Cin, int Cout) {
+  static const int forced = getenv("GSD_WGRAD_ALGO") ? atoi(getenv("GSD_WGRAD_ALGO")) : -1;
+  if (forced == 0) return 0;
+  if (forced == 1) return 1;
+  return Cin >= 16 && Cout >= 16;   // the 3-channel first layer keeps the pixel-split direct kernel
+}
+
+int64_t gsd_wgrad_w43_workspace(int N, int H, int W, int Cin, int Cout) { return plan_wg43(N, H, W, Cout, Cin).slab_elems; }
+
+// arguments already validated by gsd_conv3x3_wgrad
+int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw, float* workspace,
+                      int64_t workspace_elems, int N, int H, int W, void* stream) {
+  const WgW43Plan pl = plan_wg43(N, H, W, Cout, Cin);
+  GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_conv3x3_wgrad: workspace %lld < %lld elements",
+              (long long)workspace_elems, (long long)pl.slab_elems);
+  WgW43Params P;
+  P.a0 = to_srcd(a[0]);
+  P.a1 = nsrc > 1 ? to_srcd(a[1]) : null_srcd();
+  P.dy = to_srcd(*dy);
+  P.slabs = workspace;
+  P.M = Cout; P.Ncols = Cin;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp; P.XS = pl.XS;
+  P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
+  GSD_REQUIRE(pl.WR * pl.WCp <= 256, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: halo window too large");
+  const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
+  const size_t lds = (size_t)2 * (WG_BM * WG_DS + WG_BN * pl.XS) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_w43_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad3x3_w43_kernel, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
+  const long long per = 3LL * Cout * Cin;
+  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+  hipLaunchKernelGGL(wgrad_w43_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43) reduce");
+  return GSD_OK;
+}
