@@ -168,25 +168,35 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        # dominant kernel: the 128x128-tile conv3x3 implicit GEMM (forward + dgrad of every layer with >64 out channels)
-        dom = "conv3x3_dma_kernel<2,2>" if args.dtype == "f32" else "bf16_conv3x3"
+        # dominant kernel: the conv3x3 kernel (forward + dX launches) with the largest share of the timed region.
+        # klog rows: (kernel, algorithmic flops, event, event, shape[, flops executed by the MFMAs])
+        klog = [r if len(r) > 5 else tuple(r) + (r[1],) for r in klog]
         peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-        flops = sum(f for v, f, _, _, _ in klog if v == dom)
-        ms = sum(a.elapsed_time(b) for v, _, a, b, _ in klog if v == dom)
-        launches = sum(1 for v, _, _, _, _ in klog if v == dom)
-        all_flops = sum(f for _, f, _, _, _ in klog)
-        all_ms = sum(a.elapsed_time(b) for _, _, a, b, _ in klog)
+        by_kernel = {}
+        for v, f, a, b, _, ex in klog:
+            d = by_kernel.setdefault(v, [0.0, 0.0, 0, 0.0])
+            d[0] += f
+            d[1] += a.elapsed_time(b)
+            d[2] += 1
+            d[3] += ex
+        if args.dtype == "f32":
+            dom = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else "conv3x3_w43_kernel"
+        else:
+            dom = "bf16_conv3x3"
+        flops, ms, launches, executed = by_kernel.get(dom, [0.0, 0.0, 0, 0.0])
+        all_flops = sum(r[1] for r in klog)
+        all_ms = sum(r[2].elapsed_time(r[3]) for r in klog)
         if args.per_layer:
             import collections
             agg = collections.OrderedDict()
-            for v, f, a, b, sig in klog:
+            for v, f, a, b, sig, _ in klog:
                 d = agg.setdefault(sig, [0.0, 0.0, 0])
                 d[0] += f
                 d[1] += a.elapsed_time(b)
                 d[2] += 1
             if args.dtype == "bf16":
                 byname = collections.OrderedDict()
-                for v, f, a, b, _ in klog:
+                for v, f, a, b, _, _ in klog:
                     d = byname.setdefault(v, [0.0, 0.0, 0])
                     d[0] += f
                     d[1] += a.elapsed_time(b)
@@ -234,6 +244,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
+                         # achieved = ALGORITHMIC flops (2*9*Cout*Cin per pixel) / time.  The Winograd F(4,3) kernel executes
+                         # half of them (+ tile padding), so frac can exceed 1; mfma_frac = flops its MFMAs actually issued
+                         # / time / peak is the matrix-core utilisation.
+                         "mfma_executed": round(executed / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+                         "mfma_frac": round(executed / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else 0.0,
                          "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
                          "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,

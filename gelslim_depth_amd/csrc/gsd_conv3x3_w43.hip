@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane >> 4, l16 = lane & 15;
 
-  const int mb = blockIdx.x % P.mblocks;
-  const int pt = blockIdx.x / P.mblocks;
+  // The m-blocks of one pixel tile read the same halo: hardware deals blocks round-robin over the 8 XCDs, so give every XCD
+  // a contiguous range of logical ids (pixel tile major, m-block minor) and its L2 serves the halo once.
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int mb = lid % P.mblocks;
+  const int pt = lid / P.mblocks;
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
   const int n = pt / tpi;
@@ -376,11 +379,15 @@ struct W43Plan {
   int TH, TW, TWq, tiles_y, tiles_x, mblocks, WR, WC, WCp;
 };
 
-// TH x TW output tile of 64 Winograd tiles (TW a multiple of 4, TH*TW <= 256) whose padded halo window fits the 512 DMA
-// positions: fewest blocks first, then the widest rows (longer coalesced row segments).
+// TH x TW output tile of 64 Winograd tiles (TH*TW <= 256) whose padded halo window fits the 512 DMA positions.  Every
+// block does the work of 64 tiles whatever it covers, so: fewest blocks; among equals 32-wide rows, then the widest
+// (measured over TW = 4..64, profiles/bench_conv_forms.py with GSD_W43_TW: widths that are not a power of two lose more in
+// the kernel than their tighter fit saves).
 bool plan_w43(int H, int W, int M, W43Plan* best) {
-  long best_tiles = -1;
-  for (int tw = 4; tw <= 64; tw += 4) {
+  long best_cost = -1;
+  static const int force_tw = getenv("GSD_W43_TW") ? atoi(getenv("GSD_W43_TW")) : 0;   // tuning
+  for (int tw = 4; tw <= 64; tw *= 2) {
+    if (force_tw && tw != force_tw) continue;
     int th = 256 / tw;
     const int wcp = round_up(tw + 2, 4);
     while (th > 1 && (th + 2) * wcp > 512) --th;
@@ -388,16 +395,16 @@ bool plan_w43(int H, int W, int M, W43Plan* best) {
     if (th > H) th = H;
     const int ty = ceil_div(H, th);
     th = ceil_div(H, ty);
-    const long tiles = (long)ty * ceil_div(W, tw);
-    if (best_tiles < 0 || tiles <= best_tiles) {
-      best_tiles = tiles;
+    const long cost = (long)ty * ceil_div(W, tw) * 4 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
       best->TH = th; best->TW = tw; best->TWq = tw / 4;
       best->tiles_y = ty; best->tiles_x = ceil_div(W, tw);
       best->WR = th + 2; best->WC = tw + 2; best->WCp = wcp;
     }
   }
   best->mblocks = ceil_div(M, W43_BM);
-  return best_tiles > 0;
+  return best_cost >= 0;
 }
 
 int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {

@@ -307,10 +307,14 @@ struct WgW43Plan {
 WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   WgW43Plan p;
   long best = -1;
+  static const int force_tw = getenv("GSD_WG43_TW") ? atoi(getenv("GSD_WG43_TW")) : 0;   // tuning
   for (int tw = 4; tw <= 64; tw *= 2) {   // 16 tiles = TH rows x TW/4 tiles
+    if (force_tw && tw != force_tw) continue;
     const int th = 64 / tw;
     const long tiles = (long)ceil_div(H, th) * ceil_div(W, tw);
-    const long cost = tiles * 1000 + (th + 2) * round_up(tw + 2, 4);   // fewest stages, then the smallest halo window
+    // fewest stages, weighted by what a stage of that shape costs (measured, profiles/bench_wgrad_forms.py with
+    // GSD_WG43_TW: 4 x 16 is the cheapest, 8 x 8 and 2 x 32 are ~7 % dearer, 1 x 64 and 16 x 4 much dearer)
+    const long cost = tiles * (tw == 16 ? 100 : (tw == 8 || tw == 32) ? 107 : 160);
     if (best < 0 || cost < best) {
       best = cost;
       p.TH = th; p.TW = tw;

@@ -187,7 +187,7 @@ class UNetEngine:
         part = self.partials.data_ptr() if train else None
         ev = self._log_begin()
         check(u.form_f.conv(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
-        self._log_end(ev, u.cout, u.cin, n, lh, lw)
+        self._log_end(ev, u.cout, u.cin, n, lh, lw, u.form_f.algo)
         if train:
             rows = u.form_f.partial_rows(n, lh, lw, u.cout)
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
@@ -213,13 +213,20 @@ class UNetEngine:
         e.record()
         return e
 
-    def _log_end(self, ev, m: int, k_ch: int, n: int, lh: int, lw: int) -> None:
+    def _log_end(self, ev, m: int, k_ch: int, n: int, lh: int, lw: int, algo: int = 0) -> None:
+        """(kernel, ALGORITHMIC flops of the convolution = 2*9*M*K*pixels, events, shape, flops the MFMAs executed)."""
         if ev is None:
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        variant = "conv3x3_dma_kernel<1,4>" if m <= 64 else "conv3x3_dma_kernel<2,2>"
-        self.kernel_log.append((variant, 2.0 * m * k_ch * 9 * n * lh * lw, ev, e, (m, k_ch, lh, lw)))
+        flops = 2.0 * m * k_ch * 9 * n * lh * lw
+        if algo:
+            variant = "conv3x3_w43_kernel"
+            executed = 2048.0 * lib.gsd_conv3x3_w43_mfma_count(n, lh, lw, k_ch, m)   # one v_mfma_f32_16x16x4_f32 = 2048 flops
+        else:
+            variant = "conv3x3_dma_kernel<1,4>" if m <= 64 else "conv3x3_dma_kernel<2,2>"
+            executed = flops
+        self.kernel_log.append((variant, flops, ev, e, (m, k_ch, lh, lw), executed))
 
     def _pad_off(self, lvl: int) -> Tuple[int, int]:
         # F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet.py:43-47)
@@ -322,7 +329,7 @@ class UNetEngine:
         ev = self._log_begin()
         check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
               "conv3x3 dgrad")
-        self._log_end(ev, u.cin, u.cout, n, lh, lw)
+        self._log_end(ev, u.cin, u.cout, n, lh, lw, u.form_d.algo)
 
     def _dgrad_fused(self, u: _Unit, prev: _Unit, P, st: int) -> None:
         """dX of unit u straight into prev.g as dz of prev's relu(bn(.)) (+ partial sums): u's input is prev's output."""
@@ -337,7 +344,7 @@ class UNetEngine:
                                            prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
                                            prev.invstd.data_ptr(), self.partials.data_ptr(), n, lh, lw, st),
               "conv3x3_dgrad_bnrelu")
-        self._log_end(ev, u.cin, u.cout, n, lh, lw)
+        self._log_end(ev, u.cin, u.cout, n, lh, lw, u.form_d.algo)
 
     def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
         """dout: (N, n_classes, H, W) gradient of the loss w.r.t. the output.
