@@ -13,11 +13,11 @@
 //   D_{f,r}[co][ci] = sum_tiles U_f[co][tile] * V_{f,r}[tile][ci]          (18 accumulators per (co,ci) instead of 9)
 //   dW[co][ci][r][s] = sum_f G[f][s] * D_{f,r}[co][ci]                      (wgrad_w43_reduce_kernel, after the split sum)
 //
-// GEMM view: M = co, N = ci, K = tiles (4 per v_mfma_f32_16x16x4_f32).  Block = 4 waves, tile 64 co x 32 ci; wave tile
+// GEMM view: M = co, N = ci, K = tiles (4 per v_mfma_f32_16x16x4_f32).  Block = 4 or 8 waves (see the kernel); wave tile
 // 32 co x 16 ci x 18 = 144 accumulator registers.  A stage is 16 tiles (64 pixels, TH rows x TW columns): dy rows
 // [co][64 px, tile-major] and the activation halo windows [ci][(TH+2) x (TW+2)] reach LDS by global_load_lds (dword
 // gathers, zero padding / out-of-segment positions from a sentinel: NaN under a ReLU, else 0), double buffered, two
-// blocks per CU.  The deferred BatchNorm+ReLU of the activation is applied after the ds_read (a lane's input channel is
+// waves per SIMD.  The deferred BatchNorm+ReLU of the activation is applied after the ds_read (a lane's input channel is
 // fixed), then B^T; A dy needs 9 VALU operations per 4 values.  Split-K over stages with ordered slab reduction as in
 // gsd_wgrad.hip: bitwise reproducible.
 #include "gsd_common.h"
@@ -39,18 +39,22 @@ struct WgW43Params {
 };
 
 namespace {
-constexpr int WG_BM = 64, WG_BN = 32, WG_DS = 68;
+constexpr int WG_DS = 68;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_w43_kernel(const WgW43Params P) {
-  constexpr int BM = WG_BM, BN = WG_BN, DS = WG_DS, MT = 2;
+// NWM x NWN waves of 32 co x 16 ci: (2,2) block 64 co x 32 ci, 4 waves, two blocks per CU; (4,2) 128 co x 32 ci and (2,4)
+// 64 co x 64 ci, 8 waves, one block per CU: one operand's tile is then amortised over twice the MFMAs (24 instead of 32
+// DMA instructions per wave and stage; measured 8 % faster than two 4-wave blocks).
+template <int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
+  constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
   const int BUF = BM * DS + BN * XS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int j = lane >> 4, l16 = lane & 15;
 
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -117,19 +121,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_w43_kernel(const WgW43Params 
       const bool pix_ok = (h0 + a_r) < P.H && (w0 + a_c) < P.W;
       const int aoff = (h0 + a_r) * P.dy.W + (w0 + a_c);
       const float* rbase = P.dy.p + (long long)n * P.dy.ns + (long long)(m0 + wave) * P.dy.cs;
-      const long long rstep = 4 * P.dy.cs;
-      const int nrows = skipA ? 0 : BM / 4;
+      const long long rstep = (long long)NW * P.dy.cs;
+      const int nrows = skipA ? 0 : BM / NW;
       if (inside && m0 + BM <= P.M) {
 #pragma unroll 4
         for (int i = 0; i < nrows; ++i) {
-          __builtin_amdgcn_global_load_lds(rbase + aoff, Ab + (wave + 4 * i) * DS, 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(rbase + aoff, Ab + (wave + NW * i) * DS, 4, 0, 0);
           rbase += rstep;
         }
       } else {
 #pragma unroll 4
         for (int i = 0; i < nrows; ++i) {
-          const float* g = (pix_ok && m0 + wave + 4 * i < P.M) ? rbase + aoff : &gsd_pad_wg43[0];
-          __builtin_amdgcn_global_load_lds(g, Ab + (wave + 4 * i) * DS, 4, 0, 0);
+          const float* g = (pix_ok && m0 + wave + NW * i < P.M) ? rbase + aoff : &gsd_pad_wg43[0];
+          __builtin_amdgcn_global_load_lds(g, Ab + (wave + NW * i) * DS, 4, 0, 0);
           rbase += rstep;
         }
       }
@@ -151,10 +155,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_w43_kernel(const WgW43Params 
       for (int p = 0; p < 4; ++p)
         if ((unsigned)(hsB + b_rr[p]) < (unsigned)P.a1.H && (unsigned)(wsB + b_cc[p]) < (unsigned)P.a1.W) vmB |= 1 << p;
     }
-    const int nch = skipB ? 0 : BN / 4;
+    const int nch = skipB ? 0 : BN / NW;
 #pragma unroll 2
     for (int i = 0; i < nch; ++i) {
-      const int ch = wave + 4 * i;
+      const int ch = wave + NW * i;
       const int c = n0 + ch;
       const bool first = c < P.a0.C;
       const SrcD& S = first ? P.a0 : P.a1;
@@ -300,7 +304,7 @@ __global__ void wgrad_w43_reduce_kernel(const float* __restrict__ slabs, float* 
 namespace {
 
 struct WgW43Plan {
-  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS, mblocks, nblocks, stages_total, splits;
+  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS, BM, BN, mblocks, nblocks, stages_total, splits;
   int64_t slab_elems;
 };
 
@@ -325,11 +329,14 @@ WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   p.tiles_x = ceil_div(W, p.TW);
   p.WR = p.TH + 2; p.WC = p.TW + 2; p.WCp = round_up(p.WC, 4);
   p.XS = round_up(p.WR * p.WCp, 8) + 4;   // channel stride = 4 mod 8 floats: the 16 channels of a ds_read_b128 hit 16 different bank groups
-  p.mblocks = ceil_div(M, WG_BM);
-  p.nblocks = ceil_div(Ncols, WG_BN);
+  static const bool small = getenv("GSD_WG43_SMALL") != nullptr;   // tuning: 4-wave blocks only
+  p.BM = (M >= 128 && !small) ? 128 : 64;
+  p.BN = (p.BM == 64 && Ncols >= 64 && !small) ? 64 : 32;
+  p.mblocks = ceil_div(M, p.BM);
+  p.nblocks = ceil_div(Ncols, p.BN);
   p.stages_total = N * p.tiles_y * p.tiles_x;
   static const int target = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;
-  int splits = ceil_div(target, p.mblocks * p.nblocks);
+  int splits = ceil_div(p.BM * p.BN > 64 * 32 ? target / 2 : target, p.mblocks * p.nblocks);   // one round of resident blocks
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits > 2048) splits = 2048;
   if (splits < 1) splits = 1;
@@ -368,18 +375,27 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   GSD_REQUIRE(pl.WR * pl.WCp <= 256, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: halo window too large");
   const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
-  const size_t lds = (size_t)2 * (WG_BM * WG_DS + WG_BN * pl.XS) * sizeof(float);
+  const size_t lds = (size_t)2 * (pl.BM * WG_DS + pl.BN * pl.XS) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_w43_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
+    const void* fns[3] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2>),
+                          reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2>),
+                          reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4>)};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return GSD_ERR_HIP;
+      }
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad3x3_w43_kernel, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
+  if (pl.BM == 128)
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2>), dim3((int)grid), dim3(512), lds, (hipStream_t)stream, P);
+  else if (pl.BN == 64)
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4>), dim3((int)grid), dim3(512), lds, (hipStream_t)stream, P);
+  else
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2>), dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
   const long long per = 3LL * Cout * Cin;
   const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
