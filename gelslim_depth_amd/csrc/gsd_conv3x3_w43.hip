@@ -55,21 +55,28 @@ constexpr int W43_W4 = W43_WTILE / 4;       // float4s
 constexpr int W43_NWI = (W43_W4 + 255) / 256;
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) {
-  constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4, NWI = W43_NWI;
+// WM = groups of 4 waves per block: 1 -> 64 m x 256 px, two blocks per CU; 2 -> 128 m x 256 px (two 64-channel weight
+// images side by side), 8 waves, one block per CU: the halo DMA -- the expensive part of the data movement -- is then shared
+// by twice the MFMAs (9 instead of 13 DMA instructions per wave and chunk).  Used for Cin >= 1024 only (see w43_impl).
+template <int WM>
+__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(const W43Params P) {
+  constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM, NWAVE = 4 * WM;
+  constexpr int NWI = (W4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PS = P.PS;
-  const int BUF = WTILE + 4 * PS;
+  const int BUF = WM * WTILE + 4 * PS;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave8 >> 2, wave = wave8 & 3;   // wave: pixel group of the wave, wm: its 64-channel group
   const int j = lane >> 4, l16 = lane & 15;
 
   // The m-blocks of one pixel tile read the same halo: hardware deals blocks round-robin over the 8 XCDs, so give every XCD
   // a contiguous range of logical ids (pixel tile major, m-block minor) and its L2 serves the halo once.
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int mb = lid % P.mblocks;
+  const int mbb = lid % P.mblocks;              // P.mblocks counts blocks (WM 64-channel groups each)
   const int pt = lid / P.mblocks;
+  const int mb = mbb * WM + wm;
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
   const int n = pt / tpi;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
   const bool q_ok = q < P.TH * P.TWq;
   const int tr = q_ok ? q / P.TWq : 0;
   const int tq = q_ok ? q - tr * P.TWq : 0;
-  const int baddr = WTILE + j * PS + tr * P.WCp + 4 * tq;   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
+  const int baddr = WM * WTILE + j * PS + tr * P.WCp + 4 * tq;   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
   int vmask = 0;                                            // pixels of the tile that exist in the image
   if (q_ok && h0 + tr < P.H) {
 #pragma unroll
@@ -91,10 +98,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
   }
 
   // ---- DMA lane geometry (as gsd_conv3x3.hip, window rows padded to WCp floats) ------------------------------------------
-  int xo0[2], xo1[2];
+  constexpr int NPP = 2 / WM;   // position chunks of 64 per wave: the block's waves cover the 512 window positions once
+  int xo0[NPP], xo1[NPP];
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int pos = (wave + 4 * pp) * 64 + lane;
+  for (int pp = 0; pp < NPP; ++pp) {
+    const int pos = (wave8 + NWAVE * pp) * 64 + lane;
     xo0[pp] = xo1[pp] = -2;
     const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
     if (rr < P.WR && cc < P.WC) {
@@ -106,41 +114,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
       xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.W + ws : -1;
     }
   }
-  const float* wsrc0 = P.wt + (size_t)mb * P.nchunks * WTILE;
-  const bool p_on[2] = {wave < P.NPV, wave + 4 < P.NPV};
+  const float* wsrc0 = P.wt + (size_t)(mbb * WM) * P.nchunks * WTILE;   // the block's WM weight images follow each other
+  bool p_on[NPP];
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) p_on[pp] = wave8 + NWAVE * pp < P.NPV;
 
   int d_seg = 0, d_left = P.src0.C;
   const float* d_base = P.src0.p + (long long)n * P.src0.ns;
   long long d_cs = P.src0.cs;
   const float* d_sent = P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
-  int d_xo[2] = {xo0[0], xo0[1]};
+  int d_xo[NPP];
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo0[pp];
 
   // slots 0..NWI-1: the weight chunk (16 B per lane); slot NWI+ch: input channel ch of the chunk
   auto dma_slot = [&](int slot, int chunk, int buf) {
     float* Wb = smem + buf * BUF;
     if (slot < NWI) {
-      const float* wsrc = wsrc0 + (size_t)chunk * WTILE + tid * 4;
-      if (tid + slot * 256 < W4)
-        __builtin_amdgcn_global_load_lds(wsrc + slot * 1024, Wb + (slot * 256 + wave * 64) * 4, 16, 0, 0);
+      const int e = tid + slot * NT;                 // 16-byte piece of the block's WM weight images (LDS: linear in e)
+      const int img = e >= W43_W4 ? 1 : 0;
+      const float* wsrc = wsrc0 + ((size_t)img * P.nchunks + chunk) * WTILE + (e - img * W43_W4) * 4;
+      if (e < W4) __builtin_amdgcn_global_load_lds(wsrc, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
     } else if (slot < NWI + 4) {
       const int ch = slot - NWI;
-      float* Xb = Wb + WTILE;
+      float* Xb = Wb + WM * WTILE;
       if (d_left == 0 && d_seg == 0) {
         d_seg = 1;
         d_left = P.src1.C;
         d_base = P.src1.p + (long long)n * P.src1.ns;
         d_cs = P.src1.cs;
         d_sent = P.src1.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
-        d_xo[0] = xo1[0];
-        d_xo[1] = xo1[1];
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo1[pp];
       }
       const bool c_ok = d_left > 0;
       const float* sentinel = c_ok ? d_sent : &gsd_pad_w43[0];
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
+      for (int pp = 0; pp < NPP; ++pp) {
         if (p_on[pp] && d_xo[pp] != -2) {
           const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : sentinel;
-          __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave + 4 * pp) * 64, 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
         }
       }
       if (c_ok) {
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
 
   const int Kpad = P.nchunks * 4;
   float* sAff = smem + 2 * BUF;
-  for (int c = tid; c < Kpad; c += 256) {
+  for (int c = tid; c < Kpad; c += NT) {
     const bool first = c < P.src0.C;
     const SrcD& S = first ? P.src0 : P.src1;
     const int cc = first ? c : c - P.src0.C;
@@ -164,14 +177,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
     sAff[c] = sc;
     sAff[Kpad + c] = sh;
   }
-  float* sBw = sAff + 2 * Kpad;   // [4][BM]: scale, shift, mean, invstd of the fused BatchNorm-backward epilogue
+  constexpr int BMB = WM * BM;    // output channels of the block
+  float* sBw = sAff + 2 * Kpad;   // [4][BMB]: scale, shift, mean, invstd of the fused BatchNorm-backward epilogue
   if (P.bw_raw != nullptr) {
-    for (int c = tid; c < BM; c += 256) {
-      const int co = m0 + c < P.Cout ? m0 + c : 0;
+    for (int c = tid; c < BMB; c += NT) {
+      const int co = mbb * BMB + c < P.Cout ? mbb * BMB + c : 0;
       sBw[c] = P.bw_scale[co];
-      sBw[BM + c] = P.bw_shift[co];
-      sBw[2 * BM + c] = P.bw_mean[co];
-      sBw[3 * BM + c] = P.bw_invstd[co];
+      sBw[BMB + c] = P.bw_shift[co];
+      sBw[2 * BMB + c] = P.bw_mean[co];
+      sBw[3 * BMB + c] = P.bw_invstd[co];
     }
   }
   const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
     v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
   };
 
-  const int a_lane = l16 * 4;
+  const int a_lane = wm * WTILE + l16 * 4;
 #pragma unroll
   for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
@@ -336,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w43_kernel(const W43Params P) 
       for (int reg = 0; reg < 4; ++reg) {
         const int co = m0 + m * 16 + j * 4 + reg;
         float* const px = d0 + (long long)co * P.dst0.cs + off0;
-        const int cl = m * 16 + j * 4 + reg;
-        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        const int cl = wm * BM + m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BMB + cl], bmu = sBw[2 * BMB + cl], bis = sBw[3 * BMB + cl];
         const int sm = co < P.Cout ? sm0 : 0;
         float y[4];
         out_transform(m, reg, y);
@@ -407,10 +421,11 @@ bool plan_w43(int H, int W, int M, W43Plan* best) {
   return best_cost >= 0;
 }
 
+template <int WM>
 int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_w43_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -418,7 +433,8 @@ int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv3x3_w43_kernel, dim3(grid), dim3(256), lds, st, P);
+  GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: LDS image %zu B too large", lds);
+  hipLaunchKernelGGL(conv3x3_w43_kernel<WM>, dim3(grid), dim3(256 * WM), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w43");
   return GSD_OK;
 }
@@ -477,17 +493,21 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.Cout = Cout;
   P.Mpad = round_up(Cout, 64);
   P.nchunks = ceil_div(Cin, 4);
-  P.mblocks = pl.mblocks;
+  static const bool small = getenv("GSD_W43_SMALL") != nullptr;   // tuning: 4-wave blocks only
+  // measured (profiles/bench_conv_forms.py, GSD_W43_SMALL): the 8-wave block only pays for the longest K loops (Cin = 1024:
+  // -5 %); below that two independent 4-wave blocks per CU hide each other's barriers better (+6 % for the 8-wave form)
+  const int WM = (pl.mblocks % 2 == 0 && Cin >= 1024 && !small) ? 2 : 1;
+  P.mblocks = pl.mblocks / WM;
   P.N = N; P.H = H; P.W = W;
   P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
   P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp;
   P.PS = round_up(P.WR * P.WCp, 4) + 4;   // + one bank group: the four channel planes of a k-step start 16 B apart (mod 4)
   P.NPV = ceil_div(P.WR * P.WCp, 64);
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: halo window too large");
-  const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
+  const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
-  const size_t lds = (size_t)(2 * (W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W43_BM) * sizeof(float);
-  return launch_w43(P, (int)grid, lds, (hipStream_t)stream);
+  const size_t lds = (size_t)(2 * (WM * W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
+  return WM == 2 ? launch_w43<2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w43<1>(P, (int)grid, lds, (hipStream_t)stream);
 }
 
 extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
