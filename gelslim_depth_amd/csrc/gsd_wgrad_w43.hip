@@ -71,16 +71,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   const int a_t = lane >> 2;
   const int a_r = a_t / P.TWq;
   const int a_c = (a_t - a_r * P.TWq) * 4 + (lane & 3);
-  // B: window positions p*64 + lane -> (row, column) of the padded window
-  int b_rr[4], b_cc[4];
-  bool b_ok[4];
+  // B: window positions p*64 + lane -> (row, column) of the padded window and the float offset from the window origin in
+  // a plane of segment A / B (their widths may differ).  Every instruction moves all 64 lanes (no exec masks on the
+  // issue path): a lane past the window re-reads the window origin into the slack behind it (XS >= npv*64).
   const int npv = (P.WR * P.WCp + 63) >> 6;
+  int b_rr[4], b_cc[4], oA[4], oB[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int pos = p * 64 + lane;
     b_rr[p] = pos / P.WCp;
     b_cc[p] = pos - b_rr[p] * P.WCp;
-    b_ok[p] = p < npv && b_rr[p] < P.WR && b_cc[p] < P.WC;
+    const bool in_win = b_rr[p] < P.WR && b_cc[p] < P.WC;
+    if (!in_win) b_rr[p] = b_cc[p] = 0;
+    oA[p] = b_rr[p] * P.a0.W + b_cc[p];
+    oB[p] = b_rr[p] * P.a1.W + b_cc[p];
   }
 
   // deferred BatchNorm+ReLU of this lane's input channel
@@ -164,20 +168,30 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       const SrcD& S = first ? P.a0 : P.a1;
       const int cc = first ? c : c - P.a0.C;
       const bool c_ok = c < P.Ncols && cc < S.C;
-      const int Wd = first ? P.a0.W : P.a1.W;
       float* Xd = Bb + ch * XS;
       const float* cbase = S.p + (long long)n * S.ns + (long long)(c_ok ? cc : 0) * S.cs + (first ? woA : woB);
+      // per-position offsets of this channel's segment, selected by VALUE (a select between the two arrays themselves
+      // would put them in scratch memory)
+      int o[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) o[p] = first ? oA[p] : oB[p];
       if (c_ok && (first ? inA : inB)) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (b_ok[p]) __builtin_amdgcn_global_load_lds(cbase + (b_rr[p] * Wd + b_cc[p]), Xd + p * 64, 4, 0, 0);
+          if (p < npv) __builtin_amdgcn_global_load_lds(cbase + o[p], Xd + p * 64, 4, 0, 0);
       } else {
         const float* sentinel = (c_ok && S.relu) ? &gsd_pad_wg43[1] : &gsd_pad_wg43[0];
         const int m = c_ok ? (first ? vmA : vmB) : 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-          if (b_ok[p])
-            __builtin_amdgcn_global_load_lds((m >> p & 1) ? cbase + (b_rr[p] * Wd + b_cc[p]) : sentinel, Xd + p * 64, 4, 0, 0);
+        for (int p = 0; p < 4; ++p) {
+          if (p < npv) {
+            const unsigned long long pa = reinterpret_cast<unsigned long long>(cbase + o[p]);
+            const unsigned long long ps = reinterpret_cast<unsigned long long>(sentinel);
+            const bool ok = (m >> p & 1) != 0;
+            const unsigned lo32 = ok ? (unsigned)pa : (unsigned)ps, hi32 = ok ? (unsigned)(pa >> 32) : (unsigned)(ps >> 32);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(((unsigned long long)hi32 << 32) | lo32), Xd + p * 64, 4, 0, 0);
+          }
+        }
       }
     }
   };
@@ -328,7 +342,9 @@ WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   p.tiles_y = ceil_div(H, p.TH);
   p.tiles_x = ceil_div(W, p.TW);
   p.WR = p.TH + 2; p.WC = p.TW + 2; p.WCp = round_up(p.WC, 4);
-  p.XS = round_up(p.WR * p.WCp, 8) + 4;   // channel stride = 4 mod 8 floats: the 16 channels of a ds_read_b128 hit 16 different bank groups
+  // channel stride: whole 64-lane DMA instructions land inside the channel's slot, and = 4 mod 8 floats so that the 16
+  // channels of a ds_read_b128 hit 16 different bank groups
+  p.XS = round_up(((p.WR * p.WCp + 63) / 64) * 64, 8) + 4;
   static const bool small = getenv("GSD_WG43_SMALL") != nullptr;   // tuning: 4-wave blocks only
   p.BM = (M >= 128 && !small) ? 128 : 64;
   p.BN = (p.BM == 64 && Ncols >= 64 && !small) ? 64 : 32;
