@@ -240,7 +240,10 @@ def main():
                                    ("BASELINE.json configs[1]: eval-mode forward fp32, 3x320x427 -> 1x320x427, "
                                     "U-Net [64,128,256,512,1024], HIP kernels"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6)},
+                       "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6),
+                       "conv3x3_form": ("bf16 MFMA implicit GEMM" if args.dtype == "bf16" else
+                                        {"0": "direct taps", "1": "winograd F(4,3) rows"}.get(
+                                            os.environ.get("GSD_CONV_ALGO", ""), "winograd F(4,3) rows, fp32 (Cin>=16) / direct taps (first layer)"))},
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

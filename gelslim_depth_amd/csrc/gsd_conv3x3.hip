@@ -415,7 +415,8 @@ extern "C" int gsd_conv3x3_partial_rows(int N, int H, int W, int Cout) {
 // (ideal: half; measured x1.3-1.7 on the U-Net's layers, profiles/bench_conv_forms.py).  GSD_CONV_ALGO=0|1 forces one.
 extern "C" int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int Cout);
 extern "C" int gsd_conv3x3_algo(int N, int H, int W, int Cin, int Cout) {
-  static const int forced = getenv("GSD_CONV_ALGO") ? atoi(getenv("GSD_CONV_ALGO")) : -1;
+  const char* env = getenv("GSD_CONV_ALGO");   // read per call: the tests switch forms inside one process
+  const int forced = env ? atoi(env) : -1;
   if (forced == 0 || forced == 1) return forced;
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   if (Cin < 16) return 0;   // a K loop of 1-3 chunks is all prologue + epilogue, and the Winograd epilogue is the longer one

@@ -365,7 +365,8 @@ WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
 
 // 1: gsd_conv3x3_wgrad serves this shape with the Winograd form.  GSD_WGRAD_ALGO=0|1 forces one (tuning, A/B runs).
 int gsd_wgrad_w43_use(int N, int H, int W, int Cin, int Cout) {
-  static const int forced = getenv("GSD_WGRAD_ALGO") ? atoi(getenv("GSD_WGRAD_ALGO")) : -1;
+  const char* env = getenv("GSD_WGRAD_ALGO");   // read per call: the tests switch forms inside one process
+  const int forced = env ? atoi(env) : -1;
   if (forced == 0) return 0;
   if (forced == 1) return 1;
   return Cin >= 16 && Cout >= 16;   // the 3-channel first layer keeps the pixel-split direct kernel

@@ -153,6 +153,35 @@ def test_conv3x3_wgrad(gsd, n, ci, co, h, w):
     assert rc == -4 and b"workspace" in gsd.lib.gsd_last_error()
 
 
+@pytest.mark.parametrize("n,c0,c1,co,h,w,uh,uw", [(2, 6, 5, 9, 9, 11, 6, 8), (1, 16, 16, 32, 21, 29, 20, 28),
+                                                  (2, 64, 64, 64, 13, 19, 12, 18), (1, 24, 40, 130, 10, 37, 8, 36)])
+def test_conv3x3_wgrad_two_segments(gsd, n, c0, c1, co, h, w, uh, uw):
+    """dW of the decoder's first conv: activation = cat(relu(bn(skip)), F.pad(up)) (unet.py:46-48) given as two segments --
+    a deferred-BatchNorm one and a plain one of another size placed at the F.pad offset.  Shapes with >= 16 channels run
+    the Winograd form, the first one the direct form."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(c0 * 7 + c1)
+    skip_raw = rnd(rng, n, c0, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, c0).astype(np.float32), rnd(rng, c0, scale=0.3)
+    up = rnd(rng, n, c1, uh, uw)
+    a0 = np.maximum(skip_raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    upp, (top, left) = on.pad_to(up, h, w)
+    dy = rnd(rng, n, co, h, w)
+    _, dwr = on.conv3x3_bwd(np.concatenate([a0, upp], 1), np.zeros((co, c0 + c1, 3, 3), np.float32), dy, need_dx=False)
+    srd, upd, scd, shd, dyd = dev(skip_raw), dev(up), dev(sc), dev(sh), dev(dy)
+    dw = torch.full((co, c0 + c1, 3, 3), float("nan"), device="cuda")
+    need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, c0 + c1, co)
+    ws = torch.zeros(need, device="cuda")
+    a_src = gsd.src_array([gsd.make_src(srd, scd, shd, relu=True), gsd.make_src(upd, off=(top, left))])
+    dy_src = gsd.make_src(dyd)
+    gsd.check(gsd.lib.gsd_conv3x3_wgrad(a_src, 2, C.byref(dy_src), c0 + c1, co, dw.data_ptr(), ws.data_ptr(), need, n, h, w,
+                                        gsd.stream_ptr()))
+    got = dw.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_l1(got, dwr) < 5e-5
+    assert rel_l1(got[:, c0:], dwr[:, c0:]) < 5e-5      # the offset segment on its own
+
+
 @pytest.mark.parametrize("n,ci,h,w", [(2, 8, 4, 5), (1, 128, 20, 26), (2, 36, 7, 9)])
 def test_convT_fwd_bwd(gsd, n, ci, h, w):
     from oracle import unet_numpy as on
