@@ -138,25 +138,43 @@ extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float
 // ---------------------------------------------------------------------------------------------
 // column sums of a [rows][ncols] fp32 matrix into fp64 (two ordered stages)
 // ---------------------------------------------------------------------------------------------
-constexpr int RG = 64;  // row groups of stage 1
-__global__ void colsum_stage1(const float* __restrict__ part, int rows, int ld, int ncols, double* __restrict__ tmp) {
-  // block (64 cols x 4 row lanes); grid (ceil(ncols/64), RG)
+constexpr int RG = 64;  // row groups of stage 1 (part of the workspace contract: callers allocate (1+RG) x columns doubles)
+constexpr int CS_LANES = 16;   // row lanes per block: 64 columns x 16 rows in flight, four independent partial sums each
+// blockIdx.z = column range `half` (the sum | sum-of-squares halves of a conv partial row are `half_off` apart); a few
+// ten thousand partial rows of 64..1024 columns: the grid is (columns/64, 64, halves) blocks of 1024 threads.
+__global__ __launch_bounds__(64 * CS_LANES) void colsum_stage1(const float* __restrict__ part, int rows, int ld, int ncols,
+                                                               int half_off, double* __restrict__ tmp) {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   const int g = blockIdx.y;
+  part += (size_t)blockIdx.z * half_off;
+  tmp += (size_t)blockIdx.z * RG * ncols;
   const int per = (rows + RG - 1) / RG;
   const int rb = g * per, re = min(rb + per, rows);
-  double s = 0.0;
-  if (col < ncols)
-    for (int r = rb + rl; r < re; r += 4) s += (double)part[(size_t)r * ld + col];
-  __shared__ double red[4][64];
-  red[rl][threadIdx.x & 63] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (col < ncols) {
+    int r = rb + rl;
+    for (; r + 3 * CS_LANES < re; r += 4 * CS_LANES) {   // four loads in flight per thread
+      const float a = part[(size_t)r * ld + col], b = part[(size_t)(r + CS_LANES) * ld + col];
+      const float c = part[(size_t)(r + 2 * CS_LANES) * ld + col], d = part[(size_t)(r + 3 * CS_LANES) * ld + col];
+      s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+    }
+    for (; r < re; r += CS_LANES) s0 += (double)part[(size_t)r * ld + col];
+  }
+  __shared__ double red[CS_LANES][64];
+  red[rl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rl == 0 && col < ncols)
-    tmp[(size_t)g * ncols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (rl == 0 && col < ncols) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < CS_LANES; ++i) t += red[i][threadIdx.x];
+    tmp[(size_t)g * ncols + col] = t;
+  }
 }
 __global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double* __restrict__ sums) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  tmp += (size_t)blockIdx.y * RG * ncols;
+  sums += (size_t)blockIdx.y * ncols;
   if (col < ncols) {
     double s = 0.0;
     for (int g = 0; g < RG; ++g) s += tmp[(size_t)g * ncols + col];
@@ -169,15 +187,12 @@ __global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double*
 extern "C" int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad, int C, double* sums, void* stream) {
   GSD_REQUIRE(partials && sums && rows > 0 && C > 0 && Mpad >= C, GSD_ERR_BAD_ARG, "gsd_bn_reduce_partials: bad argument");
   double* tmp = sums + 2 * C;
-  // the two halves (sum | sumsq) are Mpad apart in a partial row; reduce them as two column ranges
-  for (int half = 0; half < 2; ++half) {
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(C, 64), RG), dim3(256), 0, (hipStream_t)stream,
-                       partials + (size_t)half * Mpad, rows, 2 * Mpad, C, tmp + (size_t)half * RG * C);
-    GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       tmp + (size_t)half * RG * C, C, sums + (size_t)half * C);
-    GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage2");
-  }
+  // the two halves (sum | sumsq) are Mpad apart in a partial row: two column ranges of one launch
+  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(C, 64), RG, 2), dim3(64 * CS_LANES), 0, (hipStream_t)stream, partials, rows,
+                     2 * Mpad, C, Mpad, tmp);
+  GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(C, 256), 2), dim3(256), 0, (hipStream_t)stream, tmp, C, sums);
+  GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage2");
   return GSD_OK;
 }
 
@@ -470,10 +485,10 @@ extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale,
 extern "C" int gsd_bn_bwd_reduce_partials(const float* partials, int rows, int C, double* sums, void* stream) {
   GSD_REQUIRE(partials && sums && rows > 0 && C > 0, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce_partials: bad argument");
   double* tmp = sums + 3 * C;
-  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(3 * C, 64), RG), dim3(256), 0, (hipStream_t)stream, partials, rows,
-                     3 * C, 3 * C, tmp);
+  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(3 * C, 64), RG, 1), dim3(64 * CS_LANES), 0, (hipStream_t)stream, partials, rows,
+                     3 * C, 3 * C, 0, tmp);
   GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_partials stage1");
-  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(3 * C, 256)), dim3(256), 0, (hipStream_t)stream, tmp, 3 * C, sums);
+  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(3 * C, 256), 1), dim3(256), 0, (hipStream_t)stream, tmp, 3 * C, sums);
   GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce_partials stage2");
   return GSD_OK;
 }
