@@ -294,24 +294,46 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     }
 }
 
-// slab[split][r*6+f][co][ci] -> dW[co][ci][r][s] = sum_f G[f][s] * (sum over splits, in split order)
-__global__ void wgrad_w43_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int M, int Ncols) {
+// slab[split][r*6+f][co][ci] -> dW[co][ci][r][s] = sum_f G[f][s] * (sum over splits, in a fixed order).
+// Block = 64 elements x 16 split lanes: the layers with few (co, ci) pairs are the ones with hundreds of splits, and one
+// thread per element would walk them serially (95 us per launch on average before, most of it latency).
+template <int WR_LANES>
+__global__ __launch_bounds__(WR_LANES == 1 ? 256 : 64 * WR_LANES) void wgrad_w43_reduce_kernel(const float* __restrict__ slabs,
+                                                                                              float* __restrict__ dw, int splits,
+                                                                                              int M, int Ncols) {
+  constexpr int EL = WR_LANES == 1 ? 256 : 64;   // elements per block
   const long long plane = (long long)M * Ncols;
   const long long total = 3 * plane;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(e / plane);
-    const long long mc = e - r * plane;
+  const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+  __shared__ float red[6][WR_LANES][EL];
+  for (long long e0 = (long long)blockIdx.x * EL; e0 < total; e0 += (long long)gridDim.x * EL) {
+    const long long e = e0 + el;
+    const bool ok = e < total;
+    const int r = ok ? (int)(e / plane) : 0;
+    const long long mc = ok ? e - r * plane : 0;
     float D[6];
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += slabs[((size_t)k * 18 + r * 6 + f) * plane + mc];
-      D[f] = s;
+      if (ok)
+        for (int k = sl; k < splits; k += WR_LANES) s += slabs[((size_t)k * 18 + r * 6 + f) * plane + mc];
+      red[f][sl][el] = s;
     }
-    float* o = dw + (size_t)mc * 9 + r * 3;
-    o[0] = 0.25f * D[0] - (1.f / 6.f) * (D[1] + D[2]) + (1.f / 24.f) * (D[3] + D[4]);
-    o[1] = (1.f / 6.f) * (D[2] - D[1]) + (1.f / 12.f) * (D[3] - D[4]);
-    o[2] = (1.f / 6.f) * (D[3] + D[4] - D[1] - D[2]) + D[5];
+    __syncthreads();
+    if (sl == 0 && ok) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WR_LANES; ++i) s += red[f][i][el];
+        D[f] = s;
+      }
+      float* o = dw + (size_t)mc * 9 + r * 3;
+      o[0] = 0.25f * D[0] - (1.f / 6.f) * (D[1] + D[2]) + (1.f / 24.f) * (D[3] + D[4]);
+      o[1] = (1.f / 6.f) * (D[2] - D[1]) + (1.f / 12.f) * (D[3] - D[4]);
+      o[2] = (1.f / 6.f) * (D[3] + D[4] - D[1] - D[2]) + D[5];
+    }
+    __syncthreads();
   }
 }
 
@@ -415,8 +437,16 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
     hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2>), dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
   const long long per = 3LL * Cout * Cin;
-  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-  hipLaunchKernelGGL(wgrad_w43_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
+  if (pl.splits >= 64) {
+    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<16>, dim3(rgrid), dim3(1024), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
+  } else if (pl.splits >= 8) {
+    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<4>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
+  } else {
+    const int rgrid = (int)(ceil_div64(per, 256) < 8192 ? ceil_div64(per, 256) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<1>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
+  }
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43) reduce");
   return GSD_OK;
 }
