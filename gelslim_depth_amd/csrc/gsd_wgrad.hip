@@ -483,22 +483,58 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
 // Sum the slabs in split order and write the reference layout.
 //   MODE 0: slab[split][tap][co][ci] -> dW[co][ci][tap]
 //   MODE 1: slab[split][m][ci]       -> dW[ci][m]          (m = co*4+kh*2+kw)
-template <int MODE>
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int splits, int M,
-                                    int Ncols) {
+// LANES split lanes per element (block = 64 elements x LANES): the launches with few output elements are the ones with
+// hundreds of slabs (the 3-channel first layer: 1,728 elements x 2,048 slabs), which one thread per element walks serially.
+template <int MODE, int LANES>
+__global__ __launch_bounds__(LANES == 1 ? 256 : 64 * LANES) void wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                                                     float* __restrict__ dw, int splits, int M,
+                                                                                     int Ncols) {
+  constexpr int EL = LANES == 1 ? 256 : 64;
   const long long per = (long long)(MODE == 0 ? 9 : 1) * M * Ncols;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long long)gridDim.x * blockDim.x) {
+  const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+  __shared__ float red[LANES][EL];
+  for (long long e0 = (long long)blockIdx.x * EL; e0 < per; e0 += (long long)gridDim.x * EL) {
+    const long long e = e0 + el;
+    const bool ok = e < per;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * per + e];
-    const int col = (int)(e % Ncols);
-    const long long t2 = e / Ncols;
-    const int mr = (int)(t2 % M);
-    if (MODE == 0) {
-      const int tap = (int)(t2 / M);
-      dw[((size_t)mr * Ncols + col) * 9 + tap] = s;
-    } else {
-      dw[(size_t)col * M + mr] = s;
+    if (ok)
+      for (int k = sl; k < splits; k += LANES) s += slabs[(size_t)k * per + e];
+    if (LANES > 1) {
+      red[sl][el] = s;
+      __syncthreads();
+      if (sl == 0) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LANES; ++i) s += red[i][el];
+      }
     }
+    if (sl == 0 && ok) {
+      const int col = (int)(e % Ncols);
+      const long long t2 = e / Ncols;
+      const int mr = (int)(t2 % M);
+      if (MODE == 0) {
+        const int tap = (int)(t2 / M);
+        dw[((size_t)mr * Ncols + col) * 9 + tap] = s;
+      } else {
+        dw[(size_t)col * M + mr] = s;
+      }
+    }
+    if (LANES > 1) __syncthreads();
+  }
+}
+
+template <int MODE>
+void launch_wgrad_reduce(const float* slabs, float* dw, int splits, int M, int Ncols, hipStream_t st) {
+  const long long per = (long long)(MODE == 0 ? 9 : 1) * M * Ncols;
+  if (splits >= 64) {
+    const int g = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MODE, 16>), dim3(g), dim3(1024), 0, st, slabs, dw, splits, M, Ncols);
+  } else if (splits >= 8) {
+    const int g = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MODE, 4>), dim3(g), dim3(256), 0, st, slabs, dw, splits, M, Ncols);
+  } else {
+    const int g = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<MODE, 1>), dim3(g), dim3(256), 0, st, slabs, dw, splits, M, Ncols);
   }
 }
 
@@ -725,10 +761,7 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
     rc = pl.wide ? launch_dma<1, 4, 3>(P, grid, 2 * lds, (hipStream_t)stream)
                  : launch_dma<2, 2, 3>(P, grid, 2 * lds, (hipStream_t)stream);
   if (rc) return rc;
-  const long long per = 9LL * Cout * Cin;
-  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-  hipLaunchKernelGGL((wgrad_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, nslabs,
-                     Cout, Cin);
+  launch_wgrad_reduce<0>(workspace, dw, nslabs, Cout, Cin, (hipStream_t)stream);
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad reduce");
   return GSD_OK;
 }
@@ -787,10 +820,7 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
     rc = GSD_OK;
   }
   if (rc) return rc;
-  const long long per = (long long)M * Cin;
-  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-  hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits,
-                     M, Cin);
+  launch_wgrad_reduce<1>(workspace, dw, pl.splits, M, Cin, (hipStream_t)stream);
   GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad reduce");
   if (dbias != nullptr) {
     GSD_REQUIRE(dy->c_stride == (int64_t)4 * H * W && dy->n_stride == (int64_t)Cout * 4 * H * W, GSD_ERR_UNSUPPORTED,
