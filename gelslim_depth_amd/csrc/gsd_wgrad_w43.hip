@@ -106,12 +106,25 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   // Address arithmetic is kept out of the per-instruction path (the kernel is VALU-bound next to 144 MFMAs per stage): per
   // stage one scalar window origin per segment, per lane the constants above; a stage whose window lies inside the
   // segment ("interior", the common case) needs no per-lane validity at all, a border stage computes it once per segment.
-  auto issue_dma = [&](int stage, int buf) {
+  // coordinates of the next stage to issue, carried incrementally (two integer divisions per stage cost ~40 scalar
+  // instructions, and with two waves per SIMD every instruction of a wave costs an issue slot)
+  int st_n, st_ty, st_tx;
+  {
     const int tpi = P.tiles_y * P.tiles_x;
-    const int n = stage / tpi;
-    const int rs = stage - n * tpi;
-    const int ty = rs / P.tiles_x;
-    const int h0 = ty * P.TH, w0 = (rs - ty * P.tiles_x) * P.TW;
+    st_n = s_begin / tpi;
+    const int rs = s_begin - st_n * tpi;
+    st_ty = rs / P.tiles_x;
+    st_tx = rs - st_ty * P.tiles_x;
+  }
+  auto issue_dma = [&](int stage, int buf) {
+    const int n = st_n, h0 = st_ty * P.TH, w0 = st_tx * P.TW;
+    if (++st_tx == P.tiles_x) {
+      st_tx = 0;
+      if (++st_ty == P.tiles_y) {
+        st_ty = 0;
+        ++st_n;
+      }
+    }
     float* Ab = smem + buf * BUF;
     float* Bb = Ab + BM * DS;
 #ifdef WG43_ABL

@@ -94,3 +94,32 @@ def test_checkpoint_layout_round_trips_with_the_reference_model(tmp_path):
     for (n1, p1), (n2, p2) in zip(ours.named_parameters(), ref.named_parameters()):
         if p1.dim() == 4:
             assert abs(p1.abs().max().item() - p2.abs().max().item()) < 0.35 * p2.abs().max().item(), n1
+
+
+def test_conv_form_choice_and_size_queries(monkeypatch):
+    """Host-side planning of the two conv3x3 forms (no kernel is launched): the per-shape choice on the U-Net's layers,
+    the work the Winograd form saves, and the workspace / layout queries the engine sizes its buffers with."""
+    from gelslim_depth_amd import _lib
+    lib = _lib.lib
+    monkeypatch.delenv("GSD_CONV_ALGO", raising=False)
+    monkeypatch.delenv("GSD_WGRAD_ALGO", raising=False)
+    h, w = 320, 427
+    for lvl, c in enumerate([64, 128, 256, 512, 1024]):
+        cin = 3 if lvl == 0 else c // 2
+        for ci, co in ((cin, c), (c, c)):
+            algo = lib.gsd_conv3x3_algo(32, h, w, ci, co)
+            assert algo == (0 if ci < 16 else 1), (lvl, ci, co, algo)
+            direct_mfma = 2.0 * 9 * 32 * h * w * ci * co / 2048          # unpadded direct-tap MFMA count
+            w43 = lib.gsd_conv3x3_w43_mfma_count(32, h, w, ci, co)
+            if ci >= 16:
+                assert 0.5 * direct_mfma <= w43 <= 0.78 * direct_mfma, (lvl, w43 / direct_mfma)   # half + tile padding
+            assert lib.gsd_conv3x3_w43_partial_rows(32, h, w, co) > 0
+            # Winograd weight images: 18 rows per input channel instead of 9, 64-column m-blocks
+            assert lib.gsd_weight_layout_size(4, co, ci) == -(-co // 64) * 64 * (-(-ci // 4) * 4) * 18
+            assert lib.gsd_weight_layout_size(5, co, ci) == -(-ci // 64) * 64 * (-(-co // 4) * 4) * 18
+            assert lib.gsd_conv3x3_wgrad_workspace(32, h, w, ci, co) > 0
+        h, w = h // 2, w // 2
+    monkeypatch.setenv("GSD_CONV_ALGO", "0")
+    assert lib.gsd_conv3x3_algo(32, 320, 427, 64, 64) == 0
+    monkeypatch.setenv("GSD_CONV_ALGO", "1")
+    assert lib.gsd_conv3x3_algo(32, 320, 427, 3, 64) == 1
