@@ -57,7 +57,7 @@ constexpr int W43_NWI = (W43_W4 + 255) / 256;
 
 // WM = groups of 4 waves per block: 1 -> 64 m x 256 px, two blocks per CU; 2 -> 128 m x 256 px (two 64-channel weight
 // images side by side), 8 waves, one block per CU: the halo DMA -- the expensive part of the data movement -- is then shared
-// by twice the MFMAs (9 instead of 13 DMA instructions per wave and chunk).  Used for Cin >= 1024 only (see w43_impl).
+// by twice the MFMAs (9 instead of 13 DMA instructions per wave and chunk).  Tuning option (GSD_W43_BIG), not the default.
 template <int WM>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(const W43Params P) {
   constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM, NWAVE = 4 * WM;
@@ -119,6 +119,23 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) p_on[pp] = wave8 + NWAVE * pp < P.NPV;
 
+  const long long wlane = tid * 4;   // this lane's float offset inside a 1 KiB weight piece group
+  long long xl0[NPP];   // first segment's offsets as 64-bit lane values (the address add is then a single instruction)
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) xl0[pp] = xo0[pp];
+  {
+    // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only: the lanes that
+    // would otherwise DMA the sentinel there on every fill); visible to the consumers after the first barrier
+    const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+      if (p_on[pp] && xo0[pp] == -1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WM * WTILE + ch * PS + (wave8 + NWAVE * pp) * 64 + lane] = pad0;
+      }
+  }
   int d_seg = 0, d_left = P.src0.C;
   const float* d_base = P.src0.p + (long long)n * P.src0.ns;
   long long d_cs = P.src0.cs;
@@ -132,9 +149,14 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     float* Wb = smem + buf * BUF;
     if (slot < NWI) {
       const int e = tid + slot * NT;                 // 16-byte piece of the block's WM weight images (LDS: linear in e)
-      const int img = e >= W43_W4 ? 1 : 0;
-      const float* wsrc = wsrc0 + ((size_t)img * P.nchunks + chunk) * WTILE + (e - img * W43_W4) * 4;
-      if (e < W4) __builtin_amdgcn_global_load_lds(wsrc, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
+      if constexpr (WM == 1) {
+        // one image: scalar chunk base + the lane's fixed offset
+        if (e < W4) __builtin_amdgcn_global_load_lds(wsrc0 + (size_t)chunk * WTILE + slot * (NT * 4) + wlane, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
+      } else {
+        const int img = e >= W43_W4 ? 1 : 0;
+        const float* wsrc = wsrc0 + ((size_t)img * P.nchunks + chunk) * WTILE + (e - img * W43_W4) * 4;
+        if (e < W4) __builtin_amdgcn_global_load_lds(wsrc, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
+      }
     } else if (slot < NWI + 4) {
       const int ch = slot - NWI;
       float* Xb = Wb + WM * WTILE;
@@ -148,12 +170,22 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
         for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo1[pp];
       }
       const bool c_ok = d_left > 0;
-      const float* sentinel = c_ok ? d_sent : &gsd_pad_w43[0];
+      if (c_ok && d_seg == 0) {
+        // fast path, first segment: the padding positions of every plane were written once at kernel start (below), so a
+        // fill only moves the lanes that have a pixel -- no select, no sentinel pointer, one v_lshl_add_u64 per instruction
 #pragma unroll
-      for (int pp = 0; pp < NPP; ++pp) {
-        if (p_on[pp] && d_xo[pp] != -2) {
-          const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : sentinel;
-          __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
+        for (int pp = 0; pp < NPP; ++pp)
+          if (p_on[pp] && xo0[pp] >= 0)
+            __builtin_amdgcn_global_load_lds(d_base + xl0[pp], Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
+      } else {
+        // second (concat) segment and K padding: every window position is written, padding from the sentinel
+        const float* sentinel = c_ok ? d_sent : &gsd_pad_w43[0];
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) {
+          if (p_on[pp] && d_xo[pp] != -2) {
+            const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : sentinel;
+            __builtin_amdgcn_global_load_lds(g, Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
+          }
         }
       }
       if (c_ok) {
@@ -493,10 +525,10 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.Cout = Cout;
   P.Mpad = round_up(Cout, 64);
   P.nchunks = ceil_div(Cin, 4);
-  static const bool small = getenv("GSD_W43_SMALL") != nullptr;   // tuning: 4-wave blocks only
-  // measured (profiles/bench_conv_forms.py, GSD_W43_SMALL): the 8-wave block only pays for the longest K loops (Cin = 1024:
-  // -5 %); below that two independent 4-wave blocks per CU hide each other's barriers better (+6 % for the 8-wave form)
-  const int WM = (pl.mblocks % 2 == 0 && Cin >= 1024 && !small) ? 2 : 1;
+  // measured (profiles/bench_conv_forms.py): two independent 4-wave blocks per CU hide each other's barriers better than one
+  // 8-wave block shares its halo (+6 % for the 8-wave form at Cin <= 512, +1.5 % at Cin = 1024); GSD_W43_BIG=1 selects it
+  static const bool big = getenv("GSD_W43_BIG") != nullptr;
+  const int WM = (pl.mblocks % 2 == 0 && big) ? 2 : 1;
   P.mblocks = pl.mblocks / WM;
   P.N = N; P.H = H; P.W = W;
   P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
