@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     b_off[ks] = BM * DS + (wn * 16 + l16) * XS + trow * P.WCp + 4 * tq;
   }
 
-  auto compute = [&](int cur) {
+  // `late`: issue the next stage's DMA after the first k-step instead of in front of the stage (see the stage loop)
+  auto compute = [&](int cur, bool late, int next_stage, bool more) {
     const float* Sb = smem + cur * BUF;
     f32x4 ya[2][MT];
     f32x4 ra[2][3];
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[r][f], acc[m][r * 6 + f]);
+      if (ks == 0 && late && more) issue_dma(next_stage, cur ^ 1);
     }
   };
 
@@ -290,8 +292,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   for (int it = 0; it < nst; ++it) {
     const int cur = it & 1;
     gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
-    if (it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
-    compute(cur);
+    // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
+    // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
+    // first k-step BEFORE it issues its share of the next stage's DMA.
+    const bool late = NW == 8 && wave >= 4;
+    if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+    compute(cur, late, s_begin + it + 1, it + 1 < nst);
   }
 
 #pragma unroll
