@@ -63,7 +63,8 @@ def test_mfma_lane_maps(gsd):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 3, 64, 20, 33), (2, 8, 130, 13, 17), (1, 64, 64, 40, 53),
-                                         (3, 16, 200, 5, 4), (2, 12, 64, 33, 70)])
+                                         (3, 16, 200, 5, 4), (2, 12, 64, 33, 70), (2, 16, 16, 1, 1), (1, 16, 32, 2, 3),
+                                         (1, 20, 16, 3, 70), (1, 16, 16, 1, 130)])
 @ALGOS
 def test_conv3x3_plain(gsd, algo, n, ci, co, h, w):
     from oracle import unet_numpy as on
@@ -128,7 +129,8 @@ def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo):
     assert rel_l1(g_up.cpu().numpy(), dxr[:, c0:, top:top + 6, left:left + 8]) < F.tol
 
 
-@pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 64, 64, 21, 29), (2, 20, 130, 6, 70), (1, 3, 16, 40, 53)])
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 5, 7, 9, 11), (1, 64, 64, 21, 29), (2, 20, 130, 6, 70), (1, 3, 16, 40, 53),
+                                         (2, 16, 16, 1, 1), (1, 16, 32, 2, 3), (1, 32, 16, 3, 70), (3, 16, 200, 1, 130)])
 def test_conv3x3_wgrad(gsd, n, ci, co, h, w):
     from oracle import unet_numpy as on
     rng = np.random.default_rng(ci * 31 + co)
