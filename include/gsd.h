@@ -130,7 +130,10 @@ int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout,
 /* dW of conv3x3: dW[co][ci][kh][kw] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1].
  * `a` is given as up to two segments with deferred BN (recomputed on load), `dy` plain.
  * Deterministic split-K: partial slabs in `workspace` (gsd_conv3x3_wgrad_workspace elements),
- * then an ordered reduction writes dW in the reference's (Co,Ci,3,3) layout. */
+ * then an ordered reduction writes dW in the reference's (Co,Ci,3,3) layout.
+ * The library picks the arithmetic form per shape (direct taps, or the transposed Winograd F(4,3) identity
+ * dg = G^T[(A dy).(B^T d)] along rows for Cin, Cout >= 16: half the MFMA work, fp32 throughout; GSD_WGRAD_ALGO=0|1
+ * forces one); the workspace query covers either. */
 int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout,
                       float* dw, float* workspace, int64_t workspace_elems,
