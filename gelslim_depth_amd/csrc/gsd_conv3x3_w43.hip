@@ -150,8 +150,14 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     if (slot < NWI) {
       const int e = tid + slot * NT;                 // 16-byte piece of the block's WM weight images (LDS: linear in e)
       if constexpr (WM == 1) {
-        // one image: scalar chunk base + the lane's fixed offset
-        if (e < W4) __builtin_amdgcn_global_load_lds(wsrc0 + (size_t)chunk * WTILE + slot * (NT * 4) + wlane, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
+        // one image: scalar chunk base + the lane's fixed offset.  The last slot is half full (1152 = 4.5 x 256 pieces):
+        // it goes to waves 2 and 3, because waves 0 and 1 already move two position chunks of every halo plane where
+        // waves 2 and 3 move one -- the barrier waits for the busiest wave.
+        if (slot < NWI - 1) {
+          __builtin_amdgcn_global_load_lds(wsrc0 + (size_t)chunk * WTILE + slot * (NT * 4) + wlane, Wb + (slot * NT + wave8 * 64) * 4, 16, 0, 0);
+        } else if (wave8 >= 2) {
+          __builtin_amdgcn_global_load_lds(wsrc0 + (size_t)chunk * WTILE + (slot * NT - 128) * 4 + wlane, Wb + (slot * NT - 128 + wave8 * 64) * 4, 16, 0, 0);
+        }
       } else {
         const int img = e >= W43_W4 ? 1 : 0;
         const float* wsrc = wsrc0 + ((size_t)img * P.nchunks + chunk) * WTILE + (e - img * W43_W4) * 4;
