@@ -3,7 +3,10 @@
 fp32, full train step (forward + MSE + backward + Adam + EMA), every device operation a libgsd HIP kernel.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+N > 1 without a torch.distributed environment: this process starts N ranks of itself through
+`python -m torch.distributed.run` (a CHILD process, before anything here has touched the GPU), forwards rank 0's
+JSON line and exits with the child's code.  Under torch.distributed.run (RANK / WORLD_SIZE set) it is one rank.
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Data parallel,
 weak scaling: every rank processes its own batch of 32; gradients are all-reduced over RCCL.
@@ -12,6 +15,8 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how each field i
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,13 +24,68 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 DIMS = [64, 128, 256, 512, 1024]
 H, W = 320, 427
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: bf16 MFMA dense peak (not the 2:1-sparsity figure)
+HBM_PEAK_TBS = 8.0                   # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
+# SURVEY.md 8(d), the north-star kernel `inc` (3->64->64 @320x427), ideal-fusion fp32 bytes per image: read x 1.64 MB,
+# write + re-read raw c0 34.98 + 34.98, write raw c1 34.98  (the consumer's re-read of c1 belongs to the next kernel)
+INC_ALGO_BYTES_PER_IMAGE_FP32 = (3 + 3 * 64) * H * W * 4
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json: 32)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed GLOBAL batch split over the ranks (configs[3]: 64); overrides --batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the short configs[1] (batch-16 inference) and configs[4]-share (bf16 batch 32) legs at N=1")
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the metric's arithmetic (BASELINE configs[1-3], default); bf16: mixed precision, configs[4]")
+    ap.add_argument("--graph", action="store_true", help="--workload infer only: replay the forward as one hipGraph")
+    ap.add_argument("--workload", choices=["train", "infer"], default="train",
+                    help="train: BASELINE configs[2] (the metric, default); infer: configs[1], eval-mode forward only")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no rank environment: run the N ranks as a child torch.distributed.run job.
+    Nothing in THIS process has initialised the GPU (torch is not even imported yet), so no exec of a GPU process occurs."""
+    import torch      # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asks for {args.gpus} ranks, one per GPU, but this node shows {have} GPU(s); "
+              "RCCL refuses two ranks on one device. Run on a node with enough GPUs.", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)        # launcher / RCCL chatter never reaches stdout
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def host_cores() -> int:
@@ -47,6 +107,8 @@ def host_cores() -> int:
 def cpu_baseline(seconds_budget: float = 25.0):
     """The reference's CPU path (its torch-operator sequence, oracle/torch_cpu_path.py) timed on this box's host
     cores on a bounded sample of the same workload: full train steps at 320x427, batch 2."""
+    import numpy as np
+    import torch
     from gelslim_depth_amd import synth
     from oracle import torch_cpu_path as ot      # cpu_baseline leg only
     cores = host_cores()
@@ -69,32 +131,154 @@ def cpu_baseline(seconds_budget: float = 25.0):
                       f"torch CPU operators as the reference executes them, median {med:.2f} s/step"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json: 32)")
-    ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling: fixed GLOBAL batch split over the ranks (configs[3]: 64); overrides --batch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync-bn", action="store_true")
-    ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32: the metric's arithmetic (BASELINE configs[1-3], default); bf16: mixed precision, configs[4]")
-    ap.add_argument("--graph", action="store_true", help="--workload infer only: replay the forward as one hipGraph")
-    ap.add_argument("--workload", choices=["train", "infer"], default="train",
-                    help="train: BASELINE configs[2] (the metric, default); infer: configs[1], eval-mode forward only")
-    args = ap.parse_args()
+class Leg:
+    """One timed workload: model + step + synthetic batch resident in HBM."""
 
+    def __init__(self, dev, rank, dtype, workload, batch, pg=None, sync_bn=False, graph=False):
+        import torch
+        from gelslim_depth_amd import synth
+        from gelslim_depth_amd.models.unet import UNet
+        from gelslim_depth_amd.train import TrainStep
+        self.torch = torch
+        self.dtype, self.workload, self.B = dtype, workload, batch
+        model = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS, precision="bf16" if dtype == "bf16" else "fp32")
+        st = synth.make_state(3, 1, DIMS, 0, "conditioned")            # random-init weights of the named architecture
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        self.model = model.to(dev).train()
+        self.step = TrainStep(self.model, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse", process_group=pg,
+                              sync_bn=sync_bn)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        self.x = torch.rand((batch, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
+        self.tgt = -0.9 * torch.rand((batch, 1, H, W), device=dev, generator=g)         # U(-0.9,0] (normalised depth)
+        if workload == "infer":
+            self.model.eval()
+            if graph:
+                from gelslim_depth_amd.graph import GraphedInference
+                graphed = GraphedInference(self.model, self.x)
+                self.one_step = lambda: graphed(self.x)
+            else:
+                self.one_step = self._infer
+        else:
+            self.one_step = lambda: self.step(self.x, self.tgt)
+
+    def _infer(self):
+        with self.torch.no_grad():
+            self.model(x=self.x)
+
+    def run(self, steps, warmup, barrier):
+        """W untimed steps, then exactly K steps between two barrier+synchronize; returns (seconds, kernel log, regions)."""
+        for _ in range(warmup):
+            self.one_step()
+        barrier()
+        eng = self.model._engine
+        eng.kernel_log, eng.region_log = [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        klog, rlog = eng.kernel_log, eng.region_log
+        eng.kernel_log = eng.region_log = None
+        return elapsed, klog, rlog
+
+    def inc_hbm(self, rlog):
+        """North-star second roofline: the `inc` double-conv forward against the HBM roof.  achieved = ALGORITHMIC bytes
+        (SURVEY 8(d) ideal fusion, halved for bf16 storage) / measured time of the region (HIP events on the launch stream)."""
+        ms = [a.elapsed_time(b) for name, a, b in rlog if name == "inc_forward"]
+        if not ms:
+            return None
+        avg = sum(ms) / len(ms)
+        by = INC_ALGO_BYTES_PER_IMAGE_FP32 * self.B * (0.5 if self.dtype == "bf16" else 1.0)
+        tbs = by / (avg * 1e-3) / 1e12
+        return {"bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
+                + ("im2col + 2 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
+                   else "direct conv + Winograd conv + BN statistics launches"),
+                "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),
+                "algorithmic_bytes": int(by), "avg_ms": round(avg, 4), "launches_timed": len(ms),
+                "note": ("fp32: this block is MFMA-bound (AI 99 FLOP/B vs ridge 20), the HBM fraction is reported, not targeted"
+                         if self.dtype == "f32" else "bf16: AI ~200 FLOP/B vs ridge ~310, HBM roof applies")}
+
+
+def conv_roofline(klog, dtype, steps, ms_per_step, per_layer=False):
+    """Roofline of the dominant conv3x3 kernel from the live HIP-event log.
+    klog rows: (kernel, algorithmic flops, event, event, shape[, flops executed by the MFMAs])."""
+    klog = [r if len(r) > 5 else tuple(r) + (r[1],) for r in klog]
+    peak = FP32_MFMA_PEAK_TFLOPS if dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    by_kernel = {}
+    for v, f, a, b, _, ex in klog:
+        d = by_kernel.setdefault(v, [0.0, 0.0, 0, 0.0])
+        d[0] += f
+        d[1] += a.elapsed_time(b)
+        d[2] += 1
+        d[3] += ex
+    if dtype == "f32":
+        dom = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else "conv3x3_w43_kernel"
+    else:
+        dom = "bf16_conv3x3"
+    flops, ms, launches, executed = by_kernel.get(dom, [0.0, 0.0, 0, 0.0])
+    all_flops = sum(r[1] for r in klog)
+    all_ms = sum(r[2].elapsed_time(r[3]) for r in klog)
+    if per_layer:
+        import collections
+        if dtype == "bf16":
+            for v, (f, t, c, _) in by_kernel.items():
+                print("%-16s launches %4d total %.2f ms/step  %.1f TFLOP/s" %
+                      (v, c, t / steps, f / (t * 1e-3) / 1e12), file=sys.stderr)
+        else:
+            agg = collections.OrderedDict()
+            for v, f, a, b, sig, _ in klog:
+                d = agg.setdefault(sig, [0.0, 0.0, 0])
+                d[0] += f
+                d[1] += a.elapsed_time(b)
+                d[2] += 1
+            for sig, (f, t, c) in agg.items():
+                print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
+                      (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
+    algorithmic = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    done = executed / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # achieved = flops the kernel's MFMA instructions EXECUTE (2048 per v_mfma_f32_16x16x4_f32, tile padding included) / time:
+    # <= peak by construction.  The Winograd F(4,3) kernel needs half the multiplications of the direct convolution, so the
+    # ALGORITHMIC rate (2*9*Cout*Cin flops per pixel / time, what SURVEY 8(d) prices) is reported next to it and may exceed peak.
+    return dom, {"bound": "mfma", "kernel": dom, "achieved": round(done, 2), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(done / peak, 4),
+                 "algorithmic_tflops": round(algorithmic, 2), "algorithmic_vs_peak": round(algorithmic / peak, 4),
+                 "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                 "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
+                 "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+                 "conv3x3_share_of_step": round(all_ms / steps / ms_per_step, 3) if ms_per_step > 0 else 0.0}
+
+
+def workload_name(dtype, workload, B):
+    if workload == "infer":
+        return ("BASELINE.json configs[1]: batch-%d eval-mode forward %s, 3x320x427 -> 1x320x427, "
+                "U-Net [64,128,256,512,1024], HIP kernels" % (B, "fp32" if dtype == "f32" else "bf16"))
+    if dtype == "f32":
+        head = "BASELINE.json configs[2]: batch-%d full train step (fwd+MSE+bwd+Adam+EMA) fp32, " % B
+    else:
+        head = ("BASELINE.json configs[4] (per-GPU share): batch-%d full train step, bf16 mixed precision "
+                "(bf16 NHWC activations on bf16 MFMA, fp32 master weights/statistics/Adam), " % B)
+    return head + "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels"
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
+                         "one rank per GPU is required (RCCL refuses duplicate devices)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
+    n_ranks_seen = 1
     if world > 1 or os.environ.get("GSD_FORCE_SYNC"):
         import torch.distributed as dist
         # keep stdout to the ONE JSON line: RCCL writes its version banner (NCCL_DEBUG=VERSION is exported in this image) and
@@ -108,121 +292,50 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
+        n_ranks_seen = dist.get_world_size()
 
-    from gelslim_depth_amd import synth
-    from gelslim_depth_amd.models.unet import UNet
-    from gelslim_depth_amd.train import TrainStep
-
-    model = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS, precision="bf16" if args.dtype == "bf16" else "fp32")
-    st = synth.make_state(3, 1, DIMS, 0, "conditioned")            # random-init weights of the named architecture
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
-    model = model.to(dev).train()
-    step = TrainStep(model, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse", process_group=pg,
-                     sync_bn=args.sync_bn)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
     B = args.batch
     if args.global_batch > 0:
         if args.global_batch % world:
             raise SystemExit("--global-batch must be divisible by the number of ranks")
         B = args.global_batch // world
-    x = torch.rand((B, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
-    tgt = -0.9 * torch.rand((B, 1, H, W), device=dev, generator=g)         # U(-0.9,0] (normalised depth)
 
     def barrier():
         if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "infer":
-        model.eval()
-        if args.graph:
-            from gelslim_depth_amd.graph import GraphedInference
-            graphed = GraphedInference(model, x)
-
-            def one_step():
-                graphed(x)
-        else:
-            def one_step():
-                with torch.no_grad():
-                    model(x=x)
-    else:
-        def one_step():
-            step(x, tgt)
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    eng = model._engine
-    eng.kernel_log = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    klog = eng.kernel_log
-    eng.kernel_log = None
-    loss = float(step.last_loss.item())
+    leg = Leg(dev, rank, args.dtype, args.workload, B, pg=pg, sync_bn=args.sync_bn, graph=args.graph)
+    elapsed, klog, rlog = leg.run(args.steps, args.warmup, barrier)
+    loss = float(leg.step.last_loss.item())
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     if rank == 0:
-        # dominant kernel: the conv3x3 kernel (forward + dX launches) with the largest share of the timed region.
-        # klog rows: (kernel, algorithmic flops, event, event, shape[, flops executed by the MFMAs])
-        klog = [r if len(r) > 5 else tuple(r) + (r[1],) for r in klog]
-        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-        by_kernel = {}
-        for v, f, a, b, _, ex in klog:
-            d = by_kernel.setdefault(v, [0.0, 0.0, 0, 0.0])
-            d[0] += f
-            d[1] += a.elapsed_time(b)
-            d[2] += 1
-            d[3] += ex
-        if args.dtype == "f32":
-            dom = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else "conv3x3_w43_kernel"
-        else:
-            dom = "bf16_conv3x3"
-        flops, ms, launches, executed = by_kernel.get(dom, [0.0, 0.0, 0, 0.0])
-        all_flops = sum(r[1] for r in klog)
-        all_ms = sum(r[2].elapsed_time(r[3]) for r in klog)
-        if args.per_layer:
-            import collections
-            agg = collections.OrderedDict()
-            for v, f, a, b, sig, _ in klog:
-                d = agg.setdefault(sig, [0.0, 0.0, 0])
-                d[0] += f
-                d[1] += a.elapsed_time(b)
-                d[2] += 1
-            if args.dtype == "bf16":
-                byname = collections.OrderedDict()
-                for v, f, a, b, _, _ in klog:
-                    d = byname.setdefault(v, [0.0, 0.0, 0])
-                    d[0] += f
-                    d[1] += a.elapsed_time(b)
-                    d[2] += 1
-                for v, (f, t, c) in byname.items():
-                    print("%-16s launches %4d total %.2f ms/step  %.1f TFLOP/s" %
-                          (v, c, t / args.steps, f / (t * 1e-3) / 1e12), file=sys.stderr)
-            else:
-                for sig, (f, t, c) in agg.items():
-                    print("conv3x3 M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
-                          (sig + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json)
+        ms_per_step = elapsed / args.steps * 1e3
+        dom, roof = conv_roofline(klog, args.dtype, args.steps, ms_per_step, args.per_layer)
+        # HBM bytes per launch of the dominant kernel: NOT observed by this run -- read from the committed rocprofv3 --pmc passes
+        # (separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; profiles/traffic.json names its sources)
+        roof["traffic"], roof["traffic_source"] = None, None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
             if tj.get("kernel") == dom and B == 32 and args.dtype == "f32":
-                traffic = round(float(tj["hbm_bytes_per_launch"]))
+                roof["traffic"] = round(float(tj["hbm_bytes_per_launch"]))
+                roof["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes: %s)" % ", ".join(tj.get("sources", []))
         except (OSError, ValueError, KeyError):
             pass
-        ms_per_step = elapsed / args.steps * 1e3
+        hbm = leg.inc_hbm(rlog)
+        if hbm is not None:
+            roof["hbm"] = hbm
         out = {
             "metric": "train frames/sec (320x427) at batch 32" if args.workload == "train"
                       else "inference frames/sec (320x427), eval-mode forward",
             "value": round(B * world * args.steps / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -231,32 +344,35 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": (("BASELINE.json configs[2]: batch-%d full train step (fwd+MSE+bwd+Adam+EMA) fp32, " % B
-                                     if args.dtype == "f32" else
-                                     "BASELINE.json configs[4] (per-GPU share): batch-%d full train step, bf16 mixed precision "
-                                     "(bf16 NHWC activations on bf16 MFMA, fp32 master weights/statistics/Adam), " % B) +
-                                    "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels")
-                                   if args.workload == "train" else
-                                   ("BASELINE.json configs[1]: eval-mode forward fp32, 3x320x427 -> 1x320x427, "
-                                    "U-Net [64,128,256,512,1024], HIP kernels"),
+            "config": {"workload": workload_name(args.dtype, args.workload, B),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6),
                        "conv3x3_form": ("bf16 MFMA implicit GEMM" if args.dtype == "bf16" else
                                         {"0": "direct taps", "1": "winograd F(4,3) rows"}.get(
                                             os.environ.get("GSD_CONV_ALGO", ""), "winograd F(4,3) rows, fp32 (Cin>=16) / direct taps (first layer)"))},
-            "roofline": {"bound": "mfma", "kernel": dom,
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         # achieved = ALGORITHMIC flops (2*9*Cout*Cin per pixel) / time.  The Winograd F(4,3) kernel executes
-                         # half of them (+ tile padding), so frac can exceed 1; mfma_frac = flops its MFMAs actually issued
-                         # / time / peak is the matrix-core utilisation.
-                         "mfma_executed": round(executed / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
-                         "mfma_frac": round(executed / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else 0.0,
-                         "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                         "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
-                         "all_conv3x3_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
-                         "conv3x3_share_of_step": round(all_ms / args.steps / ms_per_step, 3)},
+            "roofline": roof,
         }
+        if world == 1 and not args.no_extra and args.workload == "train" and args.dtype == "f32":
+            # the other single-GPU configurations BASELINE.json names, a few steps each, AFTER the timed region of the metric
+            del leg
+            torch.cuda.empty_cache()
+            extra = {}
+            for key, dt, wl, b in (("configs[1] batch-16 inference fp32", "f32", "infer", 16),
+                                   ("configs[4] per-GPU share: batch-32 bf16 train step", "bf16", "train", 32)):
+                lg = Leg(dev, 0, dt, wl, b)
+                el, kl, rl = lg.run(5, 2, barrier)
+                _, rf = conv_roofline(kl, dt, 5, el / 5 * 1e3)
+                e = {"workload": workload_name(dt, wl, b), "value": round(b * 5 / el, 2), "unit": "frames/s",
+                     "ms_per_step": round(el / 5 * 1e3, 3), "steps": 5, "warmup": 2, "dtype": dt, "roofline": rf}
+                h = lg.inc_hbm(rl)
+                if h is not None:
+                    e["roofline"]["hbm"] = h
+                if wl == "train":
+                    e["final_loss"] = round(float(lg.step.last_loss.item()), 6)
+                extra[key] = e
+                del lg
+                torch.cuda.empty_cache()
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

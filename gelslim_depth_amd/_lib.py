@@ -32,6 +32,11 @@ class gsd_dst(C.Structure):
                 ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
 
 
+class gsd_guard(C.Structure):
+    """Non-finite guard of a train step (include/gsd.h): two device int32 words + the step's tick."""
+    _fields_ = [("words", C.c_void_p), ("tick", C.c_int32)]
+
+
 class gsd_nhwc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("pitch", C.c_int64),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32)]
@@ -44,6 +49,7 @@ _F = C.c_float
 _D = C.c_double
 _SRC = C.POINTER(gsd_src)
 _DST = C.POINTER(gsd_dst)
+_GUARD = C.POINTER(gsd_guard)
 class gsd_bf16_bnbwd(C.Structure):
     _fields_ = [("y", C.POINTER(gsd_nhwc)), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
                 ("invstd", C.c_void_p)]
@@ -75,7 +81,7 @@ SIGNATURES = {
     "gsd_convT2x2_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_convT2x2_wgrad": (_I, [_SRC, _SRC, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_bn_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
-    "gsd_bn_finalize": (_I, [_P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gsd_bn_finalize": (_I, [_P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _GUARD, _P]),
     "gsd_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "gsd_bn_bwd_partial_rows": (_I, [_I, _I, _I, _I]),
     "gsd_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _SRC, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
@@ -85,9 +91,9 @@ SIGNATURES = {
     "gsd_sum_planes": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "gsd_maxpool2": (_I, [_SRC, _P, _I, _I, _I, _I, _P]),
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
-    "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _P]),
-    "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P]),
-    "gsd_bn_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _GUARD, _P]),
+    "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _GUARD, _P]),
+    "gsd_bn_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _GUARD, _P]),
     "gsd_bn_bwd_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _P, _P, _P, _P]),
     "gsd_area_resize_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _F, _F, _P]),
     "gsd_ingest_images": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _I, _F, _F, _P]),
@@ -202,6 +208,18 @@ def make_nhwc(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None) -> g
     d.N, d.H, d.W = n, h, w
     d.C = ct - c_off if c_len is None else c_len
     return d
+
+
+def make_guard(words: Optional[torch.Tensor], tick: int):
+    """gsd_guard over a 2-element int32 device tensor, or None (a NULL guard)."""
+    if words is None:
+        return None
+    if words.dtype != torch.int32 or not words.is_cuda or words.numel() < 2 or tick == 0:
+        raise GsdError("a guard needs two int32 words on the GPU and a non-zero tick")
+    g = gsd_guard()
+    g.words = words.data_ptr()
+    g.tick = tick
+    return C.pointer(g)
 
 
 def int_array(vals: Sequence[int]):

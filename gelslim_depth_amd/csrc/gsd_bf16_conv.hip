@@ -495,15 +495,10 @@ int launch(GConvP& P, long items, size_t lds, hipStream_t st, const char* what) 
   GSD_REQUIRE(items > 0 && items < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: %ld work items out of range", what, items);
   P.nitems = (int)items;
   const long grid = launch_grid(items, P.mblocks);
-  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>)); e != hipSuccess) {
+    gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   GSD_REQUIRE(grid > 0 && grid < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: grid %ld out of range", what, grid);
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "%s: LDS %zu B too large", what, lds);

@@ -276,7 +276,7 @@ WPlan make_wplan(bool halo, int T, int N, int H, int W, int M, int Ncols) {
   p.mblocks = ceil_div(M, p.BM);
   p.nblocks = ceil_div(Ncols, p.BNC);
   p.stages_total = N * p.tiles_y * p.tiles_x;
-  static const int target = getenv("GSD_BF16_WGRAD_BLOCKS") ? atoi(getenv("GSD_BF16_WGRAD_BLOCKS")) : 512;   // tuning knob
+  const int target = gsd_env_int("GSD_BF16_WGRAD_BLOCKS", 512);   // tuning knob
   int splits = ceil_div(target, p.mblocks * p.nblocks);   // default: ONE round of 2 resident blocks per CU x 256 CUs (measured: 512 -> 866 TFLOP/s, 1024 -> 766, 256 -> 647 over the layer set; fewer splits also halve the slab traffic)
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits < 1) splits = 1;
@@ -290,15 +290,10 @@ WPlan make_wplan(bool halo, int T, int N, int H, int W, int M, int Ncols) {
 
 template <int HALO, int TT, int WM, int WN>
 int launch_w(const GWgradP& P, int grid, size_t lds, hipStream_t st, const char* what) {
-  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gwgrad_bf16_kernel<HALO, TT, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gwgrad_bf16_kernel<HALO, TT, WM, WN>)); e != hipSuccess) {
+    gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "%s: LDS %zu B too large", what, lds);
   hipLaunchKernelGGL((gwgrad_bf16_kernel<HALO, TT, WM, WN>), dim3(grid), dim3(256), lds, st, P);

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 #include "gsd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -134,6 +136,30 @@ static inline int gsd_check_dst(const gsd_dst& s, const char* what) {
               what);
   return 0;
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): remember per device (bit = device
+// ordinal) that it has been set.  The only process-wide state of the library: an idempotent launch-attribute cache that no
+// result depends on (setting the attribute twice is harmless, so a lost race only repeats the call).
+struct gsd_attr_once {
+  std::atomic<uint64_t> mask{0};
+};
+static inline hipError_t gsd_allow_big_lds(gsd_attr_once& once, const void* fn, int bytes = 160 * 1024) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev < 64 && (once.mask.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev < 64) once.mask.fetch_or(bit, std::memory_order_relaxed);
+  return e;
+}
+// Tuning knobs are read from the environment on EVERY call (no cached statics: a test or an A/B harness may change them
+// inside one process, and the library keeps no mutable state that a result depends on).
+static inline int gsd_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v != nullptr ? atoi(v) : dflt;
+}
+static inline bool gsd_env_set(const char* name) { return getenv(name) != nullptr; }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

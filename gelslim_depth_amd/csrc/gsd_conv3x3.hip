@@ -371,7 +371,7 @@ struct ConvPlan {
 };
 
 ConvPlan plan_conv3x3(int H, int W, int M) {
-  static const int big_min = getenv("GSD_CONV_BIG") ? atoi(getenv("GSD_CONV_BIG")) : 0;   // tuning: min H*W for 128x256
+  const int big_min = gsd_env_int("GSD_CONV_BIG", 0);   // tuning: min H*W for 128x256
   ConvPlan p;
   p.wide = M <= 64;
   p.big = !p.wide && big_min > 0 && H * W >= big_min;
@@ -387,15 +387,10 @@ ConvPlan plan_conv3x3(int H, int W, int M) {
 
 template <int WM, int WN, int NT>
 int launch(const Conv3Params& P, int grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<WM, WN, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("gsd_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&conv3x3_dma_kernel<WM, WN, NT>)); e != hipSuccess) {
+    gsd_set_error("gsd_conv3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   hipLaunchKernelGGL((conv3x3_dma_kernel<WM, WN, NT>), dim3(grid), dim3(256), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3");
@@ -473,7 +468,7 @@ static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, 
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3: grid too large");
   size_t lds = (size_t)(2 * (36 * pl.BM + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * pl.BM) * sizeof(float);   // 2 tile images + BN coefficients (input side, output side)
-  static const int lds_min = getenv("GSD_CONV_LDS_MIN") ? atoi(getenv("GSD_CONV_LDS_MIN")) : 0;   // tuning: cap blocks/CU
+  const int lds_min = gsd_env_int("GSD_CONV_LDS_MIN", 0);   // tuning: cap blocks/CU
   if ((size_t)lds_min > lds) lds = lds_min;
   if (pl.wide) return launch<1, 4, 4>(P, (int)grid, lds, (hipStream_t)stream);
   if (pl.big) return launch<2, 2, 8>(P, (int)grid, lds, (hipStream_t)stream);

@@ -437,7 +437,7 @@ struct W43Plan {
 // the kernel than their tighter fit saves).
 bool plan_w43(int H, int W, int M, W43Plan* best) {
   long best_cost = -1;
-  static const int force_tw = getenv("GSD_W43_TW") ? atoi(getenv("GSD_W43_TW")) : 0;   // tuning
+  const int force_tw = gsd_env_int("GSD_W43_TW", 0);   // tuning
   for (int tw = 4; tw <= 64; tw *= 2) {
     if (force_tw && tw != force_tw) continue;
     int th = 256 / tw;
@@ -461,15 +461,10 @@ bool plan_w43(int H, int W, int M, W43Plan* best) {
 
 template <int WM>
 int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM>)); e != hipSuccess) {
+    gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: LDS image %zu B too large", lds);
   hipLaunchKernelGGL(conv3x3_w43_kernel<WM>, dim3(grid), dim3(256 * WM), lds, st, P);
@@ -533,7 +528,7 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.nchunks = ceil_div(Cin, 4);
   // measured (profiles/bench_conv_forms.py): two independent 4-wave blocks per CU hide each other's barriers better than one
   // 8-wave block shares its halo (+6 % for the 8-wave form at Cin <= 512, +1.5 % at Cin = 1024); GSD_W43_BIG=1 selects it
-  static const bool big = getenv("GSD_W43_BIG") != nullptr;
+  const bool big = gsd_env_set("GSD_W43_BIG");
   const int WM = (pl.mblocks % 2 == 0 && big) ? 2 : 1;
   P.mblocks = pl.mblocks / WM;
   P.N = N; P.H = H; P.W = W;

@@ -196,13 +196,26 @@ extern "C" int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad,
   return GSD_OK;
 }
 
+// Non-finite guard (gsd_guard, include/gsd.h): a batch statistic that is NaN/Inf never reaches the running statistics (a
+// diverged or NaN-fed step would otherwise poison eval mode for good: every consumer turns a NaN activation into 0 through
+// max(., 0), so the loss can stay finite), and the step is marked so that gsd_adam_ema can skip it.
+// Returns whether the running statistics may be updated: not with non-finite values, and not once an EARLIER layer of this
+// step has raised the guard (behind a NaN layer the activations are all 0 -- finite, but not statistics worth keeping).
+__device__ __forceinline__ bool bn_stats_finite(double mu, double var, int* guard_words, int tick) {
+  const bool finite = isfinite(mu) && isfinite(var);
+  if (guard_words == nullptr) return finite;
+  if (!finite) guard_words[0] = tick;   // benign race: every writer stores the same tick
+  return finite && guard_words[0] != tick;
+}
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+                                   float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                   int* guard_words, int tick) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double mu = sums[c] / count;
   double var = sums[C + c] / count - mu * mu;  // biased (normalisation) variance
+  const bool finite = bn_stats_finite(mu, var, guard_words, tick);
   if (var < 0.0) var = 0.0;
   const double is = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * is);
@@ -210,7 +223,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
   invstd[c] = (float)is;
   scale[c] = sc;
   shift[c] = (float)((double)beta[c] - mu * (double)gamma[c] * is);
-  if (running_mean != nullptr) {
+  if (running_mean != nullptr && finite) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
                                                                  double* __restrict__ sums, double count, const float* gamma,
                                                                  const float* beta, float eps, float momentum, float* running_mean,
                                                                  float* running_var, float* mean, float* invstd, float* scale,
-                                                                 float* shift) {
+                                                                 float* shift, int* guard_words, int tick) {
   const int off[2] = {0, off2};
   double v[2];
   if (!rf_block_sums<2>(part, rows, ld, off, C, v)) return;
@@ -264,13 +277,14 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
   sums[C + c] = q;
   const double mu = s / count;
   double var = q / count - mu * mu;
+  const bool finite = bn_stats_finite(mu, var, guard_words, tick);
   if (var < 0.0) var = 0.0;
   const double is = 1.0 / sqrt(var + (double)eps);
   mean[c] = (float)mu;
   invstd[c] = (float)is;
   scale[c] = (float)((double)gamma[c] * is);
   shift[c] = (float)((double)beta[c] - mu * (double)gamma[c] * is);
-  if (running_mean != nullptr) {
+  if (running_mean != nullptr && finite) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
@@ -279,13 +293,15 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
 
 extern "C" int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad, int C, double* sums, double count,
                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                                      float* running_var, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+                                      float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                      const gsd_guard* guard, void* stream) {
   GSD_REQUIRE(partials && sums && gamma && beta && mean && invstd && scale && shift && rows > 0 && C > 0 && Mpad >= C && count > 0,
               GSD_ERR_BAD_ARG, "gsd_bn_reduce_finalize: bad argument");
   GSD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GSD_ERR_BAD_ARG,
               "gsd_bn_reduce_finalize: running stats must come together");
   hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(C, RF_CH)), dim3(RF_CH * RF_LANES), 0, (hipStream_t)stream, partials, rows, 2 * Mpad,
-                     Mpad, C, sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     Mpad, C, sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                     guard ? guard->words : nullptr, guard ? guard->tick : 0);
   GSD_LAUNCH_CHECK("gsd_bn_reduce_finalize");
   return GSD_OK;
 }
@@ -325,13 +341,14 @@ extern "C" int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int l
 
 extern "C" int gsd_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                               float* scale, float* shift, void* stream) {
+                               float* scale, float* shift, const gsd_guard* guard, void* stream) {
   GSD_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && count > 0, GSD_ERR_BAD_ARG,
               "gsd_bn_finalize: bad argument");
   GSD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GSD_ERR_BAD_ARG,
               "gsd_bn_finalize: running stats must come together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, count, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                     guard ? guard->words : nullptr, guard ? guard->tick : 0);
   GSD_LAUNCH_CHECK("gsd_bn_finalize");
   return GSD_OK;
 }
@@ -649,15 +666,19 @@ __global__ __launch_bounds__(256) void loss_stage1(const float* __restrict__ o, 
   __syncthreads();
   if (threadIdx.x == 0) reinterpret_cast<double*>(ws)[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void loss_stage2(const float* ws, int nblocks, long long numel, float* loss_out) {
+__global__ void loss_stage2(const float* ws, int nblocks, long long numel, float* loss_out, int* guard_words, int tick) {
   // single wave
   double s = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 64) s += reinterpret_cast<const double*>(ws)[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) loss_out[0] = (float)(s / (double)numel);
+  if (threadIdx.x == 0) {
+    const float loss = (float)(s / (double)numel);
+    loss_out[0] = loss;
+    if (guard_words != nullptr && !isfinite(loss)) guard_words[0] = tick;   // the reference's `pred_loss.isnan()` test, on the device
+  }
 }
 extern "C" int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_t numel, float grad_scale, float* loss_out,
-                                float* grad, float* workspace, void* stream) {
+                                float* grad, float* workspace, const gsd_guard* guard, void* stream) {
   GSD_REQUIRE(o && t && loss_out && workspace && numel > 0 && (kind == 0 || kind == 1), GSD_ERR_BAD_ARG,
               "gsd_loss_fwd_bwd: bad argument");
   GSD_REQUIRE(((uintptr_t)workspace & 7) == 0, GSD_ERR_BAD_ARG, "gsd_loss_fwd_bwd: workspace must be 8-byte aligned");
@@ -669,7 +690,8 @@ extern "C" int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_
     hipLaunchKernelGGL((loss_stage1<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, o, t, (long long)numel,
                        grad_scale, grad, workspace);
   GSD_LAUNCH_CHECK("gsd_loss_fwd_bwd stage1");
-  hipLaunchKernelGGL(loss_stage2, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, blocks, (long long)numel, loss_out);
+  hipLaunchKernelGGL(loss_stage2, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, blocks, (long long)numel, loss_out,
+                     guard ? guard->words : nullptr, guard ? guard->tick : 0);
   GSD_LAUNCH_CHECK("gsd_loss_fwd_bwd stage2");
   return GSD_OK;
 }
@@ -681,7 +703,11 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ ema, long long numel, float lr_over_bc1,
                                                        float sqrt_bc2, float b1, float b2, float eps, float wd,
-                                                       float one_minus_d, float gscale) {
+                                                       float one_minus_d, float gscale, int* guard_words, int tick) {
+  if (guard_words != nullptr && guard_words[0] == tick) {   // this step saw a non-finite statistic or loss: skip it, count it
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard_words[1], 1);
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long long)gridDim.x * 256) {
     float pv = p[i];
     const float gv = fmaf(wd, pv, g[i] * gscale);   // g += wd*p            (torch _single_tensor_adam)
@@ -701,15 +727,18 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 }
 extern "C" int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, int step, float lr,
                             float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
-                            void* stream) {
+                            const gsd_guard* guard, void* stream) {
   GSD_REQUIRE(p && g && m && v && numel > 0 && step >= 1, GSD_ERR_BAD_ARG, "gsd_adam_ema: bad argument");
+  GSD_REQUIRE(guard == nullptr || (guard->words != nullptr && guard->tick != 0), GSD_ERR_BAD_ARG,
+              "gsd_adam_ema: a guard needs its two device words and a non-zero tick");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float lr_over_bc1 = (float)((double)lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
   const int blocks = (int)(ceil_div64(numel, 256) < 4096 ? ceil_div64(numel, 256) : 4096);
   hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)numel,
-                     lr_over_bc1, sqrt_bc2, beta1, beta2, eps, weight_decay, 1.0f - ema_decay, grad_scale);
+                     lr_over_bc1, sqrt_bc2, beta1, beta2, eps, weight_decay, 1.0f - ema_decay, grad_scale,
+                     guard ? guard->words : nullptr, guard ? guard->tick : 0);
   GSD_LAUNCH_CHECK("gsd_adam_ema");
   return GSD_OK;
 }

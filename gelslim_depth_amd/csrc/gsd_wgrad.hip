@@ -571,7 +571,7 @@ void choose_wgrad_tile(int H, int W, int* TH, int* TW) {
   // (stages * pixels per stage); then the WIDEST rows: a DMA instruction that covers one 256-byte row segment is
   // measurably faster than one that covers two 128-byte segments (TH 2 x TW 32 was 13 % slower than 1 x 64 although
   // its halo traffic is a third lower) -- the cost is per cache line touched, not per byte.
-  static const bool halo_first = getenv("GSD_WGRAD_HALO") != nullptr;
+  const bool halo_first = gsd_env_set("GSD_WGRAD_HALO");
   long min_work = -1;
   for (int pass = 0; pass < 2; ++pass) {
     long best = -1;
@@ -634,7 +634,7 @@ WgradPlan plan_wgrad(int mode, int N, int H, int W, int M, int Ncols) {
     p.stages_total = N * p.tiles_flat;
   }
   const int tiles = p.mblocks * p.nblocks;
-  static const int target3 = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;   // tuning knob (512: one round of 2 blocks/CU; 1024 measured 1 % slower end to end)
+  const int target3 = gsd_env_int("GSD_WGRAD_BLOCKS", 512);   // tuning knob (512: one round of 2 blocks/CU; 1024 measured 1 % slower end to end)
   int splits = ceil_div(target3, tiles);   // one round of 2 resident blocks per CU x 256 CUs
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits > 2048) splits = 2048;
@@ -656,15 +656,10 @@ int check_plain(const gsd_src& s, const char* what) {
 
 template <int WM, int WN>
 int launch_convT_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wgrad_kernel<WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_wgrad_kernel<WM, WN>)); e != hipSuccess) {
+    gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   hipLaunchKernelGGL((convT_wgrad_kernel<WM, WN>), dim3(grid), dim3(256), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");
@@ -673,15 +668,10 @@ int launch_convT_wgrad(const WgradParams& P, int grid, size_t lds, hipStream_t s
 
 template <int WM, int WN, int NBUF>
 int launch_dma(const WgradParams& P, int grid, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_dma_kernel<WM, WN, NBUF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
-    attr_done = true;
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&wgrad3x3_dma_kernel<WM, WN, NBUF>)); e != hipSuccess) {
+    gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: LDS tile %zu B too large", lds);
   hipLaunchKernelGGL((wgrad3x3_dma_kernel<WM, WN, NBUF>), dim3(grid), dim3(NBUF == 3 ? 512 : 256), lds, st, P);
@@ -747,7 +737,7 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
   for (int i = 0; i < nsrc; ++i)
     GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
                 "gsd_conv3x3_wgrad: an affine activation segment must also have relu (zero padding uses a NaN sentinel)");
-  static const int wmode = getenv("GSD_WGRAD_MODE") ? atoi(getenv("GSD_WGRAD_MODE")) : 1;   // 1 (default, fastest) / 2 / 3: see kernel
+  const int wmode = gsd_env_int("GSD_WGRAD_MODE", 1);   // 1 (default, fastest) / 2 / 3: see kernel
   const int nslabs = pl.ksplit ? 4 * pl.splits : (wmode == 3 ? 2 * pl.splits : pl.splits);
   int rc;
   if (pl.ksplit)
@@ -805,15 +795,10 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
   if (pl.wide) {   // M = 4*Cout <= 64: never the case for this network; the register-staged kernel keeps it working
     rc = launch_convT_wgrad<1, 4>(P, grid, lds, (hipStream_t)stream);
   } else {
-    static bool attr_done = false;  // benign race: setting the same attribute twice is harmless
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT_wgrad_dma_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return GSD_ERR_HIP;
-      }
-      attr_done = true;
+    static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+    if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_wgrad_dma_kernel)); e != hipSuccess) {
+      gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
     }
     hipLaunchKernelGGL(convT_wgrad_dma_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
     GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");

@@ -366,7 +366,7 @@ struct WgW43Plan {
 WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   WgW43Plan p;
   long best = -1;
-  static const int force_tw = getenv("GSD_WG43_TW") ? atoi(getenv("GSD_WG43_TW")) : 0;   // tuning
+  const int force_tw = gsd_env_int("GSD_WG43_TW", 0);   // tuning
   for (int tw = 4; tw <= 64; tw *= 2) {   // 16 tiles = TH rows x TW/4 tiles
     if (force_tw && tw != force_tw) continue;
     const int th = 64 / tw;
@@ -386,13 +386,13 @@ WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   // channel stride: whole 64-lane DMA instructions land inside the channel's slot, and = 4 mod 8 floats so that the 16
   // channels of a ds_read_b128 hit 16 different bank groups
   p.XS = round_up(((p.WR * p.WCp + 63) / 64) * 64, 8) + 4;
-  static const bool small = getenv("GSD_WG43_SMALL") != nullptr;   // tuning: 4-wave blocks only
+  const bool small = gsd_env_set("GSD_WG43_SMALL");   // tuning: 4-wave blocks only
   p.BM = (M >= 128 && !small) ? 128 : 64;
   p.BN = (p.BM == 64 && Ncols >= 64 && !small) ? 64 : 32;
   p.mblocks = ceil_div(M, p.BM);
   p.nblocks = ceil_div(Ncols, p.BN);
   p.stages_total = N * p.tiles_y * p.tiles_x;
-  static const int target = getenv("GSD_WGRAD_BLOCKS") ? atoi(getenv("GSD_WGRAD_BLOCKS")) : 512;
+  const int target = gsd_env_int("GSD_WGRAD_BLOCKS", 512);
   int splits = ceil_div(p.BM * p.BN > 64 * 32 ? target / 2 : target, p.mblocks * p.nblocks);   // one round of resident blocks
   if (splits > p.stages_total) splits = p.stages_total;
   if (splits > 2048) splits = 2048;
@@ -434,20 +434,15 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   GSD_REQUIRE(pl.WR * pl.WCp <= 256, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: halo window too large");
   const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
   const size_t lds = (size_t)2 * (pl.BM * WG_DS + pl.BN * pl.XS) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    const void* fns[3] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2>),
-                          reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2>),
-                          reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4>)};
-    for (const void* fn : fns) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return GSD_ERR_HIP;
-      }
+  static gsd_attr_once big_lds[3];   // per-device caches of an idempotent launch attribute (gsd_common.h)
+  const void* fns[3] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4>)};
+  for (int i = 0; i < 3; ++i)
+    if (hipError_t e = gsd_allow_big_lds(big_lds[i], fns[i]); e != hipSuccess) {
+      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
     }
-    attr_done = true;
-  }
   if (pl.BM == 128)
     hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2>), dim3((int)grid), dim3(512), lds, (hipStream_t)stream, P);
   else if (pl.BN == 64)

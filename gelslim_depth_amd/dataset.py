@@ -270,18 +270,23 @@ class DeviceLoader:
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         """Data parallel: every rank draws the same permutation (same seed) and takes its contiguous share of each global
-        batch of batch_size*world_size samples (contiguous split of the global batch)."""
+        batch of batch_size*world_size samples (contiguous split of the global batch).
+
+        Every rank yields the SAME number of batches, each of the same size on every rank (the step issues collectives:
+        a rank that skipped the last step would leave the others blocked in the gradient all-reduce, and unequal shares
+        would mis-weight the 1/world gradient mean): a ragged last global batch is padded to a multiple of world_size by
+        wrapping around to the start of the permutation, as torch's DistributedSampler does, or dropped with drop_last."""
         perm = self.order().to(self.dataset.device)
-        n, per = perm.numel(), self.batch_size * self.world_size
+        n, per, world = perm.numel(), self.batch_size * self.world_size, self.world_size
         for s in range(0, n, per):
             g = perm[s:s + per]
             if g.numel() < per and self.drop_last:
                 break
-            share = (g.numel() + self.world_size - 1) // self.world_size
-            mine = g[self.rank * share:(self.rank + 1) * share]
-            if mine.numel() == 0:
-                continue
-            yield self.dataset.batch(mine)
+            pad = (-g.numel()) % world
+            if pad:
+                g = torch.cat([g, perm[torch.arange(pad, device=perm.device) % n]])
+            share = g.numel() // world
+            yield self.dataset.batch(g[self.rank * share:(self.rank + 1) * share])
 
 
 def train_epoch(step, loader: DeviceLoader) -> Tuple[float, int]:
@@ -292,4 +297,7 @@ def train_epoch(step, loader: DeviceLoader) -> Tuple[float, int]:
         losses.append(step(data["tactile_image"], data["depth_image"]).detach().clone())   # the step reuses its loss buffer
     if not losses:
         return 0.0, 0
-    return float(torch.stack(losses).sum().item()), len(losses)
+    total = float(torch.stack(losses).sum().item())
+    if hasattr(step, "check_finite"):
+        step.check_finite()          # nan_policy="raise": the epoch's one host sync has just happened
+    return total, len(losses)

@@ -37,7 +37,8 @@ def make_buckets(names: Sequence[str], offsets: Dict[str, Tuple[int, int]], n_le
 class GradSync:
     """Sum a flat gradient arena across ranks, bucket by bucket."""
 
-    def __init__(self, g_flat: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None, overlap: bool = True):
+    def __init__(self, g_flat: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None, overlap: bool = True,
+                 force: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.g = g_flat
@@ -45,7 +46,7 @@ class GradSync:
         self.group = group
         self.overlap = overlap
         self.world = dist.get_world_size(group)
-        self.force = bool(os.environ.get("GSD_FORCE_SYNC"))   # exercise the collectives with one rank
+        self.force = force or bool(os.environ.get("GSD_FORCE_SYNC"))   # exercise the collectives with one rank
         self._works: List = []
         self._done: List[str] = []
 

@@ -105,8 +105,11 @@ class UNetEngine:
         self.world = 1
         self._saved_train = False
         self.block_done_cb: Optional[Callable[[str], None]] = None   # data-parallel hook: a block's grads are final
+        self.guard = None          # non-finite guard of the current step (_lib.make_guard), set by TrainStep per step
+        self.generation = 0        # forwards so far: a backward belongs to exactly one (models/unet.py checks it)
         # bench hook: when a list, every conv3x3 launch appends (variant, flops, start_event, end_event)
         self.kernel_log: Optional[list] = None
+        self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
 
     # ------------------------------------------------------------------ buffers
     def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
@@ -198,7 +201,8 @@ class UNetEngine:
                 count *= self.world
             check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
                                       BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
-                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(),
+                                      self.guard, st),
                   "bn_finalize")
             P[u.nbtname].add_(1)   # int64 counter buffer (BatchNorm2d.num_batches_tracked)
         else:
@@ -207,7 +211,7 @@ class UNetEngine:
                   "bn_eval_coeffs")
 
     def _log_begin(self):
-        if self.kernel_log is None:
+        if self.kernel_log is None and self.region_log is None:
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -215,7 +219,7 @@ class UNetEngine:
 
     def _log_end(self, ev, m: int, k_ch: int, n: int, lh: int, lw: int, algo: int = 0) -> None:
         """(kernel, ALGORITHMIC flops of the convolution = 2*9*M*K*pixels, events, shape, flops the MFMAs executed)."""
-        if ev is None:
+        if ev is None or self.kernel_log is None:
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -247,11 +251,17 @@ class UNetEngine:
         st = L.stream_ptr()
         self._x = x
         self._saved_train = train
+        self.generation += 1       # every forward overwrites the saved activations
+        region = self._log_begin() if self.region_log is not None else None
         for lvl in range(self.L + 1):
             u0, u1 = self.enc[lvl]
             if lvl == 0:
                 srcs = [L.make_src(x)]
             else:
+                if lvl == 1 and region is not None:       # bench hook: the `inc` double-conv forward (2 convs + BN statistics)
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    self.region_log.append(("inc_forward", region, e))
                 prev = self.enc[lvl - 1][1]
                 s = self._act_src(prev)
                 check(lib.gsd_maxpool2(C.byref(s), self.pooled[lvl].data_ptr(), n, prev.cout, self.hs[lvl - 1],

@@ -101,7 +101,10 @@ class UNetEngineBF16:
         self.world = 1
         self._saved_train = False
         self.block_done_cb: Optional[Callable[[str], None]] = None
+        self.guard = None          # non-finite guard of the current step (_lib.make_guard), set by TrainStep per step
+        self.generation = 0        # forwards so far: a backward belongs to exactly one (models/unet.py checks it)
         self.kernel_log: Optional[list] = None
+        self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
 
     # ------------------------------------------------------------------ buffers
     def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
@@ -178,6 +181,20 @@ class UNetEngineBF16:
         dx = self.ws[lvl] - 2 * self.ws[lvl + 1]
         return dy // 2, dx // 2
 
+    def _region_begin(self):
+        if self.region_log is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _region_end(self, name: str, e0) -> None:
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.region_log.append((name, e0, e1))
+
     def _log(self, name: str, flops: float):
         """bench hook: returns a closer that records (name, flops, start, end)."""
         if self.kernel_log is None:
@@ -232,7 +249,7 @@ class UNetEngineBF16:
             check(lib.gsd_bn_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout, u.sums.data_ptr(),
                                              count, P[u.gname].data_ptr(), P[u.bname].data_ptr(), BN_EPS, BN_MOMENTUM,
                                              P[u.rmname].data_ptr(), P[u.rvname].data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
-                                             u.scale.data_ptr(), u.shift.data_ptr(), st), "bn_reduce_finalize")
+                                             u.scale.data_ptr(), u.shift.data_ptr(), self.guard, st), "bn_reduce_finalize")
         else:                        # SyncBN: the fp64 sums are all-reduced between the two halves
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout,
                                              u.sums.data_ptr(), st), "bn_reduce_partials")
@@ -240,7 +257,8 @@ class UNetEngineBF16:
             count *= self.world
             check(lib.gsd_bn_finalize(u.sums.data_ptr(), u.cout, count, P[u.gname].data_ptr(), P[u.bname].data_ptr(),
                                       BN_EPS, BN_MOMENTUM, P[u.rmname].data_ptr(), P[u.rvname].data_ptr(),
-                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), st),
+                                      u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(),
+                                      self.guard, st),
                   "bn_finalize")
         P[u.nbtname].add_(1)
         check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
@@ -256,10 +274,14 @@ class UNetEngineBF16:
         self._ensure(n, h, w, x.device, train)
         st = L.stream_ptr()
         self._saved_train = train
+        self.generation += 1       # every forward overwrites the saved activations
         dcol = L.make_nhwc(self.col0)
+        region = self._region_begin()         # bench hook: the `inc` double-conv forward (im2col, 2 convs, BN statistics + apply)
         check(lib.gsd_bf16_im2col3x3(x.data_ptr(), n, c, h, w, C.byref(dcol), st), "im2col3x3")
         for lvl in range(self.L + 1):
             u0, u1 = self.enc[lvl]
+            if lvl == 1:
+                self._region_end("inc_forward", region)
             if lvl == 0:
                 src = (self.col0, 0, self.col0.shape[3])
             else:
@@ -269,6 +291,8 @@ class UNetEngineBF16:
                 src = (self.pooled[lvl], 0, prev.cout)
             self._run_unit(u0, src, P, train, st)
             self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st)
+        if self.L == 0:
+            self._region_end("inc_forward", region)
         cur = self.enc[self.L][1]
         z = L.int_array([0])
         for j in range(self.L):

@@ -73,7 +73,7 @@ def evaluate_loader(step, loader: Iterable[Dict], loss_kind: str = "mse") -> flo
         if buf is None:
             buf = torch.zeros((1,), device=out.device, dtype=torch.float32)
             ws = torch.empty((2048,), device=out.device, dtype=torch.float64)
-        loss_fwd_bwd(loss_kind, out, t.contiguous(), None, buf, ws)
+        loss_fwd_bwd(loss_kind, out, t.float().contiguous(), None, buf, ws)
         v = float(buf.item())
         vals.append(0.0 if v != v else v)
         nb += 1
@@ -88,7 +88,11 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
     """Run epochs until the stopping rule fires (or `max_epochs`).  Returns H = {train_loss, validation_loss, test_loss}.
 
     `train_pass(step, loader) -> (sum_of_batch_losses, n_batches)`, `eval_pass(step, loader) -> mean_loss` and
-    `save(step, path)` default to the libgsd implementations; tests substitute host stubs for them."""
+    `save(step, path)` default to the libgsd implementations; tests substitute host stubs for them.
+
+    Data parallel (a build-side addition, the reference is single-process): every rank runs the same epochs on its shard
+    of each batch; the epoch losses are averaged over the ranks (`step.mean_across_ranks`) so that all ranks take the
+    same stopping and checkpoint decisions, and only rank 0 writes checkpoints, the log file and the echo."""
     if train_pass is None:
         from .dataset import train_epoch as train_pass
     if eval_pass is None:
@@ -98,9 +102,13 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
             st.save_checkpoint(path, use_ema=True)
     H: Dict[str, List[float]] = {"train_loss": [], "validation_loss": [], "test_loss": []}
     stopper = EarlyStopping(val_loss_SMA_window, validation_loss_count_threshold, train_indefinitely)
-    log = open(loss_values_path, "a") if loss_values_path else None
+    is_main = getattr(step, "rank", 0) == 0
+    across = getattr(step, "mean_across_ranks", float)
+    log = open(loss_values_path, "a") if (loss_values_path and is_main) else None
 
     def emit(line: str) -> None:
+        if not is_main:
+            return
         echo(line)
         if log is not None:
             log.write(line + "\n")
@@ -110,20 +118,21 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
         while True:
             t0 = time.time()
             total, nb = train_pass(step, train_loader)
-            train_loss = total / nb if nb else 0.0
+            train_loss = across(total / nb if nb else 0.0)
             H["train_loss"].append(train_loss)
-            validation_loss = eval_pass(step, val_loader)
+            validation_loss = across(eval_pass(step, val_loader))
             H["validation_loss"].append(validation_loss)
-            test_loss = eval_pass(step, test_loader)
+            test_loss = across(eval_pass(step, test_loader))
             H["test_loss"].append(test_loss)
             stop, stalled, new_min = stopper.update(validation_loss)
             if stalled:
                 emit(f"Validation loss stopped decreasing at epoch {e + 1}")
             if new_min:
                 emit("Validation loss is at a minimum. Saving the model")
-                os.makedirs(weights_path, exist_ok=True)
-                save(step, os.path.join(weights_path, weights_name + ".pth"))
-            if train_indefinitely and len(save_at_epochs) > 0 and e in save_at_epochs:
+                if is_main:
+                    os.makedirs(weights_path, exist_ok=True)
+                    save(step, os.path.join(weights_path, weights_name + ".pth"))
+            if train_indefinitely and len(save_at_epochs) > 0 and e in save_at_epochs and is_main:
                 os.makedirs(weights_path, exist_ok=True)
                 save(step, os.path.join(weights_path, weights_name + "_epoch" + str(e) + ".pth"))
             emit("[INFO] EPOCH: {}".format(e + 1))

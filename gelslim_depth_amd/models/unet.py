@@ -113,11 +113,21 @@ class _UNetFunction(torch.autograd.Function):
         out = module._engine.forward(x, P, train=True)
         ctx.module = module
         ctx.pnames = module._pnames
+        ctx.engine = module._engine
+        ctx.generation = module._engine.generation
         return out
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
         module: "UNet" = ctx.module
+        # The activations live in the engine's buffers, not in ctx: a later forward (another batch, an eval pass, gradient
+        # accumulation over two forwards) has overwritten them, and back-propagating through them would be silently wrong.
+        if module._engine is not ctx.engine or module._engine.generation != ctx.generation:
+            raise RuntimeError(
+                "gelslim_depth_amd.UNet: backward() of a forward whose saved activations are gone -- the model ran another "
+                f"forward since (forward #{ctx.generation}, engine is at #{module._engine.generation}) or changed precision. "
+                "Call backward() before the next forward(); for gradient accumulation, accumulate .grad between "
+                "forward/backward pairs.")
         P = module._tensor_map()
         G = module._grad_targets()
         module._engine.backward(dout, P, G)

@@ -11,9 +11,13 @@ overlapped with the rest of backward) -> one fused Adam+EMA kernel over the flat
 No autograd graph, no per-tensor optimiser launches, no host sync inside the step (the loss stays on the
 device; call .item() when you want it).
 
-Divergence from the reference, on purpose: its NaN guard (train_unet.py:371-372) replaces the loss by a
-constant without grad_fn, after which loss.backward() raises; it also costs a host sync per step.  The
-fused step does not test for NaN; `last_loss` can be inspected by the caller.
+The reference's NaN guard (train_unet.py:371-372) replaces a NaN loss by a constant without grad_fn, after which
+loss.backward() raises; it costs a host sync per step.  Here it is a device-side flag (`nan_policy`, gsd_guard in
+include/gsd.h): a step whose loss or BatchNorm batch statistics are non-finite leaves parameters, Adam moments and the
+EMA shadow untouched and is counted on the device (non-finite batch statistics never reach the running statistics, with
+or without a policy) -- "skip" carries on, "raise" raises GsdError at
+the next `check_finite()` (train_epoch calls it once per epoch: one host sync per epoch instead of two per step),
+None (default) runs the reference's arithmetic unguarded.
 """
 from __future__ import annotations
 
@@ -30,11 +34,16 @@ LOSS_KINDS = {"mse": 0, "l1": 1}
 
 
 def loss_fwd_bwd(kind: str, out: torch.Tensor, target: torch.Tensor, grad: Optional[torch.Tensor],
-                 loss_buf: torch.Tensor, ws: torch.Tensor, grad_scale: float = 1.0) -> None:
+                 loss_buf: torch.Tensor, ws: torch.Tensor, grad_scale: float = 1.0, guard=None) -> None:
     """loss_buf[0] = mean((o-t)^2) | mean(|o-t|); grad = d loss / d out * grad_scale (train_unet.py:51-52)."""
-    assert out.shape == target.shape and out.is_contiguous() and target.is_contiguous()
+    for name, t in (("output", out), ("target", target)):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise L.GsdError(f"loss_fwd_bwd: {name} must be a contiguous float32 tensor on the GPU, got {t.dtype} on "
+                             f"{t.device} (the kernel reads raw fp32; cast with .float() first)")
+    if out.shape != target.shape:
+        raise L.GsdError(f"loss_fwd_bwd: output {tuple(out.shape)} and target {tuple(target.shape)} differ in shape")
     check(lib.gsd_loss_fwd_bwd(LOSS_KINDS[kind], out.data_ptr(), target.data_ptr(), out.numel(), grad_scale,
-                               loss_buf.data_ptr(), L.ptr(grad), ws.data_ptr(), L.stream_ptr()), "loss_fwd_bwd")
+                               loss_buf.data_ptr(), L.ptr(grad), ws.data_ptr(), guard, L.stream_ptr()), "loss_fwd_bwd")
 
 
 class _LossFn(torch.autograd.Function):
@@ -75,7 +84,10 @@ class TrainStep:
 
     def __init__(self, model: UNet, lr: float = 1e-3, weight_decay: float = 1e-6, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, ema_decay: Optional[float] = 0.995, loss: str = "mse",
-                 process_group=None, sync_bn: bool = False, overlap_allreduce: bool = True):
+                 process_group=None, sync_bn: bool = False, overlap_allreduce: bool = True,
+                 nan_policy: Optional[str] = None, force_sync: bool = False):
+        if nan_policy not in (None, "skip", "raise"):
+            raise ValueError(f"nan_policy must be None, 'skip' or 'raise', got {nan_policy!r}")
         self.model = model
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.ema_decay = ema_decay
@@ -83,12 +95,14 @@ class TrainStep:
         self.step_count = 0
         self.ema_updates = 0
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         self.overlap = overlap_allreduce
+        self.nan_policy = nan_policy
         if process_group is not None:
             import torch.distributed as dist
             self.dist = dist
             self.world = dist.get_world_size(process_group)
+            self.rank = dist.get_rank(process_group)
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise L.GsdError("TrainStep needs the model on the GPU")
@@ -113,38 +127,50 @@ class TrainStep:
         self.ema_flat = self.p_flat.clone() if ema_decay is not None else None
         self.loss_buf = torch.zeros((1,), device=dev, dtype=torch.float32)
         self.loss_ws = torch.empty((2048,), device=dev, dtype=torch.float64)
+        # non-finite guard: words[0] = tick of the last bad step, words[1] = steps skipped (include/gsd.h: gsd_guard)
+        self.guard_words = torch.zeros((2,), device=dev, dtype=torch.int32) if nan_policy is not None else None
         self._dout = None
         self._out = None
         eng = model._engine
         eng.world = self.world
-        if sync_bn and self.world > 1:
+        force_sync = process_group is not None and (force_sync or bool(os.environ.get("GSD_FORCE_SYNC")))
+        if sync_bn and (self.world > 1 or force_sync):
             eng.sync_fn = lambda t: self.dist.all_reduce(t, group=self.pg)
         self.sync = None
-        if self.world > 1 or (process_group is not None and os.environ.get("GSD_FORCE_SYNC")):   # 2nd: 1-rank rehearsal
+        if self.world > 1 or force_sync:   # 2nd: rehearsal of the collectives with ONE rank
             from .distributed import GradSync, broadcast_state, make_buckets
             broadcast_state(self.p_flat, [b for _, b in model.named_buffers()], group=self.pg)
             if self.ema_flat is not None:
                 self.ema_flat.copy_(self.p_flat)
             self.sync = GradSync(self.g_flat, make_buckets(names, self.offsets, eng.L), group=self.pg,
-                                 overlap=overlap_allreduce)
+                                 overlap=overlap_allreduce, force=force_sync)
 
     def __call__(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         model = self.model
         eng = model._engine
         x = x.contiguous()
-        target = target.contiguous()
+        target = target.float().contiguous()     # the kernels read raw fp32 (a float64 / uint8 depth target is cast, as _LossFn does)
+        if not target.is_cuda:
+            raise L.GsdError("TrainStep: the target must be on the GPU")
+        guard = L.make_guard(self.guard_words, self.step_count + 1)
+        eng.guard = guard
         P = model._tensor_map()
         if self._out is None or self._out.shape != (x.shape[0], model.n_classes, x.shape[2], x.shape[3]):
             self._out = torch.empty((x.shape[0], model.n_classes, x.shape[2], x.shape[3]), device=x.device,
                                     dtype=torch.float32)
             self._dout = torch.empty_like(self._out)
-        out = eng.forward(x, P, train=True, out=self._out)
-        loss_fwd_bwd(self.loss_kind, out, target, self._dout, self.loss_buf, self.loss_ws)
-        eng.block_done_cb = self.sync.on_block_done if self.sync is not None else None
-        eng.backward(self._dout, P, model._grad_views)
-        eng.block_done_cb = None
+        try:
+            out = eng.forward(x, P, train=True, out=self._out)
+            loss_fwd_bwd(self.loss_kind, out, target, self._dout, self.loss_buf, self.loss_ws, guard=guard)
+            eng.block_done_cb = self.sync.on_block_done if self.sync is not None else None
+            eng.backward(self._dout, P, model._grad_views)
+        finally:
+            eng.block_done_cb = None
+            eng.guard = None
         if self.sync is not None:
             self.sync.finish()
+            if guard is not None:     # every rank must take the same skip decision: the summed gradient carries any rank's NaN
+                self.dist.all_reduce(self.guard_words[0:1], op=self.dist.ReduceOp.MAX, group=self.pg)
         self.step_count += 1
         d = 0.0
         if self.ema_flat is not None:
@@ -153,9 +179,34 @@ class TrainStep:
             d = min(self.ema_decay, (1.0 + self.ema_updates) / (10.0 + self.ema_updates))
         check(lib.gsd_adam_ema(self.p_flat.data_ptr(), self.g_flat.data_ptr(), self.m_flat.data_ptr(),
                                self.v_flat.data_ptr(), L.ptr(self.ema_flat), self.numel, self.step_count, self.lr,
-                               self.betas[0], self.betas[1], self.eps, self.wd, d, 1.0 / self.world, L.stream_ptr()),
+                               self.betas[0], self.betas[1], self.eps, self.wd, d, 1.0 / self.world, guard, L.stream_ptr()),
               "adam_ema")
         return self.loss_buf
+
+    def skipped_steps(self) -> int:
+        """Optimiser steps the non-finite guard has skipped so far (one host sync; 0 without a nan_policy)."""
+        return int(self.guard_words[1].item()) if self.guard_words is not None else 0
+
+    def check_finite(self) -> None:
+        """nan_policy="raise": raise if any step since the last check saw a non-finite loss or BatchNorm statistic (the
+        reference fails at that step, train_unet.py:371-374; here the arenas were left untouched by the skipped update)."""
+        if self.nan_policy != "raise":
+            return
+        n = self.skipped_steps()
+        if n:
+            bad = int(self.guard_words[0].item())
+            self.guard_words[1].zero_()
+            raise L.GsdError(f"non-finite loss or BatchNorm statistics in {n} train step(s), last at step {bad}; those "
+                             "updates were skipped (parameters, Adam moments and EMA shadow are intact)")
+
+    def mean_across_ranks(self, value: float) -> float:
+        """Mean of a host scalar over the data-parallel ranks (epoch losses: every rank must take the same early-stopping
+        and checkpoint decisions)."""
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([value], device=self.p_flat.device, dtype=torch.float64)
+        self.dist.all_reduce(t, group=self.pg)
+        return float(t.item()) / self.world
 
     def evaluate(self, x: torch.Tensor, use_ema: bool = True) -> torch.Tensor:
         """Eval-mode forward under the EMA weights WITHOUT the store / copy-in / restore the reference pays per batch

@@ -14,7 +14,9 @@
  *     synchronises (safe for hipGraph capture and for the autograd thread);
  *   - return 0 on success, a negative gsd_status otherwise; gsd_last_error() returns a
  *     thread-local message; no exceptions, no exit();
- *   - no global mutable state: every call is re-entrant.
+ *   - every call is re-entrant and no result depends on library state: tuning knobs (GSD_* environment
+ *     variables) are read on every call; the only process-wide state is an atomic per-device cache of an
+ *     idempotent launch attribute (hipFuncSetAttribute(MaxDynamicSharedMemorySize), gsd_common.h).
  *
  * "Deferred BatchNorm": a convolution never materialises relu(bn(raw)).  It writes the raw
  * convolution output plus per-block partial sums; gsd_bn_finalize turns the partials into a
@@ -39,6 +41,18 @@ typedef enum {
   GSD_ERR_HIP = -3,           /* a HIP runtime call failed (message carries hipGetErrorString) */
   GSD_ERR_WORKSPACE = -4      /* caller-provided workspace too small                           */
 } gsd_status;
+
+/* Non-finite guard of a train step -- the device-side form of the reference's `if pred_loss.isnan()`
+ * (train_utils/train_unet.py:371-372; there it costs a host sync and makes backward() raise).
+ * words: two int32 on the device, zero-initialised by the caller.  A kernel that sees a non-finite BatchNorm
+ * batch statistic (gsd_bn_finalize) or loss (gsd_loss_fwd_bwd) stores `tick` (the caller's step number,
+ * never 0) into words[0]; gsd_adam_ema called with the same tick then leaves parameters, moments and EMA
+ * untouched and adds 1 to words[1].  No host synchronisation; the caller reads words[1] when it likes.
+ * Independently of the guard, non-finite batch statistics never reach running_mean/running_var. */
+typedef struct {
+  int32_t* words;
+  int32_t tick;
+} gsd_guard;
 
 /* One channel segment of an input operand as a consumer sees it. */
 typedef struct {
@@ -151,10 +165,11 @@ int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, int Cout,
  * `sums` must hold 65*2*C doubles: the result followed by 64*2*C doubles of stage-1 scratch. */
 int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad, int C, double* sums, void* stream);
 /* sums -> mean, invstd, (scale, shift) = (gamma*invstd, beta - mean*scale); updates running stats
- * (momentum 0.1, unbiased variance) when running_mean != NULL. count = N*H*W (global if synced). */
+ * (momentum 0.1, unbiased variance) when running_mean != NULL and the batch statistics are finite.
+ * count = N*H*W (global if synced). guard may be NULL. */
 int gsd_bn_finalize(const double* sums, int C, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean, float* running_var,
-                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+                    float* mean, float* invstd, float* scale, float* shift, const gsd_guard* guard, void* stream);
 /* eval mode: (scale, shift) from running stats. */
 int gsd_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
@@ -188,7 +203,7 @@ int gsd_bn_bwd_finalize(const double* sums_local, const double* sums_global, int
  * the stand-alone backward reduce kernels, mpad for rows of 2*mpad floats from a dX epilogue. */
 int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad, int C, double* sums, double count, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                           float* mean, float* invstd, float* scale, float* shift, void* stream);
+                           float* mean, float* invstd, float* scale, float* shift, const gsd_guard* guard, void* stream);
 int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int layout_mpad, int C, double* sums, double count,
                                float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream);
 /* pass 3: d_raw = scale_g * (dz - c1 - xhat*c2), in place on dz; scale_g = gamma*invstd = scale. */
@@ -208,17 +223,18 @@ int gsd_maxpool2(const gsd_src* src, float* y, int N, int C, int H, int W, void*
 int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* b, int C, int K,
                     float* out, int N, int H, int W, void* stream);
 /* loss = mean((o-t)^2) (kind 0) or mean(|o-t|) (kind 1); grad = d loss/d o * grad_scale.
- * loss_out: 1 float (device). workspace >= 2048 floats. grad may be NULL. */
+ * loss_out: 1 float (device). workspace >= 2048 floats. grad and guard may be NULL. */
 int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_t numel, float grad_scale,
-                     float* loss_out, float* grad, float* workspace, void* stream);
+                     float* loss_out, float* grad, float* workspace, const gsd_guard* guard, void* stream);
 
 /* ---- optimiser (train_unet.py:306,375-376) -------------------------------------------------- */
 /* Fused torch.optim.Adam(lr, betas, eps, weight_decay: coupled L2) + torch_ema update over a flat
  * parameter arena. step is the 1-based Adam step; ema may be NULL; ema_decay already resolved
- * (min(decay,(1+n)/(10+n))). grad_scale multiplies g first (1/world_size after all-reduce). */
+ * (min(decay,(1+n)/(10+n))). grad_scale multiplies g first (1/world_size after all-reduce).
+ * guard (may be NULL): skip the whole update when words[0] == tick (see gsd_guard). */
 int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel,
                  int step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                 float ema_decay, float grad_scale, void* stream);
+                 float ema_decay, float grad_scale, const gsd_guard* guard, void* stream);
 
 /* ---- inference pre/post-processing (test_utils/test_depth_estimation.py:14-20, complete_prediction.py:4-10) ---- */
 /* F.interpolate(mode='area') (image_utils.py:12-15; == adaptive_avg_pool2d) fused with the difference image

@@ -123,3 +123,20 @@ def test_conv_form_choice_and_size_queries(monkeypatch):
     assert lib.gsd_conv3x3_algo(32, 320, 427, 64, 64) == 0
     monkeypatch.setenv("GSD_CONV_ALGO", "1")
     assert lib.gsd_conv3x3_algo(32, 320, 427, 3, 64) == 1
+
+
+def test_guard_struct_and_bench_self_launch_refuses_cleanly():
+    """gsd_guard layout; and `python bench.py --gpus N` without a rank environment starts its own ranks as a child job --
+    on a machine with fewer than N GPUs (this container has none) it must say so and exit non-zero without a traceback."""
+    import subprocess
+    import sys
+    from gelslim_depth_amd import _lib
+    assert ctypes.sizeof(_lib.gsd_guard) == 16 and _lib.gsd_guard.tick.offset == 8
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "one per GPU" in r.stderr and "Traceback" not in r.stderr and r.stdout.strip() == ""

@@ -102,3 +102,46 @@ def test_gradsync_world2_gloo(overlap):
         assert p.exitcode == 0
     for rank, ok_sum, ok_missing, ok_bc in res:
         assert ok_sum and ok_missing and ok_bc, (rank, ok_sum, ok_missing, ok_bc)
+
+
+class _StubDataset:
+    """What DeviceLoader needs from a DeviceDataset: len, device, batch(idx)."""
+    device = torch.device("cpu")
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, idx):
+        return {"tactile_image": idx.clone(), "depth_image": idx.clone(), "object_index": idx.clone()}
+
+
+@pytest.mark.parametrize("n,bs,world", [(65, 32, 2), (7, 2, 2), (9, 2, 4), (3, 4, 2), (64, 32, 2)])
+def test_device_loader_gives_every_rank_the_same_number_of_equal_batches(n, bs, world):
+    """Every TrainStep issues collectives, so ranks must agree on the number of steps and on the shard size of each
+    (n=65, batch 32 x 2 ranks used to leave rank 1 one step short)."""
+    from gelslim_depth_amd.dataset import DeviceLoader
+    per_rank = []
+    for r in range(world):
+        torch.manual_seed(11)
+        ld = DeviceLoader(_StubDataset(n), batch_size=bs, shuffle=True, rank=r, world_size=world)
+        per_rank.append([b["tactile_image"] for b in ld])
+        assert len(per_rank[-1]) == len(ld)
+    counts = {len(b) for b in per_rank}
+    assert len(counts) == 1
+    for i in range(len(per_rank[0])):
+        sizes = {int(b[i].numel()) for b in per_rank}
+        assert len(sizes) == 1 and sizes.pop() > 0
+    # together the ranks cover every sample; the padding only repeats samples from the start of the permutation
+    torch.manual_seed(11)
+    order = DeviceLoader(_StubDataset(n), batch_size=bs, shuffle=True).order()
+    seen = torch.cat([per_rank[r][i] for i in range(len(per_rank[0])) for r in range(world)])
+    assert torch.equal(seen[:n], order)
+    extra = seen[n:]
+    assert extra.numel() < world and torch.equal(extra, order[torch.arange(extra.numel()) % n])
+    # drop_last: no ragged batch at all
+    for r in range(world):
+        ld = DeviceLoader(_StubDataset(n), batch_size=bs, shuffle=False, drop_last=True, rank=r, world_size=world)
+        assert [int(b["tactile_image"].numel()) for b in ld] == [bs] * (n // (bs * world))

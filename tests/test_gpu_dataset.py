@@ -46,17 +46,20 @@ def test_device_dataset_vs_golden(tag, kw):
     gotd = np.concatenate([b["depth_image"].cpu().numpy() for b in batches])
     assert np.array_equal(gotd, dep[order])
     assert np.array_equal(np.concatenate([b["object_index"].cpu().numpy() for b in batches]), g[tag + "_object_index"][order])
-    # two ranks split every global batch contiguously and together cover it
+    # two ranks split every global batch contiguously and together cover it; both yield the same number of batches of the
+    # same sizes (the ragged last global batch is padded by wrapping around to the start of the permutation)
     torch.manual_seed(21)
     r0 = list(DeviceLoader(ds, batch_size=2, shuffle=True, rank=0, world_size=2))
     torch.manual_seed(21)
     r1 = list(DeviceLoader(ds, batch_size=2, shuffle=True, rank=1, world_size=2))
+    assert len(r0) == len(r1) == len(DeviceLoader(ds, batch_size=2, rank=0, world_size=2))
+    assert [b["depth_image"].shape[0] for b in r0] == [b["depth_image"].shape[0] for b in r1]
     both = []
-    for i in range(len(r0)):
-        both.append(r0[i]["depth_image"].cpu().numpy())
-        if i < len(r1):
-            both.append(r1[i]["depth_image"].cpu().numpy())
-    assert np.array_equal(np.concatenate(both), dep[order])
+    for a, b in zip(r0, r1):
+        both += [a["depth_image"].cpu().numpy(), b["depth_image"].cpu().numpy()]
+    both = np.concatenate(both)
+    padded = np.concatenate([order, order[:both.shape[0] - len(order)]])
+    assert np.array_equal(both, dep[padded])
 
 
 def test_device_dataset_uint8_and_oracle_at_reference_size():

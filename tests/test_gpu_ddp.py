@@ -113,3 +113,39 @@ def test_two_rank_bf16_syncbn_matches_single_process_global_batch(tmp_path):
     for k, v in m.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert rel_l1(res[0]["buf/" + k], v.cpu().numpy()) < 1e-3, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_one_rank_rccl_step_is_bit_equal(tmp_path, precision):
+    """The RCCL path on hardware (the GPU box has one card, so one rank): backend "nccl", collectives forced on.  Three
+    steps with bucketed async all-reduce + SyncBN + guard exchange == three steps without a process group, bit for bit."""
+    import socket
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "tests", "nccl_worker.py"), str(tmp_path), precision, str(port)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = dict(np.load(os.path.join(tmp_path, "nccl.npz")))
+    assert int(res["world"]) == 1 and str(res["backend"]) == "nccl" and int(res["skipped"]) == 0
+    dims = [16, 32, 64] if precision == "fp32" else [32, 64, 128]
+    st = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, t = synth.make_batch(3, 37, 53, 6)
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    losses = [float(step(xd, td).item()) for _ in range(3)]
+    assert np.array_equal(np.array(losses), res["losses"])
+    assert np.array_equal(step.g_flat.cpu().numpy(), res["g"])
+    assert np.array_equal(step.p_flat.cpu().numpy(), res["p"])
+    assert np.array_equal(step.ema_flat.cpu().numpy(), res["ema"])
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert np.array_equal(v.cpu().numpy(), res["buf/" + k]), k

@@ -235,7 +235,7 @@ def test_bn_finalize_and_eval_coeffs(gsd):
     gd, bd, rmd, rvd = dev(g), dev(b), dev(rm), dev(rv)
     outs = [torch.zeros(c, device="cuda") for _ in range(4)]
     gsd.check(gsd.lib.gsd_bn_finalize(sums.data_ptr(), c, float(n * h * w), gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1,
-                                      rmd.data_ptr(), rvd.data_ptr(), *[o.data_ptr() for o in outs], gsd.stream_ptr()))
+                                      rmd.data_ptr(), rvd.data_ptr(), *[o.data_ptr() for o in outs], None, gsd.stream_ptr()))
     mean, invstd, scale, shift = [o.cpu().numpy() for o in outs]
     assert rel_l1(mean, mr) < 1e-6 and rel_l1(invstd, ir) < 1e-6
     assert rel_l1(rmd.cpu().numpy(), nrm) < 1e-6 and rel_l1(rvd.cpu().numpy(), nrv) < 1e-6
@@ -331,7 +331,7 @@ def test_outconv_forward_loss_and_backward(gsd):
         ws = torch.zeros(2048, dtype=torch.float64, device="cuda")
         yrd, tgtd = dev(yr), dev(tgt)
         gsd.check(gsd.lib.gsd_loss_fwd_bwd(kind, yrd.data_ptr(), tgtd.data_ptr(), yr.size, 1.0, loss.data_ptr(),
-                                           grad.data_ptr(), ws.data_ptr(), gsd.stream_ptr()))
+                                           grad.data_ptr(), ws.data_ptr(), None, gsd.stream_ptr()))
         assert abs(loss.item() - lr) < 1e-6 * abs(lr)
         assert rel_l1(grad.cpu().numpy(), gr) < 1e-6
     _, dout = on.mse_loss(yr, tgt)
@@ -382,7 +382,7 @@ def test_adam_ema_matches_torch_and_oracle(gsd):
         d = on.ema_decay(step)
         gd = dev(g)
         gsd.check(gsd.lib.gsd_adam_ema(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(), numel,
-                                       step, 1e-3, 0.9, 0.999, 1e-8, 1e-6, d, 1.0, gsd.stream_ptr()))
+                                       step, 1e-3, 0.9, 0.999, 1e-8, 1e-6, d, 1.0, None, gsd.stream_ptr()))
     assert rel_l1(pd.cpu().numpy(), pt.detach().numpy()) < 1e-6
     assert rel_l1(pd.cpu().numpy(), p) < 1e-6
     assert rel_l1(ed.cpu().numpy(), shadow) < 1e-6
@@ -453,10 +453,10 @@ def test_bn_one_launch_reduce_finalize(gsd, rows, c, mpad):
         tail = [gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr()] + [o.data_ptr() for o in outs]
         if one:
             gsd.check(gsd.lib.gsd_bn_reduce_finalize(part.data_ptr(), rows, mpad, c, sums.data_ptr(), count, *tail,
-                                                     gsd.stream_ptr()))
+                                                     None, gsd.stream_ptr()))
         else:
             gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, c, sums.data_ptr(), gsd.stream_ptr()))
-            gsd.check(gsd.lib.gsd_bn_finalize(sums.data_ptr(), c, count, *tail, gsd.stream_ptr()))
+            gsd.check(gsd.lib.gsd_bn_finalize(sums.data_ptr(), c, count, *tail, None, gsd.stream_ptr()))
         torch.cuda.synchronize()
         return sums[:2 * c].cpu().numpy(), [o.cpu().numpy() for o in outs + [rm, rv]]
 
