@@ -83,6 +83,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    # the link leaves unresolved symbols unresolved (-shared): load the result once so that a kernel template that was
+    # referenced but never instantiated fails the BUILD, not the first import on the GPU box
+    import ctypes
+    ctypes.CDLL(tmp, mode=os.RTLD_NOW)
     os.replace(tmp, OUT)
     with open(STAMP, "w") as fh:
         fh.write(digest + "\n")

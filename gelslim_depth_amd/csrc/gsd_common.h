@@ -32,11 +32,13 @@ struct SrcD {
   const float* scale;
   const float* shift;
   int C, H, W, oh, ow, relu;
+  int ws;   // row pitch in elements (>= W)
   long long ns, cs;
 };
 struct DstD {
   float* p;
   int C, H, W, oh, ow;
+  int ws;   // row pitch in elements (>= W)
   long long ns, cs;
 };
 
@@ -44,24 +46,26 @@ static inline SrcD to_srcd(const gsd_src& s) {
   SrcD d;
   d.p = s.ptr; d.scale = s.scale; d.shift = s.shift;
   d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w; d.relu = s.relu;
+  d.ws = s.W;
   d.ns = s.n_stride; d.cs = s.c_stride;
   return d;
 }
 static inline DstD to_dstd(const gsd_dst& s) {
   DstD d;
   d.p = s.ptr; d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w;
+  d.ws = s.W;
   d.ns = s.n_stride; d.cs = s.c_stride;
   return d;
 }
 static inline SrcD null_srcd() {
   SrcD d;
   d.p = nullptr; d.scale = nullptr; d.shift = nullptr;
-  d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.relu = 0; d.ns = 0; d.cs = 0;
+  d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.relu = 0; d.ws = 0; d.ns = 0; d.cs = 0;
   return d;
 }
 static inline DstD null_dstd() {
   DstD d;
-  d.p = nullptr; d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.ns = 0; d.cs = 0;
+  d.p = nullptr; d.C = 0; d.H = 0; d.W = 0; d.oh = 0; d.ow = 0; d.ws = 0; d.ns = 0; d.cs = 0;
   return d;
 }
 

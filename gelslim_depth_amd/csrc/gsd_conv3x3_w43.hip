@@ -29,9 +29,29 @@
 #include <cstdlib>
 
 __device__ const float gsd_pad_w43[2] = {0.f, __builtin_nanf("")};
+__device__ __attribute__((aligned(16))) const float gsd_pad16_w43[8] = {0.f, 0.f, 0.f, 0.f, __builtin_nanf(""), __builtin_nanf(""),
+                                                                          __builtin_nanf(""), __builtin_nanf("")};
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Diagnostic build only (-DGSD_W43_STAMPS; never in the product library): s_memtime stamps around the segments of a K-chunk,
+// summed per wave in scalar registers and written to a buffer of their own (cdna_hip_programming.md sec. 7, In-kernel stamps).
+#ifdef GSD_W43_STAMPS
+static unsigned long long* g_w43_stamp_buf = nullptr;
+extern "C" void gsd_w43_set_stamp_buffer(void* p) { g_w43_stamp_buf = (unsigned long long*)p; }
+#define W43_STAMP(i)                                                                             \
+  {                                                                                              \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    st_acc[i] += t_ - st_prev;                                                                   \
+    st_prev = t_;                                                                                \
+  }
+#else
+#define W43_STAMP(i) {}
+#endif
 
 struct W43Params {
   SrcD src0, src1;
@@ -46,6 +66,8 @@ struct W43Params {
   int Cin, Cout, Mpad, nchunks, mblocks;
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
+  int NP, RPI, NI, RO;   // 16-byte halo pieces (X4): pieces per window row, rows per DMA instruction, instructions per plane, read offset
+  unsigned long long* stamps;   // diagnostic builds only
 };
 
 namespace {
@@ -55,12 +77,148 @@ constexpr int W43_W4 = W43_WTILE / 4;       // float4s
 constexpr int W43_NWI = (W43_W4 + 255) / 256;
 }  // namespace
 
+// Loader wave of the producer / consumer form of the kernel below (NL > 0): it issues EVERY LDS-DMA of the block -- the 18
+// one-KiB pieces of the weight chunk and the halo windows of the chunk's four input channels -- one chunk ahead of the four
+// MFMA waves, which then run a loop of ds_read + transform + MFMA only.  Measured with in-kernel stamps (profiles/
+// stamp_conv.py): a wave that issues its share of the fills itself spends ~250 cycles per global_load_lds (plus the
+// segment / padding bookkeeping around it) and the five k-steps that carried them took as long as the other thirteen
+// together; a wave that does nothing else issues them back to back (cdna_hip_programming.md, LDS-DMA loader rings).
+template <bool X4, int NL>
+__device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int BUF, int n, int h0, int w0, int mb, int lane,
+                                           int lw) {
+  constexpr int WTILE = W43_WTILE;
+  constexpr int NIL = ((X4 ? 2 : 8) + NL - 1) / NL;   // halo instructions per loader wave and channel plane
+  const int PS = P.PS;
+  int xo0[NIL], xo1[NIL], ldo[NIL];
+#pragma unroll
+  for (int k = 0; k < NIL; ++k) {
+    const int idx = lw + NL * k;
+    xo0[k] = xo1[k] = -2;
+    if constexpr (X4) {
+      ldo[k] = idx * P.RPI * P.WCp + 1;            // + 1 float: image column w0-1 then sits 16-byte aligned
+      const int rl = lane / P.NP, pc = lane - rl * P.NP;
+      const int rr = idx * P.RPI + rl;
+      if (idx < P.NI && rl < P.RPI && rr < P.WR) {
+        const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
+        int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+        xo0[k] = ((unsigned)hs < (unsigned)P.src0.H && ws >= 0 && ws < P.src0.W && ws + 4 <= P.src0.ws) ? hs * P.src0.ws + ws : -1;
+        hs = gh - P.src1.oh;
+        ws = gw - P.src1.ow;
+        xo1[k] = ((unsigned)hs < (unsigned)P.src1.H && ws >= 0 && ws < P.src1.W && ws + 4 <= P.src1.ws) ? hs * P.src1.ws + ws : -1;
+      }
+    } else {
+      ldo[k] = idx * 64;
+      const int pos = idx * 64 + lane;
+      const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
+      if (idx < P.NPV && rr < P.WR && cc < P.WC) {
+        const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
+        int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+        xo0[k] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : -1;
+        hs = gh - P.src1.oh;
+        ws = gw - P.src1.ow;
+        xo1[k] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : -1;
+      }
+    }
+  }
+  {
+    // padding positions of the first segment: written once, in both images and all four channel planes; a fill of a
+    // first-segment channel then only moves the lanes that have a pixel
+    const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
+#pragma unroll
+    for (int k = 0; k < NIL; ++k)
+      if (xo0[k] == -1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) {
+            float* d = smem + b * BUF + WTILE + ch * PS + ldo[k];
+            if constexpr (X4) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) d[lane * 4 + e] = pad0;
+            } else {
+              d[lane] = pad0;
+            }
+          }
+      }
+  }
+  int d_seg = 0, d_left = P.src0.C;
+  const float* d_base = P.src0.p + (long long)n * P.src0.ns;
+  long long d_cs = P.src0.cs;
+  const float* const zeros = X4 ? &gsd_pad16_w43[0] : &gsd_pad_w43[0];
+  const float* d_sent = X4 ? (P.src0.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
+  const float* const wsrc = P.wt + (size_t)mb * P.nchunks * WTILE + lane * 4;
+
+  auto fill = [&](int chunk, int buf) {
+    float* Wb = smem + buf * BUF;
+    const float* wc = wsrc + (size_t)chunk * WTILE;
+#pragma unroll
+    for (int i = 0; i < 18; ++i)
+      if (i % NL == lw) __builtin_amdgcn_global_load_lds(wc + i * 256, Wb + i * 256, 16, 0, 0);
+    float* Xb = Wb + WTILE;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (d_left == 0 && d_seg == 0) {
+        d_seg = 1;
+        d_left = P.src1.C;
+        d_base = P.src1.p + (long long)n * P.src1.ns;
+        d_cs = P.src1.cs;
+        d_sent = X4 ? (P.src1.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (P.src1.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
+      }
+      const bool c_ok = d_left > 0;
+      if (c_ok && d_seg == 0) {
+#pragma unroll
+        for (int k = 0; k < NIL; ++k)
+          if (xo0[k] >= 0) {
+            const float* gp = d_base + xo0[k];
+            __builtin_amdgcn_global_load_lds(gp, Xb + ch * PS + ldo[k], X4 ? 16 : 4, 0, 0);
+          }
+      } else {
+        // second (concat) segment and K padding: every window position is written, padding from the sentinel
+#pragma unroll
+        for (int k = 0; k < NIL; ++k) {
+          const int xo = d_seg == 0 ? xo0[k] : xo1[k];
+          if (xo != -2) {
+            const float* gp = (c_ok && xo >= 0) ? d_base + xo : (c_ok ? d_sent : zeros);
+            __builtin_amdgcn_global_load_lds(gp, Xb + ch * PS + ldo[k], X4 ? 16 : 4, 0, 0);
+          }
+        }
+      }
+      if (c_ok) {
+        d_base += d_cs;
+        --d_left;
+      }
+    }
+  };
+
+  fill(0, 0);
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    gsd_dma_barrier();   // chunk `chunk` has landed (this wave's vmcnt); the MFMA waves have left the other image
+    if (chunk + 1 < P.nchunks) fill(chunk + 1, (chunk + 1) & 1);
+  }
+}
+
 // WM = groups of 4 waves per block: 1 -> 64 m x 256 px, two blocks per CU; 2 -> 128 m x 256 px (two 64-channel weight
 // images side by side), 8 waves, one block per CU: the halo DMA -- the expensive part of the data movement -- is then shared
 // by twice the MFMAs (9 instead of 13 DMA instructions per wave and chunk).  Tuning option (GSD_W43_BIG), not the default.
-template <int WM>
-__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(const W43Params P) {
-  constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM, NWAVE = 4 * WM;
+//
+// X4: the halo windows move as ALIGNED 16-byte pieces (global_load_lds_dwordx4 with a per-lane source address) instead of
+// dword gathers: possible when every source row starts 16-byte aligned (row pitch, plane and image strides multiples of 4
+// floats, pad offset a multiple of 4) -- the engine allocates its activations that way.  A window row is then the NP =
+// TW/4 + 2 pieces that cover image columns w0-4 .. w0+TW+3, and the wave-uniform LDS base is shifted by ONE float so that
+// image column w0-1 lands 16-byte aligned and the consumer reads stay one b128 + one b64 per kernel row.  A quarter of the
+// gather instructions (2 per channel plane instead of 6), each a coalesced run of 16-byte lanes.  Columns >= W inside the
+// pitch come from memory: producers keep the padding value there (NaN under a ReLU'd BatchNorm, else 0).
+//
+// NL > 0: producer / consumer form -- NL extra waves per block issue all the DMA (w43_loader above); WM must be 1.
+//
+// FAST: the channel bookkeeping of the fills is done once per CHUNK in scalar registers instead of once per slot with a
+// chain of branches (which segment, how many channels it has left, which sentinel): possible when a chunk of 4 channels
+// never straddles the two source segments (src0.C % 4 == 0, always true in the U-Net).  Stamps (profiles/stamp_conv.py)
+// put the per-slot form at ~1200 of the ~6400 cycles a wave spends per chunk.
+template <int WM, bool X4, int NL, bool FAST>
+__global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1)) void conv3x3_w43_kernel(const W43Params P) {
+  static_assert(NL == 0 || WM == 1, "loader waves serve one 64-channel weight image");
+  constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM + 64 * NL, NWAVE = 4 * WM;
   constexpr int NWI = (W4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PS = P.PS;
@@ -69,6 +227,10 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave8 >> 2, wave = wave8 & 3;   // wave: pixel group of the wave, wm: its 64-channel group
+#ifdef GSD_W43_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
   const int j = lane >> 4, l16 = lane & 15;
 
   // The m-blocks of one pixel tile read the same halo: hardware deals blocks round-robin over the 8 XCDs, so give every XCD
@@ -89,7 +251,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
   const bool q_ok = q < P.TH * P.TWq;
   const int tr = q_ok ? q / P.TWq : 0;
   const int tq = q_ok ? q - tr * P.TWq : 0;
-  const int baddr = WM * WTILE + j * PS + tr * P.WCp + 4 * tq;   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
+  const int baddr = WM * WTILE + j * PS + tr * P.WCp + 4 * tq + (X4 ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
   int vmask = 0;                                            // pixels of the tile that exist in the image
   if (q_ok && h0 + tr < P.H) {
 #pragma unroll
@@ -98,31 +260,51 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
   }
 
   // ---- DMA lane geometry (as gsd_conv3x3.hip, window rows padded to WCp floats) ------------------------------------------
-  constexpr int NPP = 2 / WM;   // position chunks of 64 per wave: the block's waves cover the 512 window positions once
+  constexpr int NPP = 2 / WM;   // dword form: position chunks of 64 per wave (the block's waves cover the 512 window positions
+                                // once); X4: DMA units (channel plane, instruction) per wave and chunk
   int xo0[NPP], xo1[NPP];
+  int u_ch[NPP], u_lds[NPP];    // X4: the unit's channel of the chunk and its float offset inside the channel plane
+  bool p_on[NPP];
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) {
-    const int pos = (wave8 + NWAVE * pp) * 64 + lane;
     xo0[pp] = xo1[pp] = -2;
-    const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
-    if (rr < P.WR && cc < P.WC) {
-      const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
-      int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
-      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.W + ws : -1;
-      hs = gh - P.src1.oh;
-      ws = gw - P.src1.ow;
-      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.W + ws : -1;
+    u_ch[pp] = u_lds[pp] = 0;
+    if constexpr (X4) {
+      const int u = wave8 + NWAVE * pp;            // units 0 .. 4*NI-1: channel u / NI, instruction u % NI
+      p_on[pp] = u < 4 * P.NI;
+      u_ch[pp] = u / P.NI;
+      const int ii = u - u_ch[pp] * P.NI;
+      u_lds[pp] = ii * P.RPI * P.WCp + 1;          // + 1 float: image column w0-1 then sits 16-byte aligned
+      const int rl = lane / P.NP, pc = lane - rl * P.NP;
+      const int rr = ii * P.RPI + rl;
+      if (p_on[pp] && rl < P.RPI && rr < P.WR) {
+        const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
+        int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && ws >= 0 && ws < P.src0.W && ws + 4 <= P.src0.ws) ? hs * P.src0.ws + ws : -1;
+        hs = gh - P.src1.oh;
+        ws = gw - P.src1.ow;
+        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && ws >= 0 && ws < P.src1.W && ws + 4 <= P.src1.ws) ? hs * P.src1.ws + ws : -1;
+      }
+    } else {
+      p_on[pp] = wave8 + NWAVE * pp < P.NPV;
+      const int pos = (wave8 + NWAVE * pp) * 64 + lane;
+      const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
+      if (rr < P.WR && cc < P.WC) {
+        const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
+        int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : -1;
+        hs = gh - P.src1.oh;
+        ws = gw - P.src1.ow;
+        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : -1;
+      }
     }
   }
   const float* wsrc0 = P.wt + (size_t)(mbb * WM) * P.nchunks * WTILE;   // the block's WM weight images follow each other
-  bool p_on[NPP];
-#pragma unroll
-  for (int pp = 0; pp < NPP; ++pp) p_on[pp] = wave8 + NWAVE * pp < P.NPV;
-
   const long long wlane = tid * 4;   // this lane's float offset inside a 1 KiB weight piece group
   long long xl0[NPP];   // first segment's offsets as 64-bit lane values (the address add is then a single instruction)
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) xl0[pp] = xo0[pp];
+  if constexpr (NL == 0)
   {
     // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only: the lanes that
     // would otherwise DMA the sentinel there on every fill); visible to the consumers after the first barrier
@@ -131,22 +313,98 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     for (int pp = 0; pp < NPP; ++pp)
       if (p_on[pp] && xo0[pp] == -1) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (X4) {   // the unit's own plane: the other planes' pieces belong to other units
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WM * WTILE + ch * PS + (wave8 + NWAVE * pp) * 64 + lane] = pad0;
+            for (int e = 0; e < 4; ++e) smem[b * BUF + WM * WTILE + u_ch[pp] * PS + u_lds[pp] + lane * 4 + e] = pad0;
+          } else {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WM * WTILE + ch * PS + (wave8 + NWAVE * pp) * 64 + lane] = pad0;
+          }
+        }
       }
   }
   int d_seg = 0, d_left = P.src0.C;
   const float* d_base = P.src0.p + (long long)n * P.src0.ns;
   long long d_cs = P.src0.cs;
-  const float* d_sent = P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
+  const float* d_sent = X4 ? (P.src0.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
   int d_xo[NPP];
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo0[pp];
 
+  // FAST: per-chunk state of the halo fills (wave-uniform except f_xo / f_xl)
+  bool f_plain = true;             // first segment, all four channels exist: masked lanes only, padding already in LDS
+  int f_nch = 4;
+  const float* f_b[4] = {nullptr, nullptr, nullptr, nullptr};   // plane of each channel of the chunk
+  const float* f_sent = d_sent;
+  int f_xo[NPP];
+  long long f_xl[NPP];
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) {
+    f_xo[pp] = xo0[pp];
+    f_xl[pp] = xo0[pp];
+  }
+  auto begin_fill = [&](int chunk) {
+    const int c0 = chunk * 4;
+    const bool s1 = c0 >= P.src0.C && P.src1.C > 0;
+    const int cc0 = s1 ? c0 - P.src0.C : c0;
+    const int segC = s1 ? P.src1.C : P.src0.C;
+    const long long cs = s1 ? P.src1.cs : P.src0.cs;
+    const float* base = (s1 ? P.src1.p + (long long)n * P.src1.ns : P.src0.p + (long long)n * P.src0.ns) + (long long)cc0 * cs;
+    const int relu = s1 ? P.src1.relu : P.src0.relu;
+    f_nch = segC - cc0 < 4 ? (segC - cc0 > 0 ? segC - cc0 : 0) : 4;
+    f_plain = !s1 && f_nch == 4;
+    f_sent = X4 ? (relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f_b[c] = base + (long long)(c < f_nch ? c : 0) * cs;
+    if (P.src1.C > 0) {   // (a single-segment launch keeps the lane offsets of segment 0)
+#pragma unroll
+      for (int pp = 0; pp < NPP; ++pp) {
+        f_xo[pp] = s1 ? xo1[pp] : xo0[pp];
+        f_xl[pp] = f_xo[pp];
+      }
+    }
+  };
+  auto fast_halo = [&](int ch, float* Xb) {
+    const bool c_ok = ch < f_nch;
+    const float* const zeros = X4 ? &gsd_pad16_w43[0] : &gsd_pad_w43[0];
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp) {
+      if constexpr (X4) {
+        if (!(p_on[pp] && u_ch[pp] == ch)) continue;
+      } else {
+        if (!p_on[pp]) continue;
+      }
+      float* dstp = X4 ? Xb + ch * PS + u_lds[pp] : Xb + ch * PS + (wave8 + NWAVE * pp) * 64;
+      if (f_plain) {
+        if (f_xo[pp] >= 0) {
+          const float* gp = f_b[ch] + f_xl[pp];
+          if constexpr (X4) {
+            __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+          } else {
+            __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
+          }
+        }
+      } else if (f_xo[pp] != -2) {
+        const float* gp = (c_ok && f_xo[pp] >= 0) ? f_b[ch] + f_xl[pp] : (c_ok ? f_sent : zeros);
+        if constexpr (X4) {
+          __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+        } else {
+          __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
+        }
+      }
+    }
+  };
+
   // slots 0..NWI-1: the weight chunk (16 B per lane); slot NWI+ch: input channel ch of the chunk
   auto dma_slot = [&](int slot, int chunk, int buf) {
     float* Wb = smem + buf * BUF;
+    if constexpr (FAST) {
+      if (slot >= NWI && slot < NWI + 4) {
+        fast_halo(slot - NWI, Wb + WM * WTILE);
+        return;
+      }
+    }
     if (slot < NWI) {
       const int e = tid + slot * NT;                 // 16-byte piece of the block's WM weight images (LDS: linear in e)
       if constexpr (WM == 1) {
@@ -166,17 +424,45 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     } else if (slot < NWI + 4) {
       const int ch = slot - NWI;
       float* Xb = Wb + WM * WTILE;
+#ifdef W43_SIMPLE   // diagnostic build: one source segment, Cin % 4 == 0 -- the fill without any bookkeeping branches
+      if constexpr (!X4) {
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp)
+          if (p_on[pp] && xo0[pp] >= 0)
+            __builtin_amdgcn_global_load_lds(d_base + xl0[pp], Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
+        d_base += d_cs;
+        return;
+      }
+#endif
       if (d_left == 0 && d_seg == 0) {
         d_seg = 1;
         d_left = P.src1.C;
         d_base = P.src1.p + (long long)n * P.src1.ns;
         d_cs = P.src1.cs;
-        d_sent = P.src1.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0];
+        d_sent = X4 ? (P.src1.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (P.src1.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
 #pragma unroll
         for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo1[pp];
       }
       const bool c_ok = d_left > 0;
-      if (c_ok && d_seg == 0) {
+      if constexpr (X4) {
+        // 16-byte pieces: the unit (channel plane ch, instruction ii) of the wave that owns it; the other waves only keep the
+        // channel bookkeeping below in step
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) {
+          if (p_on[pp] && u_ch[pp] == ch) {
+            float* dstp = Xb + ch * PS + u_lds[pp];
+            if (c_ok && d_seg == 0) {
+              if (xo0[pp] >= 0) {
+                const float* gp = d_base + xl0[pp];
+                __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+              }   // padding pieces: written once, below
+            } else if (d_xo[pp] != -2) {
+              const float* g = (c_ok && d_xo[pp] >= 0) ? d_base + d_xo[pp] : (c_ok ? d_sent : &gsd_pad16_w43[0]);
+              __builtin_amdgcn_global_load_lds(g, dstp, 16, 0, 0);
+            }
+          }
+        }
+      } else if (c_ok && d_seg == 0) {
         // fast path, first segment: the padding positions of every plane were written once at kernel start (below), so a
         // fill only moves the lanes that have a pixel -- no select, no sentinel pointer, one v_lshl_add_u64 per instruction
 #pragma unroll
@@ -226,6 +512,12 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
       sBw[3 * BMB + c] = P.bw_invstd[co];
     }
   }
+  if constexpr (NL > 0) {
+    if (wave8 >= NWAVE) {   // wave-uniform: the loader waves never reach the MFMA loop or the epilogue
+      w43_loader<X4, NL>(P, smem, BUF, n, h0, w0, mbb, lane, wave8 - NWAVE);
+      return;
+    }
+  }
   const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
 
   f32x4 acc[MT][6];
@@ -250,11 +542,16 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
   };
 
   const int a_lane = wm * WTILE + l16 * 4;
+  if constexpr (NL == 0) {
+    if constexpr (FAST) begin_fill(0);
 #pragma unroll
-  for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
+    for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
+  }
+  W43_STAMP(5)   // prologue
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
     gsd_dma_barrier();
+    W43_STAMP(0)   // wait for the chunk's DMA + barrier
     const int kc = chunk * 4 + j;
     const float sc = sAff[kc], sh = sAff[Kpad + kc];
     const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
@@ -276,19 +573,38 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
         rb[(r + 1) & 1] = *reinterpret_cast<const f32x2*>(&Wc[baddr + (r + 1) * P.WCp + 4]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (r == 0) W43_STAMP(1)   // first operand reads + first transform: no MFMA of this wave yet
 #pragma unroll
       for (int f = 0; f < 6; ++f) {
         const int s = r * 6 + f, cs = s & 1;
         if (s + 1 < 18) av[cs ^ 1] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18 + s + 1) * WS + a_lane]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][f] = mfma16(av[cs][m], v[f], acc[m][f]);
-        if (more && s < 5) {
-          dma_slot(2 * s, chunk + 1, cur ^ 1);
-          dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+        if constexpr (NL == 0) {
+          if constexpr (FAST) {
+            // one slot per k-step, behind its four MFMAs: a wave is held ~100 cycles by every LDS-DMA instruction it issues
+            // (profiles/ubench/dma_issue.hip), about what its four MFMAs keep the matrix pipe busy
+            if (more && s < 5) {
+              if (s == 0) begin_fill(chunk + 1);
+              dma_slot(2 * s, chunk + 1, cur ^ 1);
+              dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+            }
+          } else if (more && s < 5) {
+#ifdef W43_STAMP_DMA
+            W43_STAMP(2)
+#endif
+            dma_slot(2 * s, chunk + 1, cur ^ 1);
+            dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
+#ifdef W43_STAMP_DMA
+            W43_STAMP(6)   // the DMA slots alone
+#endif
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (s == 4) W43_STAMP(2)   // the k-steps that carry the next chunk's DMA issue
       }
     }
+    W43_STAMP(3)     // the other thirteen k-steps (52 MFMAs)
   }
 
   // ---- epilogue: y = A^T M, NCHW stores (two destination segments with crop), BatchNorm partial sums ----------------------
@@ -298,7 +614,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     const int h = h0 + tr, w = w0 + 4 * tq;
     int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
     if ((unsigned)hd < (unsigned)P.dst0.H) {
-      off0 = hd * P.dst0.W + wd;
+      off0 = hd * P.dst0.ws + wd;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0 |= 1 << i;
@@ -306,7 +622,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
     hd = h - P.dst1.oh;
     wd = w - P.dst1.ow;
     if ((unsigned)hd < (unsigned)P.dst1.H) {
-      off1 = hd * P.dst1.W + wd;
+      off1 = hd * P.dst1.ws + wd;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1 |= 1 << i;
@@ -420,6 +736,13 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void conv3x3_w43_kernel(
       }
     }
   }
+#ifdef GSD_W43_STAMPS
+  W43_STAMP(4)   // epilogue
+  if (P.stamps != nullptr && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P.stamps[((size_t)blockIdx.x * NWAVE + wave8) * 8 + i] = st_acc[i];
+  }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -459,17 +782,73 @@ bool plan_w43(int H, int W, int M, W43Plan* best) {
   return best_cost >= 0;
 }
 
-template <int WM>
-int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st) {
+// LDS bank cost of the consumers' halo reads (one ds_read_b128 + one ds_read_b64 per kernel row; lane -> tile as in the
+// kernel) for a row pitch LP and plane stride PS: sum over the four pixel groups of the LDS cycles per read pair.
+int halo_read_cycles(int TWq, int LP, int PS, int off) {
+  static const int g128[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  int total = 0;
+  for (int wave = 0; wave < 4; ++wave) {
+    int addr[64];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int q = wave * 16 + (lane & 15);
+      addr[lane] = (lane >> 4) * PS + (q / TWq) * LP + 4 * (q % TWq) + off;
+    }
+    for (int half = 0; half < 2; ++half) {
+      for (int g = 0; g < 2; ++g) {   // ds_read_b128: 16-lane groups, 16 slots of 16 B
+        int worst = 0;
+        for (int slot = 0; slot < 16; ++slot) {
+          int distinct = 0, seen[16];
+          for (int i = 0; i < 16; ++i) {
+            const int a = addr[g128[g][i] + 32 * half];
+            if ((a / 4) % 16 != slot) continue;
+            bool dup = false;
+            for (int k = 0; k < distinct; ++k) dup = dup || seen[k] == a;
+            if (!dup) seen[distinct++] = a;
+          }
+          worst = distinct > worst ? distinct : worst;
+        }
+        total += worst;
+      }
+      int worst = 0;                  // ds_read_b64 at +4 floats: 32-lane halves, 32 slots of 8 B
+      for (int slot = 0; slot < 32; ++slot) {
+        int distinct = 0, seen[32];
+        for (int i = 0; i < 32; ++i) {
+          const int a = addr[i + 32 * half] + 4;
+          if ((a / 2) % 32 != slot) continue;
+          bool dup = false;
+          for (int k = 0; k < distinct; ++k) dup = dup || seen[k] == a;
+          if (!dup) seen[distinct++] = a;
+        }
+        worst = distinct > worst ? distinct : worst;
+      }
+      total += worst;
+    }
+  }
+  return total;
+}
+
+// one launcher per kernel instantiation (the address of the kernel keys the per-device launch-attribute cache)
+template <int WM, bool X4, int NL, bool FAST>
+int launch_one(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM>)); e != hipSuccess) {
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST>);
+  if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL(conv3x3_w43_kernel<WM>, dim3(grid), dim3(256 * WM), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w43_kernel<WM, X4, NL, FAST>), dim3(grid), dim3(256 * WM + 64 * NL), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w43");
   return GSD_OK;
+}
+
+int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm, bool x4, int nl, bool fast) {
+  if (nl == 1) return x4 ? launch_one<1, true, 1, false>(P, grid, lds, st) : launch_one<1, false, 1, false>(P, grid, lds, st);
+  if (nl == 2) return x4 ? launch_one<1, true, 2, false>(P, grid, lds, st) : launch_one<1, false, 2, false>(P, grid, lds, st);
+  if (wm == 2) return x4 ? launch_one<2, true, 0, false>(P, grid, lds, st) : launch_one<2, false, 0, false>(P, grid, lds, st);
+  if (fast) return x4 ? launch_one<1, true, 0, true>(P, grid, lds, st) : launch_one<1, false, 0, true>(P, grid, lds, st);
+  return x4 ? launch_one<1, true, 0, false>(P, grid, lds, st) : launch_one<1, false, 0, false>(P, grid, lds, st);
 }
 
 }  // namespace
@@ -520,6 +899,10 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.dst0 = to_dstd(dst[0]);
   P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
   P.wt = wt;
+  P.stamps = nullptr;
+#ifdef GSD_W43_STAMPS
+  P.stamps = g_w43_stamp_buf;
+#endif
   P.partials = partials;
   P.bw_raw = bw_raw; P.bw_scale = bw_scale; P.bw_shift = bw_shift; P.bw_mean = bw_mean; P.bw_invstd = bw_invstd;
   P.Cin = Cin;
@@ -529,6 +912,10 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   // measured (profiles/bench_conv_forms.py): two independent 4-wave blocks per CU hide each other's barriers better than one
   // 8-wave block shares its halo (+6 % for the 8-wave form at Cin <= 512, +1.5 % at Cin = 1024); GSD_W43_BIG=1 selects it
   const bool big = gsd_env_set("GSD_W43_BIG");
+  // producer / consumer form (default): GSD_W43_NL loader waves per block (0: every wave issues its share of the DMA itself)
+  const int nl = big ? 0 : gsd_env_int("GSD_W43_NL", 0);   // measured: a loader wave cannot keep up without a deeper ring
+  const bool fast = gsd_env_int("GSD_W43_FAST", 0) != 0 && (nsrc == 1 || src[0].C % 4 == 0);
+  GSD_REQUIRE(nl >= 0 && nl <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: GSD_W43_NL must be 0, 1 or 2");
   const int WM = (pl.mblocks % 2 == 0 && big) ? 2 : 1;
   P.mblocks = pl.mblocks / WM;
   P.N = N; P.H = H; P.W = W;
@@ -537,10 +924,31 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.PS = round_up(P.WR * P.WCp, 4) + 4;   // + one bank group: the four channel planes of a k-step start 16 B apart (mod 4)
   P.NPV = ceil_div(P.WR * P.WCp, 64);
   GSD_REQUIRE(P.NPV <= 8, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: halo window too large");
+  // 16-byte halo pieces: every source row must start 16-byte aligned in the consumer's column grid
+  P.NP = pl.TW / 4 + 2;
+  P.RPI = 64 / P.NP;
+  P.NI = ceil_div(P.WR, P.RPI);
+  P.RO = 0;
+  bool x4 = gsd_env_int("GSD_W43_X4", 1) != 0 && P.NI <= 2;
+  for (int i = 0; i < nsrc && x4; ++i)
+    x4 = ((uintptr_t)src[i].ptr & 15) == 0 && src[i].off_w % 4 == 0 && src[i].n_stride % 4 == 0 && src[i].c_stride % 4 == 0 &&
+         (i == 0 ? P.src0.ws : P.src1.ws) % 4 == 0;
+  if (x4) {
+    P.WCp = P.NP * 4;      // LDS row pitch: the NP pieces of a window row, contiguous (one instruction spans RPI rows)
+    P.RO = 4;
+    int best = -1;
+    for (int ps = P.WR * P.WCp + 4; ps < P.WR * P.WCp + 4 + 68; ps += 4) {
+      const int c = halo_read_cycles(pl.TWq, P.WCp, ps, P.RO);
+      if (best < 0 || c < best) {
+        best = c;
+        P.PS = ps;
+      }
+    }
+  }
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
   const size_t lds = (size_t)(2 * (WM * W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
-  return WM == 2 ? launch_w43<2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w43<1>(P, (int)grid, lds, (hipStream_t)stream);
+  return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast);
 }
 
 extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
