@@ -23,12 +23,13 @@ class gsd_src(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("off_h", C.c_int32), ("off_w", C.c_int32), ("relu", C.c_int32),
+                ("w_stride", C.c_int32), ("reserved_", C.c_int32),
                 ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
 
 
 class gsd_dst(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("off_h", C.c_int32), ("off_w", C.c_int32),
+                ("off_h", C.c_int32), ("off_w", C.c_int32), ("w_stride", C.c_int32),
                 ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "gsd_convT2x2_dgrad": (_I, [_SRC, _P, _I, _I, _DST, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad": (_I, [_SRC, _I, _SRC, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "gsd_conv3x3_wgrad_takes_pitched_dy": (_I, [_I, _I, _I, _I, _I]),
     "gsd_convT2x2_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_convT2x2_wgrad": (_I, [_SRC, _SRC, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_bn_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -87,7 +89,7 @@ SIGNATURES = {
     "gsd_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _SRC, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "gsd_bn_bwd_reduce_partials": (_I, [_P, _I, _I, _P, _P]),
     "gsd_bn_bwd_finalize": (_I, [_P, _P, _I, _D, _P, _P, _P, _P, _P, _P]),
-    "gsd_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "gsd_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "gsd_sum_planes": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "gsd_maxpool2": (_I, [_SRC, _P, _I, _I, _I, _I, _P]),
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
@@ -163,37 +165,55 @@ def _chk_f32(t: torch.Tensor) -> None:
         raise GsdError(f"expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
 
 
+def _chk_nchw(t: torch.Tensor) -> None:
+    """(N,C,H,W) with unit column stride and non-overlapping rows / planes / images (contiguous, or a view of a pitched buffer)."""
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) < t.shape[3] or t.stride(1) < t.shape[2] * t.stride(2) or \
+            (t.shape[0] > 1 and t.stride(0) < t.shape[1] * t.stride(1)):
+        raise GsdError(f"expected an NCHW tensor with unit column stride, got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def pitched_empty(shape, device, pitch_multiple: int = 4) -> torch.Tensor:
+    """An (N,C,H,W) fp32 tensor whose rows start 16-byte aligned: a view of a buffer with the row pitch rounded up to a
+    multiple of 4 floats.  Kernels that take pitched operands move it as aligned 16-byte LDS-DMA pieces."""
+    n, c, h, w = shape
+    p = -(-w // pitch_multiple) * pitch_multiple
+    return torch.empty((n, c, h, p), device=device, dtype=torch.float32)[..., :w]
+
+
 def make_src(t: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
              relu: bool = False, c_off: int = 0, c_len: Optional[int] = None,
              off: Tuple[int, int] = (0, 0)) -> gsd_src:
-    """Describe channels [c_off, c_off+c_len) of a contiguous NCHW tensor as a gsd_src segment."""
+    """Describe channels [c_off, c_off+c_len) of an NCHW tensor as a gsd_src segment.  The tensor may be a view of a
+    PITCHED buffer (rows padded to a multiple of 4 floats): any strides with stride(3) == 1 are accepted."""
     _chk_f32(t)
-    assert t.dim() == 4 and t.is_contiguous()
+    _chk_nchw(t)
     n, ct, h, w = t.shape
     cl = ct - c_off if c_len is None else c_len
     s = gsd_src()
-    s.ptr = t.data_ptr() + 4 * c_off * h * w
+    s.ptr = t.data_ptr() + 4 * c_off * t.stride(1)
     s.scale = ptr(scale)
     s.shift = ptr(shift)
     s.C, s.H, s.W = cl, h, w
     s.off_h, s.off_w = off
     s.relu = 1 if relu else 0
-    s.n_stride = ct * h * w
-    s.c_stride = h * w
+    s.w_stride = t.stride(2)
+    s.n_stride = t.stride(0)
+    s.c_stride = t.stride(1)
     return s
 
 
 def make_dst(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None, off: Tuple[int, int] = (0, 0)) -> gsd_dst:
     _chk_f32(t)
-    assert t.dim() == 4 and t.is_contiguous()
+    _chk_nchw(t)
     n, ct, h, w = t.shape
     cl = ct - c_off if c_len is None else c_len
     d = gsd_dst()
-    d.ptr = t.data_ptr() + 4 * c_off * h * w
+    d.ptr = t.data_ptr() + 4 * c_off * t.stride(1)
     d.C, d.H, d.W = cl, h, w
     d.off_h, d.off_w = off
-    d.n_stride = ct * h * w
-    d.c_stride = h * w
+    d.w_stride = t.stride(2)
+    d.n_stride = t.stride(0)
+    d.c_stride = t.stride(1)
     return d
 
 

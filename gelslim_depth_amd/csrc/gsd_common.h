@@ -46,14 +46,14 @@ static inline SrcD to_srcd(const gsd_src& s) {
   SrcD d;
   d.p = s.ptr; d.scale = s.scale; d.shift = s.shift;
   d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w; d.relu = s.relu;
-  d.ws = s.W;
+  d.ws = s.w_stride;
   d.ns = s.n_stride; d.cs = s.c_stride;
   return d;
 }
 static inline DstD to_dstd(const gsd_dst& s) {
   DstD d;
   d.p = s.ptr; d.C = s.C; d.H = s.H; d.W = s.W; d.oh = s.off_h; d.ow = s.off_w;
-  d.ws = s.W;
+  d.ws = s.w_stride;
   d.ns = s.n_stride; d.cs = s.c_stride;
   return d;
 }
@@ -125,18 +125,25 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
-static inline int gsd_check_src(const gsd_src& s, const char* what) {
+// pitched_ok: the kernel addresses rows through w_stride; otherwise the operand must be row-contiguous (w_stride == W)
+static inline int gsd_check_src(const gsd_src& s, const char* what, bool pitched_ok = false) {
   GSD_REQUIRE(s.ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null ptr", what);
   GSD_REQUIRE(s.C > 0 && s.H > 0 && s.W > 0, GSD_ERR_BAD_ARG, "%s: bad dims C=%d H=%d W=%d", what, s.C, s.H, s.W);
   GSD_REQUIRE((s.scale == nullptr) == (s.shift == nullptr), GSD_ERR_BAD_ARG, "%s: scale/shift must come together", what);
-  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
+  GSD_REQUIRE(s.w_stride >= s.W, GSD_ERR_BAD_ARG, "%s: w_stride %d < W %d", what, s.w_stride, s.W);
+  GSD_REQUIRE(pitched_ok || s.w_stride == s.W, GSD_ERR_UNSUPPORTED, "%s: this kernel needs row-contiguous data (w_stride %d != W %d)",
+              what, s.w_stride, s.W);
+  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.w_stride && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
               what);
   return 0;
 }
-static inline int gsd_check_dst(const gsd_dst& s, const char* what) {
+static inline int gsd_check_dst(const gsd_dst& s, const char* what, bool pitched_ok = false) {
   GSD_REQUIRE(s.ptr != nullptr, GSD_ERR_BAD_ARG, "%s: null ptr", what);
   GSD_REQUIRE(s.C > 0 && s.H > 0 && s.W > 0, GSD_ERR_BAD_ARG, "%s: bad dims", what);
-  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
+  GSD_REQUIRE(s.w_stride >= s.W, GSD_ERR_BAD_ARG, "%s: w_stride %d < W %d", what, s.w_stride, s.W);
+  GSD_REQUIRE(pitched_ok || s.w_stride == s.W, GSD_ERR_UNSUPPORTED, "%s: this kernel needs row-contiguous data (w_stride %d != W %d)",
+              what, s.w_stride, s.W);
+  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.w_stride && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
               what);
   return 0;
 }
@@ -164,6 +171,13 @@ static inline int gsd_env_int(const char* name, int dflt) {
   return v != nullptr ? atoi(v) : dflt;
 }
 static inline bool gsd_env_set(const char* name) { return getenv(name) != nullptr; }
+
+// entry points that read a gsd_src without gsd_check_src: the operand must be row-contiguous unless the kernel says otherwise
+static inline int gsd_require_rows_contiguous(const gsd_src& s, const char* what) {
+  GSD_REQUIRE(s.w_stride == s.W, GSD_ERR_UNSUPPORTED, "%s: this kernel needs row-contiguous data (w_stride %d != W %d)", what,
+              s.w_stride, s.W);
+  return 0;
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

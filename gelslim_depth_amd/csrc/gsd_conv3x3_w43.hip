@@ -877,16 +877,16 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: weight layout must be 16-byte aligned");
   int csum = 0;
   for (int i = 0; i < nsrc; ++i) {
-    if (int e = gsd_check_src(src[i], "gsd_conv3x3_w43 src")) return e;
+    if (int e = gsd_check_src(src[i], "gsd_conv3x3_w43 src", true)) return e;
     GSD_REQUIRE(src[i].scale == nullptr || src[i].relu != 0, GSD_ERR_UNSUPPORTED,
                 "gsd_conv3x3_w43: an affine source segment must also have relu (zero padding uses a NaN sentinel)");
-    GSD_REQUIRE((int64_t)src[i].H * src[i].W < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: plane too large");
+    GSD_REQUIRE((int64_t)src[i].H * src[i].w_stride < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: plane too large");
     csum += src[i].C;
   }
   GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: source segments hold %d channels, Cin=%d", csum, Cin);
   csum = 0;
   for (int i = 0; i < ndst; ++i) {
-    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3_w43 dst")) return e;
+    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3_w43 dst", true)) return e;
     csum += dst[i].C;
   }
   GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: destination segments hold %d channels, Cout=%d", csum, Cout);

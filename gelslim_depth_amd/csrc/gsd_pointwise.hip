@@ -478,6 +478,7 @@ extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale,
     GSD_REQUIRE(da->scale == nullptr && da->relu == 0 && da->off_h == 0 && da->off_w == 0 && da->H == H && da->W == W &&
                     da->C >= C,
                 GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: da must be a plain (>=C,H,W) tensor");
+    if (int e = gsd_require_rows_contiguous(*da, "gsd_bn_bwd_reduce da")) return e;
     P.da = to_srcd(*da);
   }
   if (mode == 0) GSD_REQUIRE(P.da.p != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode PLAIN needs da");
@@ -553,11 +554,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
     }
   }
 }
+// Out-of-place form into a PITCHED buffer (rows of `pitch` floats, pitch % 4 == 0, 16-byte aligned): the result is what the
+// dW and dX kernels read next, and rows that start 16-byte aligned let them move it as aligned 16-byte LDS-DMA pieces (a
+// quarter of the gather instructions).  Same traffic as the in-place pass.  A thread owns 4 consecutive columns of one row:
+// four coalesced dword loads per input (the contiguous W = 427 rows are not 16-byte aligned), one 16-byte store; columns
+// W .. pitch-1 are written 0 -- the padding value of a plain gradient operand.
+__global__ __launch_bounds__(256) void bn_bwd_apply_pitched_kernel(const float* __restrict__ dz, const float* __restrict__ raw,
+                                                                   const float* scale, const float* mean, const float* invstd,
+                                                                   const float* c1, const float* c2, float* __restrict__ out,
+                                                                   int C, int H, int W, int pitch) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int q4 = pitch >> 2;                       // 16-byte pieces per output row
+  const int total = H * q4;
+  const size_t plane = ((size_t)n * C + c) * (size_t)H * W;
+  float* const o = out + ((size_t)n * C + c) * (size_t)H * pitch;
+  const float sc = scale[c], mu = mean[c], is = invstd[c], k1 = c1[c], k2 = c2[c];
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int h = e / q4, w = (e - h * q4) * 4;
+    const size_t src = plane + (size_t)h * W + w;
+    f32x4 d;
+    if (w + 4 <= W) {   // one (unaligned) 16-byte load per input: the contiguous rows of W = 427 floats are not 16-byte aligned
+      const f32x4 g = *reinterpret_cast<const f32x4u*>(dz + src), r = *reinterpret_cast<const f32x4u*>(raw + src);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = sc * (g[i] - k1 - (r[i] - mu) * is * k2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = w + i < W;
+        const float g = ok ? dz[src + i] : 0.f, r = ok ? raw[src + i] : mu;
+        d[i] = ok ? sc * (g - k1 - (r - mu) * is * k2) : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(o + (size_t)h * pitch + w) = d;
+  }
+}
 extern "C" int gsd_bn_bwd_apply(float* dz, const float* raw, const float* scale, const float* mean, const float* invstd,
-                                const float* c1, const float* c2, int N, int C, int H, int W, void* stream) {
+                                const float* c1, const float* c2, int N, int C, int H, int W, float* out, int out_w_stride,
+                                void* stream) {
   GSD_REQUIRE(dz && raw && scale && mean && invstd && c1 && c2 && N > 0 && C > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG,
               "gsd_bn_bwd_apply: bad argument");
   GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_apply: N, C must be <= 65535");
+  if (out != nullptr) {
+    GSD_REQUIRE(out_w_stride >= W && out_w_stride % 4 == 0 && ((uintptr_t)out & 15) == 0, GSD_ERR_BAD_ARG,
+                "gsd_bn_bwd_apply: the pitched destination needs a 16-byte aligned base and a row pitch %% 4 == 0 (got %d for W %d)",
+                out_w_stride, W);
+    const int total = H * (out_w_stride / 4);
+    const int bx = ceil_div(total, 256) < 64 ? ceil_div(total, 256) : 64;
+    hipLaunchKernelGGL(bn_bwd_apply_pitched_kernel, dim3(bx, C, N), dim3(256), 0, (hipStream_t)stream, dz, raw, scale, mean,
+                       invstd, c1, c2, out, C, H, W, out_w_stride);
+    GSD_LAUNCH_CHECK("gsd_bn_bwd_apply (pitched)");
+    return GSD_OK;
+  }
   const int chunks = ceil_div(H * W, BWD_CHUNK);
   const bool vec4 = (H * W) % 4 == 0 && (((uintptr_t)dz | (uintptr_t)raw) & 15) == 0;
   if (vec4)
@@ -591,6 +639,7 @@ extern "C" int gsd_maxpool2(const gsd_src* src, float* y, int N, int C, int H, i
   GSD_REQUIRE(src && src->ptr && y && N > 0 && C > 0 && H > 1 && W > 1, GSD_ERR_BAD_ARG, "gsd_maxpool2: bad argument");
   GSD_REQUIRE(src->C == C && src->H == H && src->W == W && src->off_h == 0 && src->off_w == 0, GSD_ERR_BAD_ARG,
               "gsd_maxpool2: src must be the full (C,H,W) tensor");
+  if (int e = gsd_require_rows_contiguous(*src, "gsd_maxpool2 src")) return e;
   GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_maxpool2: N, C must be <= 65535");
   const int Hp = H / 2, Wp = W / 2;
   hipLaunchKernelGGL(maxpool2_kernel, dim3(ceil_div(Hp * Wp, 256), C, N), dim3(256), 0, (hipStream_t)stream,
@@ -631,7 +680,7 @@ extern "C" int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* 
               "gsd_conv1x1_out: bad argument");
   GSD_REQUIRE(K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out: n_classes %d > %d", K, OUTC_MAXK);
   GSD_REQUIRE(src->C == C && src->H == H && src->W == W && src->off_h == 0 && src->off_w == 0 &&
-                  src->c_stride == (int64_t)H * W,
+                  src->c_stride == (int64_t)H * W && src->w_stride == W,
               GSD_ERR_BAD_ARG, "gsd_conv1x1_out: src must be the full contiguous (C,H,W) tensor");
   GSD_REQUIRE(N <= 65535, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out: N must be <= 65535");
   hipLaunchKernelGGL(conv1x1_out_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, (hipStream_t)stream, to_srcd(*src),

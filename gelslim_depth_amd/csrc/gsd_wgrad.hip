@@ -649,8 +649,8 @@ int check_plain(const gsd_src& s, const char* what) {
   GSD_REQUIRE(s.ptr != nullptr && s.scale == nullptr && s.shift == nullptr && s.relu == 0 && s.off_h == 0 &&
                   s.off_w == 0,
               GSD_ERR_BAD_ARG, "%s: gradient operand must be a plain tensor", what);
-  GSD_REQUIRE(s.c_stride >= (int64_t)s.H * s.W && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG, "%s: strides too small",
-              what);
+  GSD_REQUIRE(s.w_stride >= s.W && s.c_stride >= (int64_t)s.H * s.w_stride && s.n_stride >= s.c_stride, GSD_ERR_BAD_ARG,
+              "%s: strides too small", what);
   return 0;
 }
 
@@ -707,7 +707,12 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
     csum += a[i].C;
   }
   GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: activation segments hold %d channels, Cin=%d", csum, Cin);
+  for (int i = 0; i < nsrc; ++i)
+    if (int e = gsd_require_rows_contiguous(a[i], "gsd_conv3x3_wgrad activation")) return e;
   if (int e = check_plain(*dy, "gsd_conv3x3_wgrad dy")) return e;
+  // dy may be pitched (w_stride > W) for the Winograd form, which then moves it as aligned 16-byte pieces
+  if (!gsd_wgrad_w43_use(N, H, W, Cin, Cout))
+    if (int e = gsd_require_rows_contiguous(*dy, "gsd_conv3x3_wgrad dy (direct form)")) return e;
   GSD_REQUIRE(dy->C == Cout && dy->H == H && dy->W == W, GSD_ERR_BAD_ARG, "gsd_conv3x3_wgrad: dy must be (Cout,H,W)");
   for (int i = 0; i < nsrc; ++i)
     GSD_REQUIRE(a[i].scale == nullptr || a[i].relu != 0, GSD_ERR_UNSUPPORTED,
@@ -770,6 +775,8 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
   GSD_REQUIRE((x->scale == nullptr) == (x->shift == nullptr), GSD_ERR_BAD_ARG,
               "gsd_convT2x2_wgrad: scale/shift must come together");
   if (int e = check_plain(*dy, "gsd_convT2x2_wgrad dy")) return e;
+  if (int e = gsd_require_rows_contiguous(*dy, "gsd_convT2x2_wgrad dy")) return e;
+  if (int e = gsd_require_rows_contiguous(*x, "gsd_convT2x2_wgrad x")) return e;
   GSD_REQUIRE(dy->C == Cout && dy->H == 2 * H && dy->W == 2 * W, GSD_ERR_BAD_ARG,
               "gsd_convT2x2_wgrad: dy must be (Cout,2H,2W)");
   GSD_REQUIRE(((uintptr_t)dy->ptr & 7) == 0 && (dy->c_stride & 1) == 0 && (dy->n_stride & 1) == 0, GSD_ERR_UNSUPPORTED,

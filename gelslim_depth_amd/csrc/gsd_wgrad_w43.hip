@@ -25,8 +25,26 @@
 #include <cstdlib>
 
 __device__ const float gsd_pad_wg43[2] = {0.f, __builtin_nanf("")};
+__device__ __attribute__((aligned(16))) const float gsd_zero16_wg43[4] = {0.f, 0.f, 0.f, 0.f};
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+// Diagnostic build only (-DGSD_WG43_STAMPS; never in the product library): s_memtime stamps around the segments of a stage.
+#ifdef GSD_WG43_STAMPS
+static unsigned long long* g_wg43_stamp_buf = nullptr;
+extern "C" void gsd_wg43_set_stamp_buffer(void* p) { g_wg43_stamp_buf = (unsigned long long*)p; }
+#define WG43_STAMP(i)                                                                            \
+  {                                                                                              \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    st_acc[i] += t_ - st_prev;                                                                   \
+    st_prev = t_;                                                                                \
+  }
+#else
+#define WG43_STAMP(i) {}
+#endif
 
 struct WgW43Params {
   SrcD a0, a1;  // activation (B operand), up to two concatenated segments
@@ -36,24 +54,37 @@ struct WgW43Params {
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS;
   int stages_total, splits, mblocks, nblocks;
+  unsigned long long* stamps;   // diagnostic builds only
 };
 
 namespace {
-constexpr int WG_DS = 68;
+constexpr int WG_DS = 68;      // dy row stride in LDS, dword gathers: 64 pixels + 4 (bank spread)
+constexpr int WG_DS_X4 = 64;   // AX4: rows are contiguous 256-byte runs (one DMA instruction fills four), XOR-swizzled instead
 }
 
 // NWM x NWN waves of 32 co x 16 ci: (2,2) block 64 co x 32 ci, 4 waves, two blocks per CU; (4,2) 128 co x 32 ci and (2,4)
 // 64 co x 64 ci, 8 waves, one block per CU: one operand's tile is then amortised over twice the MFMAs (24 instead of 32
 // DMA instructions per wave and stage; measured 8 % faster than two 4-wave blocks).
-template <int NWM, int NWN>
+//
+// AX4: dy comes from a PITCHED buffer (rows 16-byte aligned: gsd_bn_bwd_apply's out-of-place form) and moves as aligned
+// 16-byte pieces -- a piece is one Winograd tile (4 pixels), an instruction fills four 64-pixel rows: 32 instead of 128
+// DMA instructions per stage for dy, i.e. 12 instead of 24 per wave (stamps, profiles/stamp_wgrad.py: the waves spend ~40 %
+// of their time issuing the fills, ~250 cycles per instruction).  The LDS rows are then contiguous (no padding between
+// them), so the 16 rows of a ds_read_b128 would collide on 4 banks: tile t of row r is stored at slot t ^ (r & 15)
+// (swizzle on the SOURCE address of the DMA and on the read; cdna_hip_programming.md rule 21).
+template <int NWM, int NWN, bool AX4>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
-  constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = WG_DS, MT = 2;
+  constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
   const int BUF = BM * DS + BN * XS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GSD_WG43_STAMPS
+  unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
   const int wm = wave / NWN, wn = wave % NWN;
   const int j = lane >> 4, l16 = lane & 15;
 
@@ -68,9 +99,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
 
   // ---- DMA lane geometry -------------------------------------------------------------------------------------------------
   // A: lane = pixel (tile t = lane>>2, element lane&3) of the stage in tile-major order
-  const int a_t = lane >> 2;
+  // AX4: lane = (row lr = lane>>4 of the instruction's four rows, slot q = lane&15), slot q of row r holds tile q ^ (r & 15);
+  // the wave's instructions are i' = wave + NW*k (rows 4*i' .. 4*i'+3), so (row & 15) = (4*wave + lr) & 15 for all of them
+  const int a_lr = lane >> 4;
+  const int a_t = AX4 ? ((lane & 15) ^ ((4 * wave + a_lr) & 15)) : (lane >> 2);
   const int a_r = a_t / P.TWq;
-  const int a_c = (a_t - a_r * P.TWq) * 4 + (lane & 3);
+  const int a_c = (a_t - a_r * P.TWq) * 4 + (AX4 ? 0 : (lane & 3));
   // B: window positions p*64 + lane -> (row, column) of the padded window and the float offset from the window origin in
   // a plane of segment A / B (their widths may differ).  Every instruction moves all 64 lanes (no exec masks on the
   // issue path): a lane past the window re-reads the window origin into the slack behind it (XS >= npv*64).
@@ -83,8 +117,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     b_cc[p] = pos - b_rr[p] * P.WCp;
     const bool in_win = b_rr[p] < P.WR && b_cc[p] < P.WC;
     if (!in_win) b_rr[p] = b_cc[p] = 0;
-    oA[p] = b_rr[p] * P.a0.W + b_cc[p];
-    oB[p] = b_rr[p] * P.a1.W + b_cc[p];
+    oA[p] = b_rr[p] * P.a0.ws + b_cc[p];
+    oB[p] = b_rr[p] * P.a1.ws + b_cc[p];
   }
 
   // deferred BatchNorm+ReLU of this lane's input channel
@@ -133,10 +167,31 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     const bool skipA = false, skipB = false;
 #endif
     // ---- A: dy rows ----
-    {
+    if constexpr (AX4) {
+      const bool inside = h0 + P.TH <= P.H && w0 + P.TW <= P.dy.ws && m0 + BM <= P.M;
+      const bool pix_ok = (h0 + a_r) < P.H && (w0 + a_c) < P.W;   // the piece's first pixel exists; columns W.. of the pitch hold 0
+      const float* rbase = P.dy.p + (long long)n * P.dy.ns + (long long)(m0 + 4 * wave + a_lr) * P.dy.cs +
+                           ((long long)(h0 + a_r) * P.dy.ws + (w0 + a_c));
+      const long long rstep = (long long)(4 * NW) * P.dy.cs;
+      const int ninstr = skipA ? 0 : BM / 4 / NW;
+      if (inside) {
+#pragma unroll 4
+        for (int i = 0; i < ninstr; ++i) {
+          __builtin_amdgcn_global_load_lds(rbase, Ab + (wave + NW * i) * (4 * DS), 16, 0, 0);
+          rbase += rstep;
+        }
+      } else {
+#pragma unroll 4
+        for (int i = 0; i < ninstr; ++i) {
+          const float* g = (pix_ok && m0 + 4 * (wave + NW * i) + a_lr < P.M) ? rbase : &gsd_zero16_wg43[0];
+          __builtin_amdgcn_global_load_lds(g, Ab + (wave + NW * i) * (4 * DS), 16, 0, 0);
+          rbase += rstep;
+        }
+      }
+    } else {
       const bool inside = h0 + P.TH <= P.H && w0 + P.TW <= P.W;
       const bool pix_ok = (h0 + a_r) < P.H && (w0 + a_c) < P.W;
-      const int aoff = (h0 + a_r) * P.dy.W + (w0 + a_c);
+      const int aoff = (h0 + a_r) * P.dy.ws + (w0 + a_c);
       const float* rbase = P.dy.p + (long long)n * P.dy.ns + (long long)(m0 + wave) * P.dy.cs;
       const long long rstep = (long long)NW * P.dy.cs;
       const int nrows = skipA ? 0 : BM / NW;
@@ -158,7 +213,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     // ---- B: activation windows ----
     // (named scalars, not arrays: an array indexed by the segment lands in scratch memory, with a vmcnt(0) per access)
     const int hsA = h0 - 1 - P.a0.oh, wsA = w0 - 1 - P.a0.ow, hsB = h0 - 1 - P.a1.oh, wsB = w0 - 1 - P.a1.ow;
-    const int woA = hsA * P.a0.W + wsA, woB = hsB * P.a1.W + wsB;
+    const int woA = hsA * P.a0.ws + wsA, woB = hsB * P.a1.ws + wsB;
     const bool inA = hsA >= 0 && hsA + P.WR <= P.a0.H && wsA >= 0 && wsA + P.WC <= P.a0.W;
     const bool inB = hsB >= 0 && hsB + P.WR <= P.a1.H && wsB >= 0 && wsB + P.WC <= P.a1.W;
     int vmA = 0, vmB = 0;   // border stages: bit p = position p*64+lane exists in the segment
@@ -221,7 +276,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   for (int ks = 0; ks < 4; ++ks) {
     const int t = 4 * ks + j;
     const int trow = t / P.TWq, tq = t - trow * P.TWq;
-    a_off[ks] = (wm * 32 + l16) * DS + 4 * t;
+    a_off[ks] = (wm * 32 + l16) * DS + 4 * (AX4 ? (t ^ l16) : t);   // AX4: rows wm*32 + l16 (+16): (row & 15) == l16
     b_off[ks] = BM * DS + (wn * 16 + l16) * XS + trow * P.WCp + 4 * tq;
   }
 
@@ -283,20 +338,28 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[r][f], acc[m][r * 6 + f]);
-      if (ks == 0 && late && more) issue_dma(next_stage, cur ^ 1);
+      if (ks == 0 && late && more) {
+        WG43_STAMP(2)
+        issue_dma(next_stage, cur ^ 1);
+        WG43_STAMP(1)
+      }
     }
+    WG43_STAMP(2)   // reads + transforms + 144 MFMAs
   };
 
   const int nst = s_end - s_begin;
   if (nst > 0) issue_dma(s_begin, 0);
+  WG43_STAMP(3)   // prologue
   for (int it = 0; it < nst; ++it) {
     const int cur = it & 1;
     gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
+    WG43_STAMP(0)
     // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
     // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
     // first k-step BEFORE it issues its share of the next stage's DMA.
     const bool late = NW == 8 && wave >= 4;
     if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+    WG43_STAMP(1)   // this wave's share of the next stage's DMA
     compute(cur, late, s_begin + it + 1, it + 1 < nst);
   }
 
@@ -311,6 +374,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         for (int t = 0; t < 18; ++t) P.slabs[(((size_t)split * 18 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
       }
     }
+#ifdef GSD_WG43_STAMPS
+  WG43_STAMP(3)   // epilogue (slab stores)
+  if (P.stamps != nullptr && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) P.stamps[((size_t)blockIdx.x * NW + wave) * 4 + i] = st_acc[i];
+  }
+#endif
 }
 
 // slab[split][r*6+f][co][ci] -> dW[co][ci][r][s] = sum_f G[f][s] * (sum over splits, in a fixed order).
@@ -413,6 +483,13 @@ int gsd_wgrad_w43_use(int N, int H, int W, int Cin, int Cout) {
   return Cin >= 16 && Cout >= 16;   // the 3-channel first layer keeps the pixel-split direct kernel
 }
 
+// 1 when gsd_conv3x3_wgrad serves this shape with a kernel that takes a pitched dy (w_stride > W): the engine then lets
+// gsd_bn_bwd_apply write d_raw into a pitched buffer.
+extern "C" int gsd_conv3x3_wgrad_takes_pitched_dy(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return gsd_wgrad_w43_use(N, H, W, Cin, Cout);
+}
+
 int64_t gsd_wgrad_w43_workspace(int N, int H, int W, int Cin, int Cout) { return plan_wg43(N, H, W, Cout, Cin).slab_elems; }
 
 // arguments already validated by gsd_conv3x3_wgrad
@@ -426,6 +503,10 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   P.a1 = nsrc > 1 ? to_srcd(a[1]) : null_srcd();
   P.dy = to_srcd(*dy);
   P.slabs = workspace;
+  P.stamps = nullptr;
+#ifdef GSD_WG43_STAMPS
+  P.stamps = g_wg43_stamp_buf;
+#endif
   P.M = Cout; P.Ncols = Cin;
   P.N = N; P.H = H; P.W = W;
   P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
@@ -433,22 +514,34 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   GSD_REQUIRE(pl.WR * pl.WCp <= 256, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad: halo window too large");
   const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
-  const size_t lds = (size_t)2 * (pl.BM * WG_DS + pl.BN * pl.XS) * sizeof(float);
-  static gsd_attr_once big_lds[3];   // per-device caches of an idempotent launch attribute (gsd_common.h)
-  const void* fns[3] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4>)};
-  for (int i = 0; i < 3; ++i)
+  // dy as aligned 16-byte pieces: rows, planes and images of the gradient buffer start 16-byte aligned
+  const bool ax4 = gsd_env_int("GSD_WG43_AX4", 1) != 0 && dy->w_stride % 4 == 0 && ((uintptr_t)dy->ptr & 15) == 0 &&
+                   dy->c_stride % 4 == 0 && dy->n_stride % 4 == 0 && pl.TW % 4 == 0;
+  const size_t lds = (size_t)2 * (pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + pl.BN * pl.XS) * sizeof(float);
+  static gsd_attr_once big_lds[6];   // per-device caches of an idempotent launch attribute (gsd_common.h)
+  const void* fns[6] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2, false>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2, false>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4, false>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2, true>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2, true>),
+                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4, true>)};
+  for (int i = 0; i < 6; ++i)
     if (hipError_t e = gsd_allow_big_lds(big_lds[i], fns[i]); e != hipSuccess) {
       gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return GSD_ERR_HIP;
     }
-  if (pl.BM == 128)
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2>), dim3((int)grid), dim3(512), lds, (hipStream_t)stream, P);
-  else if (pl.BN == 64)
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4>), dim3((int)grid), dim3(512), lds, (hipStream_t)stream, P);
-  else
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2>), dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
+  const dim3 g((int)grid);
+  const hipStream_t st = (hipStream_t)stream;
+  if (pl.BM == 128) {
+    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2, true>), g, dim3(512), lds, st, P);
+    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2, false>), g, dim3(512), lds, st, P);
+  } else if (pl.BN == 64) {
+    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4, true>), g, dim3(512), lds, st, P);
+    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4, false>), g, dim3(512), lds, st, P);
+  } else {
+    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2, true>), g, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2, false>), g, dim3(256), lds, st, P);
+  }
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
   const long long per = 3LL * Cout * Cin;
   if (pl.splits >= 64) {

@@ -32,6 +32,10 @@ def _r64(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
+def _r4(w: int) -> int:
+    return (w + 3) // 4 * 4
+
+
 class _ConvForm:
     """Entry points and weight-layout modes of one of the two conv3x3 forms: 0 direct taps, 1 Winograd F(4,3) along rows."""
 
@@ -59,6 +63,8 @@ class _Unit:
         self.scale = self.shift = self.mean = self.invstd = self.c1 = self.c2 = None
         self.sums = None
         self.raw = self.g = None
+        self.dsrc = None  # d_raw as the dW / dX kernels read it: g itself, or the pitched scratch buffer (engine.gp)
+        self.pitched = False   # gsd_bn_bwd_apply writes d_raw out of place into the pitched buffer
         self.srcs = None  # gsd_src array kept for wgrad
         self.form_f = self.form_d = None   # _ConvForm of the forward / dX launch for the current shape
         self.fused_rows = 0                # partial rows written by the dX launch that produced this unit's dz
@@ -132,6 +138,7 @@ class UNetEngine:
         f32 = dict(device=dev, dtype=torch.float32)
         max_part = 1
         max_ws = 1
+        max_gp = 0
         for u in self.units:
             lh, lw = hs[u.level], ws[u.level]
             if u.raw is None:
@@ -158,6 +165,12 @@ class UNetEngine:
             if train:
                 max_part = max(max_part, lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw) * 3 * u.cout)
                 max_ws = max(max_ws, lib.gsd_conv3x3_wgrad_workspace(n, lh, lw, u.cin, u.cout))
+                # d_raw goes to a row-pitched scratch buffer (16-byte aligned rows) when both of its readers -- dW and dX
+                # of this unit -- are the Winograd kernels, which then move it as aligned 16-byte LDS-DMA pieces
+                u.pitched = bool(lib.gsd_conv3x3_wgrad_takes_pitched_dy(n, lh, lw, u.cin, u.cout)) and \
+                    (not u.need_dgrad or u.form_d.algo == 1)
+                if u.pitched:
+                    max_gp = max(max_gp, n * u.cout * lh * _r4(lw))
         for up in self.ups:
             li = up.level_in
             if up.out is None:
@@ -172,6 +185,7 @@ class UNetEngine:
         self.pooled = [None] + [torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32) for l in range(1, self.L + 1)]
         self.dpooled = [None] + ([torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32)
                                  for l in range(1, self.L + 1)] if train else [None] * self.L)
+        self.gp = torch.empty((max_gp,), **f32) if (train and max_gp) else None   # pitched d_raw scratch, one unit at a time
         self.partials = torch.empty((max_part,), **f32)
         self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
 
@@ -314,10 +328,16 @@ class UNetEngine:
                                       G[u.bname].data_ptr(), None if dwout is None else dwout.data_ptr(),
                                       u.c1.data_ptr(), u.c2.data_ptr(), st),
               "bn_bwd_finalize")
+        if u.pitched:
+            p = _r4(lw)
+            u.dsrc = self.gp[:n * u.cout * lh * p].view(n, u.cout, lh, p)[..., :lw]
+            out_ptr = u.dsrc.data_ptr()
+        else:
+            p, u.dsrc, out_ptr = 0, u.g, None
         check(lib.gsd_bn_bwd_apply(u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
-                                   u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), n, u.cout, lh, lw, st),
+                                   u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), n, u.cout, lh, lw, out_ptr, p, st),
               "bn_bwd_apply")
-        dy = L.make_src(u.g)
+        dy = L.make_src(u.dsrc)
         check(lib.gsd_conv3x3_wgrad(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, G[u.wname].data_ptr(),
                                     self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, lh, lw, st), "conv3x3_wgrad")
 
@@ -335,7 +355,7 @@ class UNetEngine:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
         check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
-        s = L.src_array([L.make_src(u.g)])
+        s = L.src_array([L.make_src(u.dsrc)])
         ev = self._log_begin()
         check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
               "conv3x3 dgrad")
@@ -346,7 +366,7 @@ class UNetEngine:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
         check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
-        s = L.make_src(u.g)
+        s = L.make_src(u.dsrc)
         d = L.make_dst(prev.g)
         prev.fused_rows = u.form_d.partial_rows(n, lh, lw, u.cin)
         ev = self._log_begin()

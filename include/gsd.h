@@ -60,9 +60,15 @@ typedef struct {
   const float* scale;   /* per-channel affine applied on load, or NULL for identity             */
   const float* shift;
   int32_t C;            /* channels in this segment                                             */
-  int32_t H, W;         /* stored extent; row stride is W                                       */
+  int32_t H, W;         /* stored extent                                                        */
   int32_t off_h, off_w; /* where stored (0,0) sits in the consumer's grid (F.pad top/left)      */
   int32_t relu;         /* max(0, .) after the affine                                           */
+  int32_t w_stride;     /* elements between rows (row pitch, >= W).  Kernels that take a pitched
+                           operand say so; the others require w_stride == W.  With a pitch that is
+                           a multiple of 4 floats (and 16-byte aligned strides) the Winograd kernels
+                           move the operand as aligned 16-byte LDS-DMA pieces; columns W .. pitch-1
+                           must then hold the operand's padding value (0 for a plain tensor).      */
+  int32_t reserved_;    /* keeps the 64-bit members aligned; 0                                  */
   int64_t n_stride;     /* elements between images                                              */
   int64_t c_stride;     /* elements between channels                                            */
 } gsd_src;
@@ -74,6 +80,7 @@ typedef struct {
   int32_t C;
   int32_t H, W;
   int32_t off_h, off_w;
+  int32_t w_stride;     /* elements between rows (row pitch, >= W); see gsd_src                  */
   int64_t n_stride;
   int64_t c_stride;
 } gsd_dst;
@@ -152,6 +159,8 @@ int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout,
                       float* dw, float* workspace, int64_t workspace_elems,
                       int N, int H, int W, void* stream);
+/* 1 when gsd_conv3x3_wgrad serves this shape with a kernel that takes a pitched dy (dy->w_stride > W, see gsd_src). */
+int gsd_conv3x3_wgrad_takes_pitched_dy(int N, int H, int W, int Cin, int Cout);
 /* dW and db of ConvTranspose2d(k2,s2): x (h,w) with deferred BN, dy (2h,2w) plain;
  * dW in the reference's (Ci,Co,2,2) layout. */
 int64_t gsd_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
@@ -206,10 +215,13 @@ int gsd_bn_reduce_finalize(const float* partials, int rows, int Mpad, int C, dou
                            float* mean, float* invstd, float* scale, float* shift, const gsd_guard* guard, void* stream);
 int gsd_bn_bwd_reduce_finalize(const float* partials, int rows, int layout_mpad, int C, double* sums, double count,
                                float* dgamma, float* dbeta, float* dwout, float* c1, float* c2, void* stream);
-/* pass 3: d_raw = scale_g * (dz - c1 - xhat*c2), in place on dz; scale_g = gamma*invstd = scale. */
+/* pass 3: d_raw = scale_g * (dz - c1 - xhat*c2); scale_g = gamma*invstd = scale.
+ * out == NULL: in place on dz.  Otherwise the result goes to `out`, an (N,C,H,out_w_stride) buffer whose rows are
+ * PITCHED (out_w_stride >= W, a multiple of 4 floats, base 16-byte aligned; columns W.. are written 0) and dz is left
+ * as it is: the dW / dX kernels that read d_raw next move a pitched operand as aligned 16-byte pieces. */
 int gsd_bn_bwd_apply(float* dz, const float* raw, const float* scale, const float* mean,
                      const float* invstd, const float* c1, const float* c2,
-                     int N, int C, int H, int W, void* stream);
+                     int N, int C, int H, int W, float* out, int out_w_stride, void* stream);
 /* out[k] = sum over n, p of x[n][k][p] (contiguous [N][K][HW]); deterministic two-stage.
  * workspace >= 64*K floats. Used for dbias of the output conv / transposed conv. */
 int gsd_sum_planes(const float* x, int N, int K, int64_t HW, float* out, float* workspace, void* stream);

@@ -1,0 +1,45 @@
+"""Where a wave of wgrad3x3_w43_kernel spends its cycles (diagnostic build: bash profiles/build_diag.sh "-DGSD_WG43_STAMPS").
+usage (GPU box): GSD_LIB_PATH=profiles/ubench/libgsd_diag.so PYTHONPATH=. python profiles/stamp_wgrad.py [ci co h w [B]]"""
+import ctypes as C
+import sys
+import numpy as np
+import torch
+from gelslim_depth_amd import _lib as L
+
+lib, check = L.lib, L.check
+args = [int(a) for a in sys.argv[1:]]
+shapes = [tuple(args[:4])] if len(args) >= 4 else [(64, 64, 320, 427), (128, 128, 160, 213), (256, 256, 80, 106), (512, 512, 40, 53), (1024, 1024, 20, 26)]
+B = args[4] if len(args) > 4 else 32
+st = L.stream_ptr()
+NAMES = ["barrier+vmcnt wait", "DMA issue (next stage)", "reads+transforms+144 MFMA", "prologue+epilogue"]
+raw = C.CDLL(L.LIB_PATH)
+raw.gsd_wg43_set_stamp_buffer.argtypes = [C.c_void_p]
+for ci, co, h, w in shapes:
+    x = torch.randn(B, ci, h, w, device="cuda")
+    sc, sh = torch.rand(ci, device="cuda") + 0.5, torch.randn(ci, device="cuda") * 0.1
+    dy = torch.randn(B, co, h, w, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    need = lib.gsd_conv3x3_wgrad_workspace(B, h, w, ci, co)
+    ws = torch.empty(need, device="cuda")
+    a_src, dy_src = L.src_array([L.make_src(x, sc, sh, relu=True)]), L.make_src(dy)
+    buf = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device="cuda")
+
+    def run():
+        check(lib.gsd_conv3x3_wgrad(a_src, 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need, B, h, w, st), "wgrad")
+    raw.gsd_wg43_set_stamp_buffer(None)
+    run(); run()
+    buf.zero_()
+    raw.gsd_wg43_set_stamp_buffer(C.c_void_p(buf.data_ptr()))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run()
+    e1.record()
+    torch.cuda.synchronize()
+    raw.gsd_wg43_set_stamp_buffer(None)
+    a = buf.cpu().numpy().reshape(-1, 4).astype(np.float64)
+    a = a[a.sum(axis=1) > 0]
+    tot = a.sum(axis=1)
+    print("%4d->%4d %3dx%3d B%d  %.3f ms incl. slab reduction (stamped build), %d waves, %.0f cycles/wave" % (ci, co, h, w, B, e0.elapsed_time(e1), len(a), tot.mean()))
+    for i, nm in enumerate(NAMES):
+        print("    %-30s %5.1f %%" % (nm, 100 * a[:, i].sum() / tot.sum()))

@@ -276,9 +276,17 @@ def _bn_bwd_run(gsd, mode, raw, scale, shift, mean, invstd, n, c, h, w, da=None,
     outs = [torch.zeros(c, device="cuda") for _ in range(5)]   # dgamma dbeta dwout c1 c2
     gsd.check(gsd.lib.gsd_bn_bwd_finalize(sums.data_ptr(), None, c, float(n * h * w), *[o.data_ptr() for o in outs],
                                           gsd.stream_ptr()))
-    gsd.check(gsd.lib.gsd_bn_bwd_apply(g.data_ptr(), rawd.data_ptr(), vecs[0].data_ptr(), vecs[2].data_ptr(),
-                                       vecs[3].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), n, c, h, w,
-                                       gsd.stream_ptr()))
+    # out-of-place form into a row-pitched buffer (what the engine feeds the Winograd dW / dX kernels), then the in-place form:
+    # identical values, zeros in the pitch padding, the input left untouched by the first call
+    pitch = (w + 3) // 4 * 4
+    base = torch.full((n, c, h, pitch), float("nan"), device="cuda")
+    g_before = g.clone()
+    args = (rawd.data_ptr(), vecs[0].data_ptr(), vecs[2].data_ptr(), vecs[3].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(),
+            n, c, h, w)
+    gsd.check(gsd.lib.gsd_bn_bwd_apply(g.data_ptr(), *args, base.data_ptr(), pitch, gsd.stream_ptr()))
+    assert torch.equal(g, g_before)
+    gsd.check(gsd.lib.gsd_bn_bwd_apply(g.data_ptr(), *args, None, 0, gsd.stream_ptr()))
+    assert torch.equal(base[..., :w], g) and bool((base[..., w:] == 0).all())
     return g.cpu().numpy(), [o.cpu().numpy() for o in outs]
 
 
@@ -498,3 +506,73 @@ def test_bn_one_launch_reduce_finalize(gsd, rows, c, mpad):
         np.testing.assert_allclose(b1[0], col[off2:off2 + c], rtol=3e-7, atol=1e-6)  # dgamma
         for a, b in zip(b1, b2):
             np.testing.assert_allclose(a, b, rtol=3e-7, atol=1e-7)
+
+
+def pitched(t, fill=0.0):
+    """Copy of an (N,C,H,W) device tensor as a view of a row-pitched buffer (pitch = W rounded up to 4 floats); the pitch
+    padding holds `fill` -- the operand's padding value, as the ABI asks (include/gsd.h: gsd_src.w_stride)."""
+    n, c, h, w = t.shape
+    base = torch.full((n, c, h, (w + 3) // 4 * 4), fill, device=t.device, dtype=t.dtype)
+    base[..., :w] = t
+    return base[..., :w]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 16, 16, 9, 11), (1, 64, 64, 21, 29), (2, 20, 130, 6, 70), (1, 128, 64, 12, 427),
+                                         (3, 32, 48, 5, 16), (2, 64, 128, 17, 53)])
+def test_conv3x3_wgrad_pitched_dy(gsd, n, ci, co, h, w):
+    """dy from a row-pitched buffer (what gsd_bn_bwd_apply's out-of-place form produces): the Winograd dW kernel moves it as
+    aligned 16-byte pieces into an XOR-swizzled LDS image -- same result as from the contiguous tensor, bit for bit
+    (same products, same summation order), and against the oracle."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(ci * 13 + co + w)
+    raw = rnd(rng, n, ci, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, ci).astype(np.float32), rnd(rng, ci, scale=0.3)
+    a = np.maximum(raw * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    dy = rnd(rng, n, co, h, w)
+    _, dwr = on.conv3x3_bwd(a, np.zeros((co, ci, 3, 3), np.float32), dy, need_dx=False)
+    rawd, scd, shd, dyd = dev(raw), dev(sc), dev(sh), dev(dy)
+    assert gsd.lib.gsd_conv3x3_wgrad_takes_pitched_dy(n, h, w, ci, co) == 1
+    need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    a_src = gsd.src_array([gsd.make_src(rawd, scd, shd, relu=True)])
+    outs = []
+    for t in (dyd, pitched(dyd)):
+        dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+        dy_src = gsd.make_src(t)
+        gsd.check(gsd.lib.gsd_conv3x3_wgrad(a_src, 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need, n, h, w,
+                                            gsd.stream_ptr()))
+        outs.append(dw.clone())
+    assert rel_l1(outs[1].cpu().numpy(), dwr) < 5e-5
+    assert torch.equal(outs[0], outs[1])
+    # the direct form (first layer) refuses a pitched dy instead of mis-reading it
+    assert gsd.lib.gsd_conv3x3_wgrad_takes_pitched_dy(n, h, w, 3, co) == 0
+    x3 = torch.zeros((n, 3, h, w), device="cuda")
+    need3 = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, 3, co)
+    ws3 = torch.zeros(need3, device="cuda")
+    dw3 = torch.zeros((co, 3, 3, 3), device="cuda")
+    dyp = gsd.make_src(pitched(dyd))
+    if w % 4:
+        rc = gsd.lib.gsd_conv3x3_wgrad(gsd.src_array([gsd.make_src(x3)]), 1, C.byref(dyp), 3, co, dw3.data_ptr(), ws3.data_ptr(),
+                                       need3, n, h, w, gsd.stream_ptr())
+        assert rc == -2 and b"row-contiguous" in gsd.lib.gsd_last_error()
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 16, 24, 9, 11), (1, 64, 64, 21, 29), (1, 32, 64, 12, 427), (2, 128, 64, 17, 53)])
+def test_conv3x3_w43_pitched_source_and_destination(gsd, n, ci, co, h, w):
+    """The Winograd conv kernel with row-pitched operands: a plain source whose pitch padding holds 0 (halo windows move as
+    aligned 16-byte pieces) and a pitched destination -- equal to the contiguous launch; the destination's padding columns are
+    not touched."""
+    rng = np.random.default_rng(ci + co + w)
+    x = dev(rnd(rng, n, ci, h, w))
+    wt_ = dev(rnd(rng, co, ci, 3, 3, scale=0.2))
+    wl = layout(gsd, 4, wt_, co, ci)
+    y0 = torch.zeros((n, co, h, w), device="cuda")
+    gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(x)]), 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y0)]), 1,
+                                      None, n, h, w, gsd.stream_ptr()))
+    pitch = (w + 3) // 4 * 4
+    ybase = torch.full((n, co, h, pitch), 7.0, device="cuda")
+    y1 = ybase[..., :w]
+    gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(pitched(x))]), 1, wl.data_ptr(), ci, co,
+                                      gsd.dst_array([gsd.make_dst(y1)]), 1, None, n, h, w, gsd.stream_ptr()))
+    assert torch.equal(y0, y1)
+    assert bool((ybase[..., w:] == 7.0).all())
