@@ -67,6 +67,7 @@ struct W43Params {
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
   int NP, RPI, NI, RO;   // 16-byte halo pieces (X4): pieces per window row, rows per DMA instruction, instructions per plane, read offset
+  int fold;              // tile rows run over the padded flat rows of the whole batch (see w43_row)
   unsigned long long* stamps;   // diagnostic builds only
 };
 
@@ -76,6 +77,22 @@ constexpr int W43_WTILE = 72 * W43_BM;      // floats per weight chunk
 constexpr int W43_W4 = W43_WTILE / 4;       // float4s
 constexpr int W43_NWI = (W43_W4 + 255) / 256;
 }  // namespace
+
+// Row folding (small images): a 20 x 26 image fills a 64-tile block to 68 %.  With P.fold the tile grid runs over the
+// "padded flat rows" of the WHOLE batch, rho = n * (H + 1) + h + 1: row n * (H + 1) is a zero row that serves as the bottom
+// padding of image n-1 and as the top padding of image n, so a block's halo window is still TH + 2 consecutive rows and
+// nothing else in the kernel changes -- a block simply covers the tail of one image and the head of the next.  Returns the
+// image and the row inside it (-1: a zero row or a row past the batch).
+__device__ __forceinline__ void w43_row(const W43Params& P, int n, int rho, int& nn, int& hh) {
+  if (!P.fold) {
+    nn = n;
+    hh = rho;
+    return;
+  }
+  nn = rho >= 0 ? rho / (P.H + 1) : 0;
+  hh = (rho >= 0 && nn < P.N) ? rho - nn * (P.H + 1) - 1 : -1;
+  if (nn >= P.N) nn = 0;
+}
 
 // Loader wave of the producer / consumer form of the kernel below (NL > 0): it issues EVERY LDS-DMA of the block -- the 18
 // one-KiB pieces of the weight chunk and the halo windows of the chunk's four input channels -- one chunk ahead of the four
@@ -241,10 +258,10 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
   const int mb = mbb * WM + wm;
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
-  const int n = pt / tpi;
+  const int n = P.fold ? 0 : pt / tpi;            // fold: the tile rows cover the whole batch, the image is a per-lane value
   const int rt = pt - n * tpi;
   const int ty = rt / P.tiles_x;
-  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;   // fold: h0 is a padded flat row (w43_row)
 
   // ---- this lane's Winograd tile: 4 pixels (tr, 4*tq .. 4*tq+3) of the block's TH x TW output tile ----------------------
   const int q = wave * 16 + l16;
@@ -253,7 +270,9 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
   const int tq = q_ok ? q - tr * P.TWq : 0;
   const int baddr = WM * WTILE + j * PS + tr * P.WCp + 4 * tq + (X4 ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows tr .. tr+2
   int vmask = 0;                                            // pixels of the tile that exist in the image
-  if (q_ok && h0 + tr < P.H) {
+  int n_t, h_t;                                             // this lane's image and row
+  w43_row(P, n, h0 + tr, n_t, h_t);
+  if (q_ok && h_t >= 0 && h_t < P.H) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (w0 + 4 * tq + i < P.W) vmask |= 1 << i;
@@ -278,24 +297,30 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
       const int rl = lane / P.NP, pc = lane - rl * P.NP;
       const int rr = ii * P.RPI + rl;
       if (p_on[pp] && rl < P.RPI && rr < P.WR) {
-        const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
+        int nn, gh;
+        w43_row(P, n, h0 - 1 + rr, nn, gh);
+        const int gw = w0 - 4 + 4 * pc;
+        const int fo0 = P.fold ? nn * (int)P.src0.ns : 0, fo1 = P.fold ? nn * (int)P.src1.ns : 0;
         int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
-        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && ws >= 0 && ws < P.src0.W && ws + 4 <= P.src0.ws) ? hs * P.src0.ws + ws : -1;
+        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && ws >= 0 && ws < P.src0.W && ws + 4 <= P.src0.ws) ? fo0 + hs * P.src0.ws + ws : -1;
         hs = gh - P.src1.oh;
         ws = gw - P.src1.ow;
-        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && ws >= 0 && ws < P.src1.W && ws + 4 <= P.src1.ws) ? hs * P.src1.ws + ws : -1;
+        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && ws >= 0 && ws < P.src1.W && ws + 4 <= P.src1.ws) ? fo1 + hs * P.src1.ws + ws : -1;
       }
     } else {
       p_on[pp] = wave8 + NWAVE * pp < P.NPV;
       const int pos = (wave8 + NWAVE * pp) * 64 + lane;
       const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
       if (rr < P.WR && cc < P.WC) {
-        const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
+        int nn, gh;
+        w43_row(P, n, h0 - 1 + rr, nn, gh);
+        const int gw = w0 - 1 + cc;
+        const int fo0 = P.fold ? nn * (int)P.src0.ns : 0, fo1 = P.fold ? nn * (int)P.src1.ns : 0;
         int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
-        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : -1;
+        xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? fo0 + hs * P.src0.ws + ws : -1;
         hs = gh - P.src1.oh;
         ws = gw - P.src1.ow;
-        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : -1;
+        xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? fo1 + hs * P.src1.ws + ws : -1;
       }
     }
   }
@@ -611,18 +636,19 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
   // per destination: element offset of the tile's first pixel inside a plane, and the mask of its pixels that are stored
   int off0 = 0, off1 = 0, sm0 = 0, sm1 = 0;
   {
-    const int h = h0 + tr, w = w0 + 4 * tq;
+    const int h = h_t, w = w0 + 4 * tq;
+    const int fo0 = P.fold ? n_t * (int)P.dst0.ns : 0, fo1 = P.fold ? n_t * (int)P.dst1.ns : 0;
     int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
-    if ((unsigned)hd < (unsigned)P.dst0.H) {
-      off0 = hd * P.dst0.ws + wd;
+    if (h >= 0 && (unsigned)hd < (unsigned)P.dst0.H) {
+      off0 = fo0 + hd * P.dst0.ws + wd;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0 |= 1 << i;
     }
     hd = h - P.dst1.oh;
     wd = w - P.dst1.ow;
-    if ((unsigned)hd < (unsigned)P.dst1.H) {
-      off1 = hd * P.dst1.ws + wd;
+    if (h >= 0 && (unsigned)hd < (unsigned)P.dst1.H) {
+      off1 = fo1 + hd * P.dst1.ws + wd;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1 |= 1 << i;
@@ -751,31 +777,58 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
 namespace {
 
 struct W43Plan {
-  int TH, TW, TWq, tiles_y, tiles_x, mblocks, WR, WC, WCp;
+  int TH, TW, TWq, tiles_y, tiles_x, mblocks, WR, WC, WCp, fold;
 };
 
-// TH x TW output tile of 64 Winograd tiles (TH*TW <= 256) whose padded halo window fits the 512 DMA positions.  Every
-// block does the work of 64 tiles whatever it covers, so: fewest blocks; among equals 32-wide rows, then the widest
-// (measured over TW = 4..64, profiles/bench_conv_forms.py with GSD_W43_TW: widths that are not a power of two lose more in
-// the kernel than their tighter fit saves).
-bool plan_w43(int H, int W, int M, W43Plan* best) {
+int halo_read_cycles(int TWq, int LP, int PS, int off);
+
+// TH x TW output tile of up to 64 Winograd tiles whose padded halo window fits the 512 DMA positions.  Every block does the
+// work of 64 tiles whatever it covers, so: fewest blocks; among equals 32-wide rows, then the widest.
+// Small images (levels 3-4 of the U-Net: 40 x 53, 20 x 26) fill such a tile badly (83 % / 68 %): for them the tile rows run
+// over the padded flat rows of the whole batch (`fold`, see w43_row) and the tile may be 7 or 14 Winograd tiles wide
+// (28 / 56 pixels: 53 -> 2 x 28, 26 -> 1 x 28), with the LDS row pitch chosen for the fewest bank conflicts of the halo reads.
+bool plan_w43(int N, int H, int W, int M, W43Plan* best) {
   long best_cost = -1;
   const int force_tw = gsd_env_int("GSD_W43_TW", 0);   // tuning
-  for (int tw = 4; tw <= 64; tw *= 2) {
-    if (force_tw && tw != force_tw) continue;
-    int th = 256 / tw;
-    const int wcp = round_up(tw + 2, 4);
-    while (th > 1 && (th + 2) * wcp > 512) --th;
-    if ((th + 2) * wcp > 512) continue;
-    if (th > H) th = H;
-    const int ty = ceil_div(H, th);
-    th = ceil_div(H, ty);
-    const long cost = (long)ty * ceil_div(W, tw) * 4 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      best->TH = th; best->TW = tw; best->TWq = tw / 4;
-      best->tiles_y = ty; best->tiles_x = ceil_div(W, tw);
-      best->WR = th + 2; best->WC = tw + 2; best->WCp = wcp;
+  const int fold_mode = gsd_env_int("GSD_W43_FOLD", -1);   // tuning: 0 never, 1 whenever possible, -1 when it saves > 4 % of the blocks
+  best->fold = 0;
+  long plain_blocks = -1;
+  for (int fold = 0; fold <= 1; ++fold) {
+    if (fold && (fold_mode == 0 || N <= 1 || (long)H * W > 8192)) continue;
+    static const int tws[9] = {32, 64, 16, 8, 4, 28, 56, 24, 48};
+    for (int k = 0; k < (fold ? 9 : 5); ++k) {
+      const int tw = tws[k];
+      if (force_tw && tw != force_tw) continue;
+      const int twq = tw / 4;
+      int th = 64 / twq;
+      int wcp = round_up(tw + 2, 4);
+      while (th > 1 && (th + 2) * wcp > 512) --th;
+      if ((th + 2) * wcp > 512) continue;
+      const int rows = fold ? N * (H + 1) : H;
+      if (th > rows) th = rows;
+      const int ty = ceil_div(rows, th);
+      if (!fold) th = ceil_div(H, ty);
+      const long blocks = (long)ty * ceil_div(W, tw) * (fold ? 1 : N);
+      if (!fold && (plain_blocks < 0 || blocks < plain_blocks)) plain_blocks = blocks;
+      if (fold && fold_mode < 0 && blocks * 104 > plain_blocks * 100) continue;
+      if ((twq & (twq - 1)) != 0 || fold) {   // odd widths: pick the LDS row pitch with the fewest bank conflicts
+        int bc = -1;
+        for (int c = round_up(tw + 2, 4); c <= round_up(tw + 2, 4) + 12 && (th + 2) * c <= 512; c += 4) {
+          const int cyc = halo_read_cycles(twq, c, round_up((th + 2) * c, 4) + 4, 0);
+          if (bc < 0 || cyc < bc) {
+            bc = cyc;
+            wcp = c;
+          }
+        }
+      }
+      const long cost = blocks * 8 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        best->fold = fold;
+        best->TH = th; best->TW = tw; best->TWq = twq;
+        best->tiles_y = ty; best->tiles_x = ceil_div(W, tw);
+        best->WR = th + 2; best->WC = tw + 2; best->WCp = wcp;
+      }
     }
   }
   best->mblocks = ceil_div(M, W43_BM);
@@ -856,15 +909,15 @@ int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm,
 extern "C" int gsd_conv3x3_w43_partial_rows(int N, int H, int W, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   W43Plan p;
-  if (!plan_w43(H, W, Cout, &p)) return 0;
-  return N * p.tiles_y * p.tiles_x * 4;
+  if (!plan_w43(N, H, W, Cout, &p)) return 0;
+  return (p.fold ? 1 : N) * p.tiles_y * p.tiles_x * 4;
 }
 
 // MFMA instructions of one launch (all blocks, padding included), for gsd_conv3x3_algo
 extern "C" int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int Cout) {
   W43Plan p;
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w43(H, W, Cout, &p)) return 0;
-  return (int64_t)N * p.tiles_y * p.tiles_x * p.mblocks * ceil_div(Cin, 4) * (4 * 72);
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w43(N, H, W, Cout, &p)) return 0;
+  return (int64_t)(p.fold ? 1 : N) * p.tiles_y * p.tiles_x * p.mblocks * ceil_div(Cin, 4) * (4 * 72);
 }
 
 static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
@@ -892,7 +945,13 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: destination segments hold %d channels, Cout=%d", csum, Cout);
 
   W43Plan pl;
-  GSD_REQUIRE(plan_w43(H, W, Cout, &pl), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: no tile shape");
+  GSD_REQUIRE(plan_w43(N, H, W, Cout, &pl), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: no tile shape");
+  if (pl.fold) {   // folded rows carry the image offset in 32-bit lane offsets
+    for (int i = 0; i < nsrc; ++i)
+      GSD_REQUIRE((int64_t)N * src[i].n_stride < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: batch too large for row folding");
+    for (int i = 0; i < ndst; ++i)
+      GSD_REQUIRE((int64_t)N * dst[i].n_stride < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: batch too large for row folding");
+  }
   W43Params P;
   P.src0 = to_srcd(src[0]);
   P.src1 = nsrc > 1 ? to_srcd(src[1]) : null_srcd();
@@ -945,8 +1004,10 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
       }
     }
   }
-  const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
+  P.fold = pl.fold;
+  const long grid = (long)(pl.fold ? 1 : N) * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
+  GSD_REQUIRE(!pl.fold || nl == 0, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: the loader-wave form does not fold rows (GSD_W43_FOLD=0)");
   const size_t lds = (size_t)(2 * (WM * W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
   return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast);
 }

@@ -576,3 +576,60 @@ def test_conv3x3_w43_pitched_source_and_destination(gsd, n, ci, co, h, w):
                                       gsd.dst_array([gsd.make_dst(y1)]), 1, None, n, h, w, gsd.stream_ptr()))
     assert torch.equal(y0, y1)
     assert bool((ybase[..., w:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(3, 16, 24, 9, 11), (5, 64, 64, 20, 26), (4, 32, 70, 13, 53), (2, 128, 64, 40, 53)])
+def test_conv3x3_w43_row_folding(gsd, monkeypatch, n, ci, co, h, w):
+    """Row folding (small images: the tile rows run over the padded flat rows of the whole batch, a block may cover the tail of
+    one image and the head of the next; tiles 28 / 56 pixels wide): every output pixel is the same sum in the same order,
+    so the results are bit-identical to the unfolded launch -- plain forward with deferred BatchNorm, two source segments
+    with an F.pad offset, two cropped destinations, and the fused BatchNorm-backward dX epilogue (partial sums to rounding)."""
+    rng = np.random.default_rng(n * 100 + w)
+    raw, g_, b_, mean, invstd, scale, shift, a = _bn_setup(rng, n, ci, h, w)
+    x, scd, shd = dev(raw), dev(scale), dev(shift)
+    wt_ = dev(rnd(rng, co, ci, 3, 3, scale=0.2))
+    wl = layout(gsd, 4, wt_, co, ci)
+    c1 = max(4, co // 3) // 4 * 4
+    up = dev(rnd(rng, n, c1, h - 2, w - 3))
+    wt2 = dev(rnd(rng, co, ci + c1, 3, 3, scale=0.2))
+    wl2 = layout(gsd, 4, wt2, co, ci + c1)
+    wl2d = layout(gsd, 5, wt2, co, ci + c1)
+    dy = dev(rnd(rng, n, co, h, w))
+    wld = layout(gsd, 5, wt_, co, ci)
+    vecs = [dev(v) for v in (scale, shift, mean, invstd)]
+    res = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("GSD_W43_FOLD", fold)
+        rows = gsd.lib.gsd_conv3x3_w43_partial_rows(n, h, w, co)
+        mpad = (co + 63) // 64 * 64
+        part = torch.zeros(rows * 2 * mpad, device="cuda")
+        y = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(x, scd, shd, relu=True)]), 1, wl.data_ptr(), ci, co,
+                                          gsd.dst_array([gsd.make_dst(y)]), 1, part.data_ptr(), n, h, w, gsd.stream_ptr()))
+        sums = torch.zeros(65 * 2 * co, device="cuda", dtype=torch.float64)
+        gsd.check(gsd.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mpad, co, sums.data_ptr(), gsd.stream_ptr()))
+        y2 = torch.full((n, co, h, w), float("nan"), device="cuda")
+        src2 = gsd.src_array([gsd.make_src(x, scd, shd, relu=True), gsd.make_src(up, off=(1, 1))])
+        gsd.check(gsd.lib.gsd_conv3x3_w43(src2, 2, wl2.data_ptr(), ci + c1, co, gsd.dst_array([gsd.make_dst(y2)]), 1, None, n, h, w,
+                                          gsd.stream_ptr()))
+        g0 = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        g1 = torch.full((n, c1, h - 2, w - 3), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(dy)]), 1, wl2d.data_ptr(), co, ci + c1,
+                                          gsd.dst_array([gsd.make_dst(g0), gsd.make_dst(g1, off=(1, 1))]), 2, None, n, h, w,
+                                          gsd.stream_ptr()))
+        rows_d = gsd.lib.gsd_conv3x3_w43_partial_rows(n, h, w, ci)
+        mpad_d = (ci + 63) // 64 * 64
+        part_d = torch.zeros(rows_d * 2 * mpad_d, device="cuda")
+        dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        s, d = gsd.make_src(dy), gsd.make_dst(dz)
+        gsd.check(gsd.lib.gsd_conv3x3_w43_dgrad_bnrelu(C.byref(s), wld.data_ptr(), co, ci, C.byref(d), x.data_ptr(),
+                                                       *[v.data_ptr() for v in vecs], part_d.data_ptr(), n, h, w, gsd.stream_ptr()))
+        sums_d = torch.zeros(65 * 2 * ci, device="cuda", dtype=torch.float64)
+        gsd.check(gsd.lib.gsd_bn_reduce_partials(part_d.data_ptr(), rows_d, mpad_d, ci, sums_d.data_ptr(), gsd.stream_ptr()))
+        res[fold] = (y, y2, g0, g1, dz, sums[:2 * co].clone(), sums_d[:2 * ci].clone(), rows)
+    for k in range(5):
+        assert bool(torch.isfinite(res["1"][k]).all()), k
+        assert torch.equal(res["0"][k], res["1"][k]), k
+    for k in (5, 6):
+        np.testing.assert_allclose(res["1"][k].cpu().numpy(), res["0"][k].cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert res["1"][7] <= res["0"][7]     # never more blocks (fewer at batch sizes that leave tail rows)
