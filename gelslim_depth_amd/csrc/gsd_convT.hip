@@ -222,6 +222,187 @@ __global__ __launch_bounds__(256) void convT_kernel(const ConvTParams P) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// FWD on the LDS-DMA template of the conv3x3 kernels (the register-staged form above ran at 48 % of the fp32 MFMA peak and
+// stays for DGRAD): block tile 128 (m = co*4+kh*2+kw) x 128 pixels, K walked in chunks of 32 input channels, both operand
+// tiles straight from L2/HBM into a double-buffered LDS image by global_load_lds -- weights as 16 one-KiB pieces of a
+// [chunk][32][128] image whose columns are permuted so that a lane's four A operands are one ds_read_b128
+// (gsd_weight_layout mode 6), activations as rows of 128 consecutive pixels of a channel plane (16-byte pieces when the
+// planes are 16-byte aligned and H*W % 4 == 0 -- true at every level of the U-Net -- else dwords).  MFMA column l16 of
+// n-tile t is pixel 4*l16 + t of the wave's 64: the four B operands of a lane are one ds_read_b128 as well, and the
+// producer's deferred BatchNorm+ReLU is applied between the read and the MFMA.  Two blocks per CU.
+struct ConvTFwdParams {
+  SrcD src;
+  DstD dst;
+  const float* wt;    // mode 6: [mblock][Kpad][128]
+  const float* bias;
+  int K, Kpad, M, nchunks, mblocks;
+  int N, H, W, tiles_flat;
+};
+
+__device__ __attribute__((aligned(16))) const float gsd_zero16_ct[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <bool X4>
+__global__ __launch_bounds__(256, 2) void convT_fwd_dma_kernel(const ConvTFwdParams P) {
+  constexpr int BM = 128, BN = 128, KC = 32, MT = 4, NT = 4;
+  constexpr int WIMG = KC * BM, XIMG = KC * BN, BUF = WIMG + XIMG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);   // the m-blocks of a pixel tile share the activation tile: one XCD's L2
+  const int mb = lid % P.mblocks;
+  const int pt = lid / P.mblocks;
+  const int m0 = mb * BM;
+  // pixel tiles run over the flattened pixels of the WHOLE batch (a 20 x 26 image is 4.06 tiles of 128): q = n * H*W + p
+  const long long q0 = (long long)pt * BN;
+  const int HW = P.H * P.W;
+  const long long QT = (long long)P.N * HW;
+
+  // deferred BatchNorm coefficients of every input channel (k), padded with the identity
+  float* sAff = smem + 2 * BUF;
+  for (int c = tid; c < P.Kpad; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (c < P.K && P.src.scale != nullptr) {
+      sc = P.src.scale[c];
+      sh = P.src.shift[c];
+    }
+    sAff[c] = sc;
+    sAff[P.Kpad + c] = sh;
+  }
+  const float lo = P.src.relu ? 0.f : -__builtin_inff();
+
+  // ---- DMA lane geometry ---------------------------------------------------------------------------------------------------
+  // weights: the chunk image is 16 KiB = 16 pieces of 1 KiB; wave w moves pieces w, w+4, w+8, w+12
+  const float* const wsrc = P.wt + (size_t)mb * P.Kpad * BM + lane * 4;
+  // activations: X4: a piece = 2 channel rows (lane>>5) x 32 sixteen-byte pieces (lane&31); dword: one row half (64 px)
+  const int xrow = X4 ? (lane >> 5) : 0;
+  const int xpx = X4 ? (lane & 31) * 4 : lane;
+  // this lane's pixel(s) of the tile: image and offset inside a channel plane (X4: H*W % 4 == 0, a piece never straddles images)
+  long long xo[X4 ? 1 : 2];
+  bool xok[X4 ? 1 : 2];
+#pragma unroll
+  for (int i = 0; i < (X4 ? 1 : 2); ++i) {
+    const long long q = q0 + xpx + 64 * i;
+    xok[i] = q < QT;
+    const int nn = xok[i] ? (int)(q / HW) : 0;
+    xo[i] = (long long)nn * P.src.ns + (xok[i] ? (q - (long long)nn * HW) : 0);
+  }
+  auto fill = [&](int chunk, int buf) {
+    float* Wb = smem + buf * BUF;
+    float* Xb = Wb + WIMG;
+    const float* wc = wsrc + (size_t)chunk * WIMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(wc + (wave + 4 * i) * 256, Wb + (wave + 4 * i) * 256, 16, 0, 0);
+    const int k0 = chunk * KC;
+    if constexpr (X4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 2 * (wave + 4 * i) + xrow;   // channel row of the chunk
+        const float* g = (xok[0] && k0 + r < P.K) ? P.src.p + xo[0] + (long long)(k0 + r) * P.src.cs : &gsd_zero16_ct[0];
+        __builtin_amdgcn_global_load_lds(g, Xb + (wave + 4 * i) * 256, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int u = wave + 4 * i;              // 64 half rows of 64 pixels
+        const int r = u >> 1, hf = u & 1;
+        const float* g = (xok[hf] && k0 + r < P.K) ? P.src.p + xo[hf] + (long long)(k0 + r) * P.src.cs : &gsd_zero16_ct[0];
+        __builtin_amdgcn_global_load_lds(g, Xb + u * 64, 4, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_off = j * BM + wm * 64 + l16 * 4;
+  const int b_off = WIMG + j * BN + wn * 64 + l16 * 4;
+  fill(0, 0);
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    gsd_dma_barrier();   // this chunk has landed; everyone has left the other image
+    if (chunk + 1 < P.nchunks) fill(chunk + 1, cur ^ 1);
+    const float* Sb = smem + cur * BUF;
+    const float* aff = sAff + chunk * KC + j;
+    f32x4 av[2], bv[2];
+    float sc[2], sh[2];
+    av[0] = *reinterpret_cast<const f32x4*>(&Sb[a_off]);
+    bv[0] = *reinterpret_cast<const f32x4*>(&Sb[b_off]);
+    sc[0] = aff[0];
+    sh[0] = aff[P.Kpad];
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {
+      const int c = s & 1;
+      if (s + 1 < KC / 4) {   // the next k-step's operands fly during this one's MFMAs
+        av[c ^ 1] = *reinterpret_cast<const f32x4*>(&Sb[a_off + (s + 1) * 4 * BM]);
+        bv[c ^ 1] = *reinterpret_cast<const f32x4*>(&Sb[b_off + (s + 1) * 4 * BN]);
+        sc[c ^ 1] = aff[(s + 1) * 4];
+        sh[c ^ 1] = aff[P.Kpad + (s + 1) * 4];
+      }
+      float b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = fmaxf(fmaf(bv[c][t], sc[c], sh[c]), lo);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(av[c][m], b[t], acc[m][t]);
+    }
+  }
+
+  // ---- epilogue: an accumulator quad is the 2x2 output patch of (co, pixel); a lane owns 4 consecutive pixels, i.e. 8
+  // consecutive floats of two output rows when they lie in one image row: 16-byte stores then, 8-byte stores otherwise
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const DstD& D = P.dst;
+  const long long qa = q0 + wn * 64 + l16 * 4;
+  if (qa < QT) {
+    const int na = (int)(qa / HW);
+    const int pa = (int)(qa - (long long)na * HW);
+    const int ha = pa / P.W, wa = pa - ha * P.W;
+    const bool one_row = wa + 3 < P.W;   // (also inside the image: H*W % 4 need not hold here)
+    if (one_row && qa + 3 < QT) {
+      float* const o = D.p + (long long)na * D.ns + (long long)(2 * ha) * D.ws + 2 * wa;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = (m0 + wm * 64 + m * 16 + j * 4) >> 2;
+        if (co < D.C) {
+          const float bz = P.bias != nullptr ? P.bias[co] : 0.f;
+          float* const oc = o + (long long)co * D.cs;
+          *reinterpret_cast<f32x4u*>(oc) = f32x4{acc[m][0][0] + bz, acc[m][0][1] + bz, acc[m][1][0] + bz, acc[m][1][1] + bz};
+          *reinterpret_cast<f32x4u*>(oc + 4) = f32x4{acc[m][2][0] + bz, acc[m][2][1] + bz, acc[m][3][0] + bz, acc[m][3][1] + bz};
+          *reinterpret_cast<f32x4u*>(oc + D.ws) = f32x4{acc[m][0][2] + bz, acc[m][0][3] + bz, acc[m][1][2] + bz, acc[m][1][3] + bz};
+          *reinterpret_cast<f32x4u*>(oc + D.ws + 4) = f32x4{acc[m][2][2] + bz, acc[m][2][3] + bz, acc[m][3][2] + bz, acc[m][3][3] + bz};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const long long q = qa + t;
+        if (q >= QT) continue;
+        const int nn = (int)(q / HW);
+        const int p = (int)(q - (long long)nn * HW);
+        const int h = p / P.W, w = p - h * P.W;
+        float* const o = D.p + (long long)nn * D.ns + (long long)(2 * h) * D.ws + 2 * w;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int co = (m0 + wm * 64 + m * 16 + j * 4) >> 2;
+          if (co < D.C) {
+            const float bz = P.bias != nullptr ? P.bias[co] : 0.f;
+            float* const oc = o + (long long)co * D.cs;
+            *reinterpret_cast<float2*>(oc) = make_float2(acc[m][t][0] + bz, acc[m][t][1] + bz);
+            *reinterpret_cast<float2*>(oc + D.ws) = make_float2(acc[m][t][2] + bz, acc[m][t][3] + bz);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, int WM, int WN>
 int launch(const ConvTParams& P, int grid, size_t lds, hipStream_t st, const char* what) {
   hipLaunchKernelGGL((convT_kernel<MODE, WM, WN>), dim3(grid), dim3(256), lds, st, P);
@@ -258,16 +439,38 @@ extern "C" int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bi
               GSD_ERR_BAD_ARG, "gsd_convT2x2: dst must be (Cout,2H,2W)");
   GSD_REQUIRE(((uintptr_t)dst->ptr & 7) == 0 && (dst->c_stride & 1) == 0 && (dst->n_stride & 1) == 0,
               GSD_ERR_UNSUPPORTED, "gsd_convT2x2: dst must be 8-byte aligned with even strides");
-  ConvTParams P;
+  GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_convT2x2: the weight image must be 16-byte aligned");
+  ConvTFwdParams P;
   P.src = to_srcd(*src);
   P.dst = to_dstd(*dst);
   P.wt = wt;
   P.bias = bias;
   P.K = Cin;
+  P.Kpad = round_up(Cin, 32);
   P.M = Cout * 4;
-  P.nchunks = ceil_div(Cin, 16);
+  P.nchunks = P.Kpad / 32;
+  P.mblocks = ceil_div(P.M, 128);
   P.N = N; P.H = H; P.W = W;
-  return run<CT_FWD>(P, (hipStream_t)stream, "gsd_convT2x2");
+  P.tiles_flat = (int)ceil_div64((int64_t)N * H * W, 128);   // pixel tiles over the whole batch
+  const long grid = (long)P.tiles_flat * P.mblocks;
+  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_convT2x2: grid too large");
+  const size_t lds = (size_t)(2 * (32 * 128 + 32 * 128) + 2 * P.Kpad) * sizeof(float);   // 64 KiB + coefficients: two blocks per CU
+  GSD_REQUIRE(lds <= 80 * 1024, GSD_ERR_UNSUPPORTED, "gsd_convT2x2: Cin %d too large for the coefficient table", Cin);
+  // 16-byte activation pieces: channel planes start 16-byte aligned and hold a multiple of 4 pixels
+  const bool x4 = gsd_env_int("GSD_CONVT_X4", 1) != 0 && ((uintptr_t)src->ptr & 15) == 0 && src->c_stride % 4 == 0 &&
+                  src->n_stride % 4 == 0 && (H * W) % 4 == 0;
+  static gsd_attr_once big_lds[2];   // per-device caches of an idempotent launch attribute (gsd_common.h)
+  const void* fn = x4 ? reinterpret_cast<const void*>(&convT_fwd_dma_kernel<true>) : reinterpret_cast<const void*>(&convT_fwd_dma_kernel<false>);
+  if (hipError_t e = gsd_allow_big_lds(big_lds[x4 ? 1 : 0], fn); e != hipSuccess) {
+    gsd_set_error("gsd_convT2x2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
+  }
+  if (x4)
+    hipLaunchKernelGGL(convT_fwd_dma_kernel<true>, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
+  else
+    hipLaunchKernelGGL(convT_fwd_dma_kernel<false>, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, P);
+  GSD_LAUNCH_CHECK("gsd_convT2x2");
+  return GSD_OK;
 }
 
 extern "C" int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, int N,

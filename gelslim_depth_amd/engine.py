@@ -178,7 +178,7 @@ class UNetEngine:
             if train and up.dout is None:
                 up.dout = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
             if up.wt_f is None or up.wt_f.device != dev:
-                up.wt_f = torch.empty((lib.gsd_weight_layout_size(2, up.cout, up.cin),), **f32)
+                up.wt_f = torch.empty((lib.gsd_weight_layout_size(6, up.cout, up.cin),), **f32)
                 up.wt_d = torch.empty((lib.gsd_weight_layout_size(3, up.cout, up.cin),), **f32)
             if train:
                 max_ws = max(max_ws, lib.gsd_convT2x2_wgrad_workspace(n, hs[li], ws[li], up.cin, up.cout))
@@ -287,7 +287,7 @@ class UNetEngine:
         for j in range(self.L):
             up = self.ups[j]
             lvl = self.L - 1 - j
-            check(lib.gsd_weight_layout(2, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_layout")
+            check(lib.gsd_weight_layout(6, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_layout")
             s = self._act_src(cur)
             d = L.make_dst(up.out)
             check(lib.gsd_convT2x2(C.byref(s), up.wt_f.data_ptr(), P[up.bname].data_ptr(), up.cin, up.cout, C.byref(d), n,

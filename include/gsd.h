@@ -99,6 +99,7 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * mode 3: convT   dgrad     W[Ci][Co][2][2]  -> k = co*4+kh*2+kw,     m = ci
  * mode 4: conv3x3 forward, Winograd F(4,3) rows: k = ci*18+r*6+f, m = co   (see gsd_conv3x3_w43)
  * mode 5: conv3x3 dgrad,   Winograd F(4,3) rows: k = co*18+r*6+f (flipped kernel), m = ci
+ * mode 6: convT   forward, LDS-DMA kernel: k = ci (rows padded to 32), m = co*4+kh*2+kw in 128-column blocks
  * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM] with BM = 64 (M <= 64) or 128, columns
  * permuted inside each 64-group (slot l*4+t = column t*16+l), so one K-chunk of one m-block is a contiguous LDS
  * image whose A operands are aligned float4s; modes 2/3 are [k row][M rounded up to 64].
@@ -141,7 +142,7 @@ int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, i
                                  const float* invstd, float* partials, int N, int H, int W, void* stream);
 
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
- * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 2. */
+ * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 6. */
 int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin, int Cout,
                  const gsd_dst* dst, int N, int H, int W, void* stream);
 /* dX of the above: src = gradient w.r.t. the (2h,2w) output (plain), dst (h,w). weights: mode 3. */

@@ -198,7 +198,7 @@ def test_convT_fwd_bwd(gsd, n, ci, h, w):
     y = torch.full((n, co, 2 * h, 2 * w), float("nan"), device="cuda")
     s = gsd.make_src(rawd, scd, shd, relu=True)
     d = gsd.make_dst(y)
-    gsd.check(gsd.lib.gsd_convT2x2(C.byref(s), layout(gsd, 2, wd, co, ci).data_ptr(), bd.data_ptr(), ci, co, C.byref(d), n, h,
+    gsd.check(gsd.lib.gsd_convT2x2(C.byref(s), layout(gsd, 6, wd, co, ci).data_ptr(), bd.data_ptr(), ci, co, C.byref(d), n, h,
                                    w, gsd.stream_ptr()))
     assert rel_l1(y.cpu().numpy(), ref) < TOL
     dy = rnd(rng, n, co, 2 * h, 2 * w)
