@@ -228,10 +228,10 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 //
 // NL > 0: producer / consumer form -- NL extra waves per block issue all the DMA (w43_loader above); WM must be 1.
 //
-// FAST: the channel bookkeeping of the fills is done once per CHUNK in scalar registers instead of once per slot with a
-// chain of branches (which segment, how many channels it has left, which sentinel): possible when a chunk of 4 channels
-// never straddles the two source segments (src0.C % 4 == 0, always true in the U-Net).  Stamps (profiles/stamp_conv.py)
-// put the per-slot form at ~1200 of the ~6400 cycles a wave spends per chunk.
+// FAST: straight halo fills, no per-slot bookkeeping (which segment, how many channels it has left, which sentinel: a
+// chain of scalar branches per slot in the general form): possible when a chunk of 4 channels never straddles the two
+// source segments and Cin % 4 == 0 (always true in the U-Net).  Stamps (profiles/stamp_conv.py) put the per-slot form at
+// ~1200 of the cycles a wave spends per chunk; measured -7 % kernel time over the U-Net's layer set.
 template <int WM, bool X4, int NL, bool FAST>
 __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1)) void conv3x3_w43_kernel(const W43Params P) {
   static_assert(NL == 0 || WM == 1, "loader waves serve one 64-channel weight image");
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) d_xo[pp] = xo0[pp];
 
-  // FAST: per-chunk state of the halo fills (wave-uniform except f_xo / f_xl)
-  bool f_plain = true;             // first segment, all four channels exist: masked lanes only, padding already in LDS
-  int f_nch = 4;
-  const float* f_b[4] = {nullptr, nullptr, nullptr, nullptr};   // plane of each channel of the chunk
-  const float* f_sent = d_sent;
+  // FAST ("straight fill"): no per-slot bookkeeping at all.  Every chunk lies inside one source segment (src0.C % 4 == 0,
+  // Cin % 4 == 0), so a halo slot is: the lanes that have a pixel move it, the plane pointer advances by one channel.  The
+  // switch to the second (concat) segment happens once per block, between two chunks: new plane pointer and lane offsets,
+  // and the padding positions of that segment are written into each LDS image the first time it is filled from it.
+  const int f_sw = P.src1.C > 0 ? P.src0.C / 4 : -1;   // first chunk of the second segment
   int f_xo[NPP];
   long long f_xl[NPP];
 #pragma unroll
@@ -369,56 +369,48 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
     f_xo[pp] = xo0[pp];
     f_xl[pp] = xo0[pp];
   }
-  auto begin_fill = [&](int chunk) {
-    const int c0 = chunk * 4;
-    const bool s1 = c0 >= P.src0.C && P.src1.C > 0;
-    const int cc0 = s1 ? c0 - P.src0.C : c0;
-    const int segC = s1 ? P.src1.C : P.src0.C;
-    const long long cs = s1 ? P.src1.cs : P.src0.cs;
-    const float* base = (s1 ? P.src1.p + (long long)n * P.src1.ns : P.src0.p + (long long)n * P.src0.ns) + (long long)cc0 * cs;
-    const int relu = s1 ? P.src1.relu : P.src0.relu;
-    f_nch = segC - cc0 < 4 ? (segC - cc0 > 0 ? segC - cc0 : 0) : 4;
-    f_plain = !s1 && f_nch == 4;
-    f_sent = X4 ? (relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) f_b[c] = base + (long long)(c < f_nch ? c : 0) * cs;
-    if (P.src1.C > 0) {   // (a single-segment launch keeps the lane offsets of segment 0)
+  auto begin_fill = [&](int chunk, int buf) {
+    if (f_sw < 0 || (chunk != f_sw && chunk != f_sw + 1)) return;
+    if (chunk == f_sw) {
+      d_base = P.src1.p + (long long)n * P.src1.ns;
+      d_cs = P.src1.cs;
 #pragma unroll
       for (int pp = 0; pp < NPP; ++pp) {
-        f_xo[pp] = s1 ? xo1[pp] : xo0[pp];
-        f_xl[pp] = f_xo[pp];
+        f_xo[pp] = xo1[pp];
+        f_xl[pp] = xo1[pp];
       }
     }
+    const float pad1 = P.src1.relu ? __builtin_nanf("") : 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+      if (p_on[pp] && f_xo[pp] == -1) {
+        if constexpr (X4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) smem[buf * BUF + WM * WTILE + u_ch[pp] * PS + u_lds[pp] + lane * 4 + e] = pad1;
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) smem[buf * BUF + WM * WTILE + ch * PS + (wave8 + NWAVE * pp) * 64 + lane] = pad1;
+        }
+      }
   };
   auto fast_halo = [&](int ch, float* Xb) {
-    const bool c_ok = ch < f_nch;
-    const float* const zeros = X4 ? &gsd_pad16_w43[0] : &gsd_pad_w43[0];
 #pragma unroll
     for (int pp = 0; pp < NPP; ++pp) {
       if constexpr (X4) {
-        if (!(p_on[pp] && u_ch[pp] == ch)) continue;
-      } else {
-        if (!p_on[pp]) continue;
-      }
-      float* dstp = X4 ? Xb + ch * PS + u_lds[pp] : Xb + ch * PS + (wave8 + NWAVE * pp) * 64;
-      if (f_plain) {
-        if (f_xo[pp] >= 0) {
-          const float* gp = f_b[ch] + f_xl[pp];
-          if constexpr (X4) {
-            __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
-          } else {
-            __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
-          }
-        }
-      } else if (f_xo[pp] != -2) {
-        const float* gp = (c_ok && f_xo[pp] >= 0) ? f_b[ch] + f_xl[pp] : (c_ok ? f_sent : zeros);
-        if constexpr (X4) {
+        if (p_on[pp] && u_ch[pp] == ch && f_xo[pp] >= 0) {
+          const float* gp = d_base + f_xl[pp];
+          float* dstp = Xb + ch * PS + u_lds[pp];
           __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
-        } else {
+        }
+      } else {
+        if (p_on[pp] && f_xo[pp] >= 0) {
+          const float* gp = d_base + f_xl[pp];
+          float* dstp = Xb + ch * PS + (wave8 + NWAVE * pp) * 64;
           __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
         }
       }
     }
+    d_base += d_cs;
   };
 
   // slots 0..NWI-1: the weight chunk (16 B per lane); slot NWI+ch: input channel ch of the chunk
@@ -449,16 +441,6 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
     } else if (slot < NWI + 4) {
       const int ch = slot - NWI;
       float* Xb = Wb + WM * WTILE;
-#ifdef W43_SIMPLE   // diagnostic build: one source segment, Cin % 4 == 0 -- the fill without any bookkeeping branches
-      if constexpr (!X4) {
-#pragma unroll
-        for (int pp = 0; pp < NPP; ++pp)
-          if (p_on[pp] && xo0[pp] >= 0)
-            __builtin_amdgcn_global_load_lds(d_base + xl0[pp], Xb + ch * PS + (wave8 + NWAVE * pp) * 64, 4, 0, 0);
-        d_base += d_cs;
-        return;
-      }
-#endif
       if (d_left == 0 && d_seg == 0) {
         d_seg = 1;
         d_left = P.src1.C;
@@ -568,7 +550,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
 
   const int a_lane = wm * WTILE + l16 * 4;
   if constexpr (NL == 0) {
-    if constexpr (FAST) begin_fill(0);
+    if constexpr (FAST) begin_fill(0, 0);
 #pragma unroll
     for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
   }
@@ -610,7 +592,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1))
             // one slot per k-step, behind its four MFMAs: a wave is held ~100 cycles by every LDS-DMA instruction it issues
             // (profiles/ubench/dma_issue.hip), about what its four MFMAs keep the matrix pipe busy
             if (more && s < 5) {
-              if (s == 0) begin_fill(chunk + 1);
+              if (s == 0) begin_fill(chunk + 1, cur ^ 1);
               dma_slot(2 * s, chunk + 1, cur ^ 1);
               dma_slot(2 * s + 1, chunk + 1, cur ^ 1);
             }
@@ -973,7 +955,8 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   const bool big = gsd_env_set("GSD_W43_BIG");
   // producer / consumer form (default): GSD_W43_NL loader waves per block (0: every wave issues its share of the DMA itself)
   const int nl = big ? 0 : gsd_env_int("GSD_W43_NL", 0);   // measured: a loader wave cannot keep up without a deeper ring
-  const bool fast = gsd_env_int("GSD_W43_FAST", 0) != 0 && (nsrc == 1 || src[0].C % 4 == 0);
+  // straight fills (no per-slot bookkeeping): every 4-channel chunk lies inside one source segment
+  const bool fast = gsd_env_int("GSD_W43_FAST", 1) != 0 && Cin % 4 == 0 && (nsrc == 1 || src[0].C % 4 == 0);
   GSD_REQUIRE(nl >= 0 && nl <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: GSD_W43_NL must be 0, 1 or 2");
   const int WM = (pl.mblocks % 2 == 0 && big) ? 2 : 1;
   P.mblocks = pl.mblocks / WM;

@@ -93,14 +93,17 @@ def test_conv3x3_plain(gsd, algo, n, ci, co, h, w):
     np.testing.assert_allclose(s[co:], (r64 * r64).sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("c0,c1,co", [(6, 5, 9), (8, 12, 20), (64, 32, 70)])
 @ALGOS
-def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo):
+def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo, c0, c1, co):
     """Consumer-side fusion: relu(bn(.)) on load, channel concat of two segments, F.pad offsets (unet.py:46-48);
-    producer-side: two destinations with the crop that is F.pad's backward."""
+    producer-side: two destinations with the crop that is F.pad's backward.  (6, 5): a 4-channel chunk straddles the
+    segments (general fills); (8, 12), (64, 32): every chunk lies in one segment -- the straight fills with the one
+    segment switch per block and the re-written padding positions."""
     from oracle import unet_numpy as on
     F = ConvForm(gsd, algo)
     rng = np.random.default_rng(7)
-    n, c0, c1, co, h, w = 2, 6, 5, 9, 9, 11
+    n, h, w = 2, 9, 11
     skip_raw = rnd(rng, n, c0, h, w)
     sc, sh = rng.uniform(0.5, 1.5, c0).astype(np.float32), rnd(rng, c0, scale=0.3)
     up = rnd(rng, n, c1, 6, 8)          # diffY=3, diffX=3 -> top=1,left=1
