@@ -233,7 +233,10 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // source segments and Cin % 4 == 0 (always true in the U-Net).  Stamps (profiles/stamp_conv.py) put the per-slot form at
 // ~1200 of the cycles a wave spends per chunk; measured -7 % kernel time over the U-Net's layer set.
 template <int WM, bool X4, int NL, bool FAST>
-__global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? 2 : 1)) void conv3x3_w43_kernel(const W43Params P) {
+#ifndef W43_MIN_WAVES   // diagnostic builds: waves per SIMD the register allocation must admit for the 4-wave form
+#define W43_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN_WAVES : 1)) void conv3x3_w43_kernel(const W43Params P) {
   static_assert(NL == 0 || WM == 1, "loader waves serve one 64-channel weight image");
   constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM + 64 * NL, NWAVE = 4 * WM;
   constexpr int NWI = (W4 + NT - 1) / NT;

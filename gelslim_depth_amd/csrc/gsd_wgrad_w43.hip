@@ -228,6 +228,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         if ((unsigned)(hsB + b_rr[p]) < (unsigned)P.a1.H && (unsigned)(wsB + b_cc[p]) < (unsigned)P.a1.W) vmB |= 1 << p;
     }
     const int nch = skipB ? 0 : BN / NW;
+    if (P.a1.C == 0 && inA && n0 + BN <= P.Ncols && !skipB) {
+      // straight fill (one activation segment, window inside it, all channels exist -- every interior stage of a plain layer):
+      // a scalar plane pointer that advances by NW channels, the lanes' fixed window offsets, nothing else
+      const float* cb = P.a0.p + (long long)n * P.a0.ns + (long long)(n0 + wave) * P.a0.cs + woA;
+      const long long cstep = (long long)NW * P.a0.cs;
+      float* Xd = Bb + wave * XS;
+#pragma unroll
+      for (int i = 0; i < BN / NW; ++i) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (p < npv) {
+            const float* gp = cb + oA[p];
+            float* dstp = Xd + p * 64;
+            __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
+          }
+        cb += cstep;
+        Xd += NW * XS;
+      }
+      return;
+    }
 #pragma unroll 2
     for (int i = 0; i < nch; ++i) {
       const int ch = wave + NW * i;

@@ -1,0 +1,48 @@
+"""Build profiles/traffic.json from three rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 0` (FETCH_SIZE; WRITE_SIZE;
+SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), as written by profiles/run_pmc.sh.  All template variants of the dominant
+kernel are pooled.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM).
+usage: python profiles/make_traffic.py <tag>     (reads gpurun_out/<tag>_{fetch,write,sq}_pmc.txt, profiles named r02_*)"""
+import json
+import re
+import sys
+
+tag = sys.argv[1]
+KERNEL = "conv3x3_w43_kernel"
+
+
+def pooled(path, counters):
+    tot = {c: 0.0 for c in counters}
+    n = 0
+    cur = None
+    for line in open(path):
+        m = re.match(r"^(\S.*) dispatches (\d+)$", line.rstrip())
+        if m:
+            cur = (m.group(1), int(m.group(2))) if KERNEL in m.group(1) else None
+            if cur:
+                n += cur[1]
+            continue
+        if cur:
+            m = re.match(r"^\s+(\S+)\s+total (\S+)", line)
+            if m and m.group(1) in tot:
+                tot[m.group(1)] += float(m.group(2))
+    return {c: v / max(n, 1) for c, v in tot.items()}, n
+
+
+fetch, n1 = pooled(f"gpurun_out/{tag}_fetch_pmc.txt", ["FETCH_SIZE"])
+write, n2 = pooled(f"gpurun_out/{tag}_write_pmc.txt", ["WRITE_SIZE"])
+sq, n3 = pooled(f"gpurun_out/{tag}_sq_pmc.txt", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"])
+cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                      # rocprofv3 sums the 8 XCDs
+busy = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0) if cycles else None   # 1024 SIMDs
+out = {
+    "kernel": KERNEL,
+    "workload": f"bench.py --steps 1 --warmup 0 (batch 32), {n1} dispatches averaged, all template variants pooled",
+    "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"],
+    "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"],
+    "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM)",
+    "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0,
+    "mfma_busy": busy,
+    "cycles_per_launch": cycles,
+    "sources": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt", f"profiles/{tag}_pmc_sq.txt"],
+}
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
