@@ -591,9 +591,31 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][f] = mfma16(av[cs][m], v[f], acc[m][f]);
         if constexpr (NL == 0) {
-          if constexpr (FAST) {
-            // one slot per k-step, behind its four MFMAs: a wave is held ~100 cycles by every LDS-DMA instruction it issues
-            // (profiles/ubench/dma_issue.hip), about what its four MFMAs keep the matrix pipe busy
+          if constexpr (FAST && WM == 1) {
+            // weights first, in ONE k-step: a wave's four pieces are adjacent (4 KiB), so they share one LDS base (M0) and differ
+            // in the instruction's immediate offset, which moves the global and the LDS address alike -- a changed M0 between
+            // two LDS-DMA instructions costs the wave ~45 cycles at two blocks per CU (profiles/ubench/dma_m0.hip); then the halo
+            if (more && s < 3) {
+              if (s == 0) {
+                begin_fill(chunk + 1, cur ^ 1);
+                float* Wn = smem + (cur ^ 1) * BUF;
+                const float* wg = wsrc0 + (size_t)(chunk + 1) * WTILE + wave8 * 1024 + lane * 4;
+                float* wl = Wn + wave8 * 1024;
+                __builtin_amdgcn_global_load_lds(wg, wl, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(wg, wl, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(wg, wl, 16, 2048, 0);
+                __builtin_amdgcn_global_load_lds(wg, wl, 16, 3072, 0);
+                if (wave8 >= 2) {   // pieces 16, 17 of the 18
+                  const float* wg2 = wsrc0 + (size_t)(chunk + 1) * WTILE + (14 + wave8) * 256 + lane * 4;
+                  float* wl2 = Wn + (14 + wave8) * 256;
+                  __builtin_amdgcn_global_load_lds(wg2, wl2, 16, 0, 0);
+                }
+              } else {
+                dma_slot(NWI + 2 * s - 2, chunk + 1, cur ^ 1);
+                dma_slot(NWI + 2 * s - 1, chunk + 1, cur ^ 1);
+              }
+            }
+          } else if constexpr (FAST) {
             if (more && s < 5) {
               if (s == 0) begin_fill(chunk + 1, cur ^ 1);
               dma_slot(2 * s, chunk + 1, cur ^ 1);
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 4) W43_STAMP(2)   // the k-steps that carry the next chunk's DMA issue
+        if (s == ((FAST && WM == 1) ? 2 : 4)) W43_STAMP(2)   // the k-steps that carry the next chunk's DMA issue
       }
     }
     W43_STAMP(3)     // the other thirteen k-steps (52 MFMAs)

@@ -137,6 +137,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     }
   }
 
+  // The activation channels [n0, n0 + BN) of a block almost always lie in ONE source segment (always in the U-Net: the concat
+  // boundary is a multiple of 64).  Then everything about the window fills that depends on the segment is a block constant:
+  // copy the segment's descriptor into scalars once and keep one set of lane offsets.
+  const bool b_seg1 = P.a1.C > 0 && n0 >= P.a0.C;
+  const bool b_one = P.a1.C == 0 || b_seg1 || n0 + BN <= P.a0.C;
+  const float* const S_p = b_seg1 ? P.a1.p : P.a0.p;
+  const long long S_ns = b_seg1 ? P.a1.ns : P.a0.ns, S_cs = b_seg1 ? P.a1.cs : P.a0.cs;
+  const int S_H = b_seg1 ? P.a1.H : P.a0.H, S_W = b_seg1 ? P.a1.W : P.a0.W, S_ws = b_seg1 ? P.a1.ws : P.a0.ws;
+  const int S_oh = b_seg1 ? P.a1.oh : P.a0.oh, S_ow = b_seg1 ? P.a1.ow : P.a0.ow;
+  const int S_c0 = n0 - (b_seg1 ? P.a0.C : 0) + wave;                         // this wave's first channel inside the segment
+  const int S_left = (b_seg1 ? P.a1.C : P.a0.C) - S_c0;                        // channel i of the wave exists iff NW * i < S_left
+  const float* const S_sent = (b_seg1 ? P.a1.relu : P.a0.relu) ? &gsd_pad_wg43[1] : &gsd_pad_wg43[0];
+  int oS[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) oS[p] = b_rr[p] * S_ws + b_cc[p];
+
   // Address arithmetic is kept out of the per-instruction path (the kernel is VALU-bound next to 144 MFMAs per stage): per
   // stage one scalar window origin per segment, per lane the constants above; a stage whose window lies inside the
   // segment ("interior", the common case) needs no per-lane validity at all, a border stage computes it once per segment.
@@ -211,6 +227,50 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       }
     }
     // ---- B: activation windows ----
+    if (b_one && !skipB) {
+      // one segment for the whole block: a scalar plane pointer that advances by NW channels + the lanes' fixed window offsets;
+      // interior stages need nothing else, border stages one validity bit per window position
+      const int hs = h0 - 1 - S_oh, ws = w0 - 1 - S_ow;
+      const bool in = hs >= 0 && hs + P.WR <= S_H && ws >= 0 && ws + P.WC <= S_W;
+      const float* cb = S_p + (long long)n * S_ns + (long long)S_c0 * S_cs + ((long long)hs * S_ws + ws);
+      const long long cstep = (long long)NW * S_cs;
+      float* Xd = Bb + wave * XS;
+      if (in && NW * (BN / NW - 1) < S_left) {
+#pragma unroll
+        for (int i = 0; i < BN / NW; ++i) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < npv) {
+              const float* gp = cb + oS[p];
+              float* dstp = Xd + p * 64;
+              __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
+            }
+          cb += cstep;
+          Xd += NW * XS;
+        }
+      } else {
+        int vm = 0;   // bit p = window position p*64+lane exists in the segment
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if ((unsigned)(hs + b_rr[p]) < (unsigned)S_H && (unsigned)(ws + b_cc[p]) < (unsigned)S_W) vm |= 1 << p;
+#pragma unroll
+        for (int i = 0; i < BN / NW; ++i) {
+          const bool c_ok = NW * i < S_left;
+          const float* const sent = c_ok ? S_sent : &gsd_pad_wg43[0];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < npv) {
+              const float* gp = (c_ok && (vm >> p & 1)) ? cb + oS[p] : sent;
+              float* dstp = Xd + p * 64;
+              __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
+            }
+          cb += cstep;
+          Xd += NW * XS;
+        }
+      }
+      return;
+    }
+    // (a block whose channels straddle the two segments: the general form)
     // (named scalars, not arrays: an array indexed by the segment lands in scratch memory, with a vmcnt(0) per access)
     const int hsA = h0 - 1 - P.a0.oh, wsA = w0 - 1 - P.a0.ow, hsB = h0 - 1 - P.a1.oh, wsB = w0 - 1 - P.a1.ow;
     const int woA = hsA * P.a0.ws + wsA, woB = hsB * P.a1.ws + wsB;
@@ -228,26 +288,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         if ((unsigned)(hsB + b_rr[p]) < (unsigned)P.a1.H && (unsigned)(wsB + b_cc[p]) < (unsigned)P.a1.W) vmB |= 1 << p;
     }
     const int nch = skipB ? 0 : BN / NW;
-    if (P.a1.C == 0 && inA && n0 + BN <= P.Ncols && !skipB) {
-      // straight fill (one activation segment, window inside it, all channels exist -- every interior stage of a plain layer):
-      // a scalar plane pointer that advances by NW channels, the lanes' fixed window offsets, nothing else
-      const float* cb = P.a0.p + (long long)n * P.a0.ns + (long long)(n0 + wave) * P.a0.cs + woA;
-      const long long cstep = (long long)NW * P.a0.cs;
-      float* Xd = Bb + wave * XS;
-#pragma unroll
-      for (int i = 0; i < BN / NW; ++i) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          if (p < npv) {
-            const float* gp = cb + oA[p];
-            float* dstp = Xd + p * 64;
-            __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
-          }
-        cb += cstep;
-        Xd += NW * XS;
-      }
-      return;
-    }
 #pragma unroll 2
     for (int i = 0; i < nch; ++i) {
       const int ch = wave + NW * i;

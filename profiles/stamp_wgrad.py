@@ -17,7 +17,8 @@ raw.gsd_wg43_set_stamp_buffer.argtypes = [C.c_void_p]
 for ci, co, h, w in shapes:
     x = torch.randn(B, ci, h, w, device="cuda")
     sc, sh = torch.rand(ci, device="cuda") + 0.5, torch.randn(ci, device="cuda") * 0.1
-    dy = torch.randn(B, co, h, w, device="cuda")
+    dy = L.pitched_empty((B, co, h, w), "cuda")     # what the engine feeds the kernel: rows 16-byte aligned
+    dy.copy_(torch.randn(B, co, h, w, device="cuda"))
     dw = torch.empty(co, ci, 3, 3, device="cuda")
     need = lib.gsd_conv3x3_wgrad_workspace(B, h, w, ci, co)
     ws = torch.empty(need, device="cuda")
