@@ -62,6 +62,19 @@ constexpr int WG_DS = 68;      // dy row stride in LDS, dword gathers: 64 pixels
 constexpr int WG_DS_X4 = 64;   // AX4: rows are contiguous 256-byte runs (one DMA instruction fills four), XOR-swizzled instead
 }
 
+// s_waitcnt vmcnt(n) for a run-time n (gfx9 encoding: vmcnt = bits[3:0] | bits[15:14] << 4; expcnt / lgkmcnt untouched)
+__device__ __forceinline__ void wg43_wait_vmcnt(int n) {
+#define WG43_W(k) case k: __builtin_amdgcn_s_waitcnt(0x0F70 | ((k) & 15) | (((k) >> 4) << 14)); break;
+  switch (n) {
+    WG43_W(1) WG43_W(2) WG43_W(3) WG43_W(4) WG43_W(5) WG43_W(6) WG43_W(7) WG43_W(8) WG43_W(9) WG43_W(10) WG43_W(11) WG43_W(12)
+    WG43_W(13) WG43_W(14) WG43_W(15) WG43_W(16) WG43_W(17) WG43_W(18) WG43_W(19) WG43_W(20) WG43_W(21) WG43_W(22) WG43_W(23)
+    WG43_W(24) WG43_W(25) WG43_W(26) WG43_W(27) WG43_W(28) WG43_W(29) WG43_W(30) WG43_W(31) WG43_W(32) WG43_W(33) WG43_W(34)
+    WG43_W(35) WG43_W(36) WG43_W(37) WG43_W(38) WG43_W(39) WG43_W(40)
+    default: __builtin_amdgcn_s_waitcnt(0x0F70); break;   // vmcnt(0)
+  }
+#undef WG43_W
+}
+
 // NWM x NWN waves of 32 co x 16 ci: (2,2) block 64 co x 32 ci, 4 waves, two blocks per CU; (4,2) 128 co x 32 ci and (2,4)
 // 64 co x 64 ci, 8 waves, one block per CU: one operand's tile is then amortised over twice the MFMAs (24 instead of 32
 // DMA instructions per wave and stage; measured 8 % faster than two 4-wave blocks).
@@ -72,8 +85,16 @@ constexpr int WG_DS_X4 = 64;   // AX4: rows are contiguous 256-byte runs (one DM
 // of their time issuing the fills, ~250 cycles per instruction).  The LDS rows are then contiguous (no padding between
 // them), so the 16 rows of a ds_read_b128 would collide on 4 banks: tile t of row r is stored at slot t ^ (r & 15)
 // (swizzle on the SOURCE address of the DMA and on the read; cdna_hip_programming.md rule 21).
-template <int NWM, int NWN, bool AX4>
+//
+// R3 (8-wave blocks): a ring of THREE LDS images and a half-stage stagger between the two waves of a SIMD.  Stamps put a wave
+// at ~30 % of its time issuing fills, ~55 % multiplying, ~15 % at the barrier -- and with two images both partners issue at
+// about the same time, so the matrix pipe idles.  Now waves 0-3 issue their share of the fills for stage s+2 and THEN multiply
+// stage s, waves 4-7 multiply stage s and THEN issue: one partner's ~4,600 cycles of fill issue lie beside the other's 144
+// MFMAs (4,608 cycles).  The fills go two stages ahead, so the late half's land in time; the wait before the barrier is a
+// counted vmcnt that leaves exactly this wave's youngest fills in flight.
+template <int NWM, int NWN, bool AX4, bool R3>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
+  static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
   constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
@@ -408,19 +429,45 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   };
 
   const int nst = s_end - s_begin;
-  if (nst > 0) issue_dma(s_begin, 0);
-  WG43_STAMP(3)   // prologue
-  for (int it = 0; it < nst; ++it) {
-    const int cur = it & 1;
-    gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
-    WG43_STAMP(0)
-    // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
-    // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
-    // first k-step BEFORE it issues its share of the next stage's DMA.
-    const bool late = NW == 8 && wave >= 4;
-    if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
-    WG43_STAMP(1)   // this wave's share of the next stage's DMA
-    compute(cur, late, s_begin + it + 1, it + 1 < nst);
+  if constexpr (R3) {
+    // DMA instructions this wave issues per stage (every one is issued whatever its lanes' validity): the counted wait below
+    const int per_stage = (AX4 ? BM / 4 / NW : BM / NW) + (BN / NW) * npv;
+    const bool late = wave >= 4;
+    if (nst > 0) issue_dma(s_begin, 0);
+    if (nst > 1) issue_dma(s_begin + 1, 1);
+    WG43_STAMP(3)   // prologue
+    int cur = 0, nxt = 2;   // image of stage `it`, image that stage it+2 is filled into
+    for (int it = 0; it < nst; ++it) {
+      // stage `it` has landed once every wave has seen all but its youngest fills (those of stage it+1, when there is one) land
+      wg43_wait_vmcnt(it + 1 < nst ? per_stage : 0);
+      __syncthreads();
+      WG43_STAMP(0)
+      const bool more = it + 2 < nst;
+      if (!late && more) issue_dma(s_begin + it + 2, nxt);
+      WG43_STAMP(1)
+      compute(cur, false, 0, false);
+      if (late && more) {
+        issue_dma(s_begin + it + 2, nxt);
+        WG43_STAMP(1)
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+  } else {
+    if (nst > 0) issue_dma(s_begin, 0);
+    WG43_STAMP(3)   // prologue
+    for (int it = 0; it < nst; ++it) {
+      const int cur = it & 1;
+      gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
+      WG43_STAMP(0)
+      // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
+      // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
+      // first k-step BEFORE it issues its share of the next stage's DMA.
+      const bool late = NW == 8 && wave >= 4;
+      if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
+      WG43_STAMP(1)   // this wave's share of the next stage's DMA
+      compute(cur, late, s_begin + it + 1, it + 1 < nst);
+    }
   }
 
 #pragma unroll
@@ -577,31 +624,41 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   // dy as aligned 16-byte pieces: rows, planes and images of the gradient buffer start 16-byte aligned
   const bool ax4 = gsd_env_int("GSD_WG43_AX4", 1) != 0 && dy->w_stride % 4 == 0 && ((uintptr_t)dy->ptr & 15) == 0 &&
                    dy->c_stride % 4 == 0 && dy->n_stride % 4 == 0 && pl.TW % 4 == 0;
-  const size_t lds = (size_t)2 * (pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + pl.BN * pl.XS) * sizeof(float);
-  static gsd_attr_once big_lds[6];   // per-device caches of an idempotent launch attribute (gsd_common.h)
-  const void* fns[6] = {reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2, false>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2, false>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4, false>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 2, true>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<4, 2, true>),
-                        reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<2, 4, true>)};
-  for (int i = 0; i < 6; ++i)
-    if (hipError_t e = gsd_allow_big_lds(big_lds[i], fns[i]); e != hipSuccess) {
-      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return GSD_ERR_HIP;
-    }
+  // three LDS images + half-stage stagger for the 8-wave forms (GSD_WG43_R3=1; measured 2 % SLOWER: a wave alone needs ~66
+  // cycles per MFMA in its multiply phase -- hipcc sinks the operand reads to their uses at 229 of 256 registers -- so the
+  // partner's fills do not lie beside idle pipe time)
+  const bool eight = pl.BM == 128 || pl.BN == 64;
+  const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + pl.BN * pl.XS) * sizeof(float);
+  const bool r3 = gsd_env_int("GSD_WG43_R3", 0) != 0 && eight && 3 * img <= 160 * 1024;
+  const size_t lds = (r3 ? 3 : 2) * img;
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
+  // one launcher per instantiation: the kernel's address keys the per-device cache of the launch attribute (gsd_common.h)
+#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_)                                                                              \
+  do {                                                                                                                  \
+    static gsd_attr_once once;                                                                                          \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_>);                          \
+    if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                                  \
+      gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                                \
+      return GSD_ERR_HIP;                                                                                               \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
+  } while (0)
   if (pl.BM == 128) {
-    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2, true>), g, dim3(512), lds, st, P);
-    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<4, 2, false>), g, dim3(512), lds, st, P);
+    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true);
+    else if (ax4) WG43_LAUNCH(4, 2, true, false);
+    else if (r3) WG43_LAUNCH(4, 2, false, true);
+    else WG43_LAUNCH(4, 2, false, false);
   } else if (pl.BN == 64) {
-    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4, true>), g, dim3(512), lds, st, P);
-    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 4, false>), g, dim3(512), lds, st, P);
+    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true);
+    else if (ax4) WG43_LAUNCH(2, 4, true, false);
+    else if (r3) WG43_LAUNCH(2, 4, false, true);
+    else WG43_LAUNCH(2, 4, false, false);
   } else {
-    if (ax4) hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2, true>), g, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((wgrad3x3_w43_kernel<2, 2, false>), g, dim3(256), lds, st, P);
+    if (ax4) WG43_LAUNCH(2, 2, true, false);
+    else WG43_LAUNCH(2, 2, false, false);
   }
+#undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
   const long long per = 3LL * Cout * Cin;
   if (pl.splits >= 64) {
