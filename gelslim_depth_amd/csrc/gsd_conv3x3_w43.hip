@@ -232,7 +232,11 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // chain of scalar branches per slot in the general form): possible when a chunk of 4 channels never straddles the two
 // source segments and Cin % 4 == 0 (always true in the U-Net).  Stamps (profiles/stamp_conv.py) put the per-slot form at
 // ~1200 of the cycles a wave spends per chunk; measured -7 % kernel time over the U-Net's layer set.
-template <int WM, bool X4, int NL, bool FAST>
+//
+// PLAIN: no source segment carries a deferred BatchNorm or ReLU (every dX launch: dy is plain; the pooled and upsampled
+// sources of the forward): the operand transform drops its 12 fma/max per kernel row and the per-chunk scale / shift
+// reads.  Measured with the transform forced plain over the layer set: -2.5 % kernel time.
+template <int WM, bool X4, int NL, bool FAST, bool PLAIN>
 #ifndef W43_MIN_WAVES   // diagnostic builds: waves per SIMD the register allocation must admit for the 4-wave form
 #define W43_MIN_WAVES 2
 #endif
@@ -538,9 +542,11 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
 
   // V = B^T d of one kernel row: raw halo values -> deferred BatchNorm+ReLU -> the 6 frequency operands
   auto transform = [&](const f32x4& ra, const f32x2& rb, float sc, float sh, float lo, float (&v)[6]) {
-    const float d0 = fmaxf(fmaf(ra[0], sc, sh), lo), d1 = fmaxf(fmaf(ra[1], sc, sh), lo);
-    const float d2 = fmaxf(fmaf(ra[2], sc, sh), lo), d3 = fmaxf(fmaf(ra[3], sc, sh), lo);
-    const float d4 = fmaxf(fmaf(rb[0], sc, sh), lo), d5 = fmaxf(fmaf(rb[1], sc, sh), lo);
+    float d0 = ra[0], d1 = ra[1], d2 = ra[2], d3 = ra[3], d4 = rb[0], d5 = rb[1];
+    if constexpr (!PLAIN) {
+      d0 = fmaxf(fmaf(d0, sc, sh), lo), d1 = fmaxf(fmaf(d1, sc, sh), lo), d2 = fmaxf(fmaf(d2, sc, sh), lo);
+      d3 = fmaxf(fmaf(d3, sc, sh), lo), d4 = fmaxf(fmaf(d4, sc, sh), lo), d5 = fmaxf(fmaf(d5, sc, sh), lo);
+    }
     const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
     const float c = d4 - d2, e = 2.f * (d3 - d1);
     v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
@@ -563,8 +569,11 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
     gsd_dma_barrier();
     W43_STAMP(0)   // wait for the chunk's DMA + barrier
     const int kc = chunk * 4 + j;
-    const float sc = sAff[kc], sh = sAff[Kpad + kc];
-    const float lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
+    float sc = 1.f, sh = 0.f, lo = 0.f;
+    if constexpr (!PLAIN) {
+      sc = sAff[kc], sh = sAff[Kpad + kc];
+      lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
+    }
     const bool more = chunk + 1 < P.nchunks;
     const float* Wc = smem + cur * BUF;
     f32x4 av[2];
@@ -889,24 +898,25 @@ int halo_read_cycles(int TWq, int LP, int PS, int off) {
 }
 
 // one launcher per kernel instantiation (the address of the kernel keys the per-device launch-attribute cache)
-template <int WM, bool X4, int NL, bool FAST>
+template <int WM, bool X4, int NL, bool FAST, bool PLAIN = false>
 int launch_one(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN>);
   if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL((conv3x3_w43_kernel<WM, X4, NL, FAST>), dim3(grid), dim3(256 * WM + 64 * NL), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN>), dim3(grid), dim3(256 * WM + 64 * NL), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w43");
   return GSD_OK;
 }
 
-int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm, bool x4, int nl, bool fast) {
+int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm, bool x4, int nl, bool fast, bool plain) {
   if (nl == 1) return x4 ? launch_one<1, true, 1, false>(P, grid, lds, st) : launch_one<1, false, 1, false>(P, grid, lds, st);
   if (nl == 2) return x4 ? launch_one<1, true, 2, false>(P, grid, lds, st) : launch_one<1, false, 2, false>(P, grid, lds, st);
   if (wm == 2) return x4 ? launch_one<2, true, 0, false>(P, grid, lds, st) : launch_one<2, false, 0, false>(P, grid, lds, st);
+  if (fast && plain) return x4 ? launch_one<1, true, 0, true, true>(P, grid, lds, st) : launch_one<1, false, 0, true, true>(P, grid, lds, st);
   if (fast) return x4 ? launch_one<1, true, 0, true>(P, grid, lds, st) : launch_one<1, false, 0, true>(P, grid, lds, st);
   return x4 ? launch_one<1, true, 0, false>(P, grid, lds, st) : launch_one<1, false, 0, false>(P, grid, lds, st);
 }
@@ -1017,7 +1027,9 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
   GSD_REQUIRE(!pl.fold || nl == 0, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: the loader-wave form does not fold rows (GSD_W43_FOLD=0)");
   const size_t lds = (size_t)(2 * (WM * W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
-  return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast);
+  bool plain = gsd_env_int("GSD_W43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any source segment
+  for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
+  return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast, plain);
 }
 
 extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,

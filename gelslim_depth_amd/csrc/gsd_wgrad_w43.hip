@@ -92,7 +92,12 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // stage s, waves 4-7 multiply stage s and THEN issue: one partner's ~4,600 cycles of fill issue lie beside the other's 144
 // MFMAs (4,608 cycles).  The fills go two stages ahead, so the late half's land in time; the wait before the barrier is a
 // counted vmcnt that leaves exactly this wave's youngest fills in flight.
-template <int NWM, int NWN, bool AX4, bool R3>
+//
+// PLAIN: no activation segment carries a deferred BatchNorm / ReLU (the pooled sources of the encoder's first convs): the
+// transform drops its 36 fma/max per k-step.  Measured with the transform forced plain: -3.8 % kernel time.  (Choosing per
+// BLOCK inside one kernel -- the upsampled half of a concat is plain too -- doubles the stage code and sends the
+// accumulators to scratch.)
+template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
   static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
   constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
@@ -401,9 +406,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r) {    // V = B^T relu(bn(raw))
-        const float d0 = fmaxf(fmaf(ra[cb][r][0], sc, sh), lo), d1 = fmaxf(fmaf(ra[cb][r][1], sc, sh), lo);
-        const float d2 = fmaxf(fmaf(ra[cb][r][2], sc, sh), lo), d3 = fmaxf(fmaf(ra[cb][r][3], sc, sh), lo);
-        const float d4 = fmaxf(fmaf(rb[cb][r][0], sc, sh), lo), d5 = fmaxf(fmaf(rb[cb][r][1], sc, sh), lo);
+        float d0 = ra[cb][r][0], d1 = ra[cb][r][1], d2 = ra[cb][r][2], d3 = ra[cb][r][3], d4 = rb[cb][r][0], d5 = rb[cb][r][1];
+        if constexpr (!PLAIN) {
+          d0 = fmaxf(fmaf(d0, sc, sh), lo), d1 = fmaxf(fmaf(d1, sc, sh), lo), d2 = fmaxf(fmaf(d2, sc, sh), lo);
+          d3 = fmaxf(fmaf(d3, sc, sh), lo), d4 = fmaxf(fmaf(d4, sc, sh), lo), d5 = fmaxf(fmaf(d5, sc, sh), lo);
+        }
         const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
         const float c = d4 - d2, e = 2.f * (d3 - d1);
         V[r][0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
@@ -631,32 +638,37 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + pl.BN * pl.XS) * sizeof(float);
   const bool r3 = gsd_env_int("GSD_WG43_R3", 0) != 0 && eight && 3 * img <= 160 * 1024;
   const size_t lds = (r3 ? 3 : 2) * img;
+  bool plain = gsd_env_int("GSD_WG43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any activation segment
+  for (int i = 0; i < nsrc; ++i) plain = plain && a[i].scale == nullptr && a[i].relu == 0;
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
   // one launcher per instantiation: the kernel's address keys the per-device cache of the launch attribute (gsd_common.h)
-#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_)                                                                              \
+#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_, PL_)                                                                            \
   do {                                                                                                                  \
     static gsd_attr_once once;                                                                                          \
-    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_>);                          \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_>);                          \
     if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                                  \
       gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                                \
       return GSD_ERR_HIP;                                                                                               \
     }                                                                                                                   \
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
   } while (0)
   if (pl.BM == 128) {
-    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true);
-    else if (ax4) WG43_LAUNCH(4, 2, true, false);
-    else if (r3) WG43_LAUNCH(4, 2, false, true);
-    else WG43_LAUNCH(4, 2, false, false);
+    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false);
+    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true);
+    else if (ax4) WG43_LAUNCH(4, 2, true, false, false);
+    else if (r3) WG43_LAUNCH(4, 2, false, true, false);
+    else WG43_LAUNCH(4, 2, false, false, false);
   } else if (pl.BN == 64) {
-    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true);
-    else if (ax4) WG43_LAUNCH(2, 4, true, false);
-    else if (r3) WG43_LAUNCH(2, 4, false, true);
-    else WG43_LAUNCH(2, 4, false, false);
+    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false);
+    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true);
+    else if (ax4) WG43_LAUNCH(2, 4, true, false, false);
+    else if (r3) WG43_LAUNCH(2, 4, false, true, false);
+    else WG43_LAUNCH(2, 4, false, false, false);
   } else {
-    if (ax4) WG43_LAUNCH(2, 2, true, false);
-    else WG43_LAUNCH(2, 2, false, false);
+    if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true);
+    else if (ax4) WG43_LAUNCH(2, 2, true, false, false);
+    else WG43_LAUNCH(2, 2, false, false, false);
   }
 #undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
