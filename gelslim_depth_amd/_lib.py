@@ -80,6 +80,9 @@ SIGNATURES = {
     "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad": (_I, [_SRC, _I, _SRC, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_takes_pitched_dy": (_I, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_wgrad_bn_supported": (_I, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_wgrad_bn_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_wgrad_bn": (_I, [_SRC, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_convT2x2_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_convT2x2_wgrad": (_I, [_SRC, _SRC, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_bn_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),

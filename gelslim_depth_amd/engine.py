@@ -65,6 +65,7 @@ class _Unit:
         self.raw = self.g = None
         self.dsrc = None  # d_raw as the dW / dX kernels read it: g itself, or the pitched scratch buffer (engine.gp)
         self.pitched = False   # gsd_bn_bwd_apply writes d_raw out of place into the pitched buffer
+        self.fused_dw = False  # first layer: no dX, so dW forms d_raw itself (gsd_conv3x3_wgrad_bn) and the apply pass is skipped
         self.srcs = None  # gsd_src array kept for wgrad
         self.form_f = self.form_d = None   # _ConvForm of the forward / dX launch for the current shape
         self.fused_rows = 0                # partial rows written by the dX launch that produced this unit's dz
@@ -171,6 +172,9 @@ class UNetEngine:
                     (not u.need_dgrad or u.form_d.algo == 1)
                 if u.pitched:
                     max_gp = max(max_gp, n * u.cout * lh * _r4(lw))
+                u.fused_dw = (not u.need_dgrad) and bool(lib.gsd_conv3x3_wgrad_bn_supported(n, lh, lw, u.cin, u.cout))
+                if u.fused_dw:
+                    max_ws = max(max_ws, lib.gsd_conv3x3_wgrad_bn_workspace(n, lh, lw, u.cin, u.cout))
         for up in self.ups:
             li = up.level_in
             if up.out is None:
@@ -328,6 +332,12 @@ class UNetEngine:
                                       G[u.bname].data_ptr(), None if dwout is None else dwout.data_ptr(),
                                       u.c1.data_ptr(), u.c2.data_ptr(), st),
               "bn_bwd_finalize")
+        if u.fused_dw:
+            check(lib.gsd_conv3x3_wgrad_bn(u.srcs, u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
+                                           u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), u.cin, u.cout,
+                                           G[u.wname].data_ptr(), self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, lh, lw, st),
+                  "conv3x3_wgrad_bn")
+            return
         if u.pitched:
             p = _r4(lw)
             u.dsrc = self.gp[:n * u.cout * lh * p].view(n, u.cout, lh, p)[..., :lw]

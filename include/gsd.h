@@ -162,6 +162,19 @@ int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
                       int N, int H, int W, void* stream);
 /* 1 when gsd_conv3x3_wgrad serves this shape with a kernel that takes a pitched dy (dy->w_stride > W, see gsd_src). */
 int gsd_conv3x3_wgrad_takes_pitched_dy(int N, int H, int W, int Cin, int Cout);
+/* dW of a conv3x3 with FEW input channels (Cin * 9 <= 32: the network's first layer, unet.py:15) with the BatchNorm
+ * backward of its output applied on the fly: d_raw = scale * (dz - c1 - (raw - mean) * invstd * c2) is formed in registers
+ * from dz and raw -- what gsd_bn_bwd_apply would have written.  The first layer has no dX, so dW is d_raw's only reader and
+ * the apply pass disappears.  With scale == raw == NULL dz is taken as the conv output's gradient as it is.
+ * `a`: ONE plain segment (no deferred BN: the input image); dz, raw: contiguous (N,Cout,H,W).  Deterministic (slabs in
+ * `workspace`, ordered reduction); dW in the reference's (Co,Ci,3,3) layout.
+ * gsd_conv3x3_wgrad_bn_supported: 1 when the shape is served (0: use gsd_bn_bwd_apply + gsd_conv3x3_wgrad). */
+int gsd_conv3x3_wgrad_bn_supported(int N, int H, int W, int Cin, int Cout);
+int64_t gsd_conv3x3_wgrad_bn_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_wgrad_bn(const gsd_src* a, const float* dz, const float* raw, const float* scale,
+                         const float* mean, const float* invstd, const float* c1, const float* c2,
+                         int Cin, int Cout, float* dw, float* workspace, int64_t workspace_elems,
+                         int N, int H, int W, void* stream);
 /* dW and db of ConvTranspose2d(k2,s2): x (h,w) with deferred BN, dy (2h,2w) plain;
  * dW in the reference's (Ci,Co,2,2) layout. */
 int64_t gsd_convT2x2_wgrad_workspace(int N, int H, int W, int Cin, int Cout);

@@ -636,3 +636,43 @@ def test_conv3x3_w43_row_folding(gsd, monkeypatch, n, ci, co, h, w):
     for k in (5, 6):
         np.testing.assert_allclose(res["1"][k].cpu().numpy(), res["0"][k].cpu().numpy(), rtol=1e-5, atol=1e-3)
     assert res["1"][7] <= res["0"][7]     # never more blocks (fewer at batch sizes that leave tail rows)
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,bn", [(2, 3, 64, 9, 37, True), (1, 3, 20, 5, 16, True), (3, 2, 70, 7, 50, True),
+                                            (2, 3, 64, 6, 33, False), (5, 1, 16, 4, 3, True), (2, 3, 64, 41, 427, True)])
+def test_conv3x3_wgrad_bn_first_layer(gsd, n, ci, co, h, w, bn):
+    """dW of the first conv with the BatchNorm backward of its output applied on the fly (unet.py:15-16 in backward):
+    same numbers as gsd_bn_bwd_apply's expression followed by the oracle's dW; twice the same bits; workspace checked."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(ci * 17 + co + w)
+    x = rnd(rng, n, ci, h, w)
+    dz, raw = rnd(rng, n, co, h, w), rnd(rng, n, co, h, w)
+    sc, mu = rng.uniform(0.5, 1.5, co).astype(np.float32), rnd(rng, co, scale=0.3)
+    istd, k1, k2 = rng.uniform(0.5, 2.0, co).astype(np.float32), rnd(rng, co, scale=0.1), rnd(rng, co, scale=0.1)
+    b = lambda v: v[None, :, None, None]
+    d_raw = (b(sc) * (dz - b(k1) - (raw - b(mu)) * b(istd) * b(k2))).astype(np.float32) if bn else dz
+    _, dwr = on.conv3x3_bwd(x, np.zeros((co, ci, 3, 3), np.float32), d_raw, need_dx=False)
+    assert gsd.lib.gsd_conv3x3_wgrad_bn_supported(n, h, w, ci, co) == 1
+    assert gsd.lib.gsd_conv3x3_wgrad_bn_supported(n, h, w, 4, co) == 0
+    need = gsd.lib.gsd_conv3x3_wgrad_bn_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    xd, dzd, rawd = dev(x), dev(dz), dev(raw)
+    par = [dev(v) for v in (sc, mu, istd, k1, k2)]
+    ptrs = [p.data_ptr() for p in par] if bn else [None] * 5
+    a_src = gsd.make_src(xd)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_wgrad_bn(C.byref(a_src), dzd.data_ptr(), rawd.data_ptr() if bn else None, *ptrs, ci, co,
+                                               dw.data_ptr(), ws.data_ptr(), need, n, h, w, gsd.stream_ptr()))
+        outs.append(dw.cpu().numpy())
+    assert np.isfinite(outs[0]).all()
+    assert rel_l1(outs[0], dwr) < 5e-5
+    assert np.array_equal(outs[0], outs[1])
+    rc = gsd.lib.gsd_conv3x3_wgrad_bn(C.byref(a_src), dzd.data_ptr(), rawd.data_ptr() if bn else None, *ptrs, ci, co,
+                                      dw.data_ptr(), ws.data_ptr(), need - 1, n, h, w, gsd.stream_ptr())
+    assert rc == -4 and b"workspace" in gsd.lib.gsd_last_error()
+    aff = gsd.make_src(xd, dev(np.ones(ci, np.float32)), dev(np.zeros(ci, np.float32)), relu=True)
+    rc = gsd.lib.gsd_conv3x3_wgrad_bn(C.byref(aff), dzd.data_ptr(), rawd.data_ptr() if bn else None, *ptrs, ci, co,
+                                      dw.data_ptr(), ws.data_ptr(), need, n, h, w, gsd.stream_ptr())
+    assert rc != 0 and b"plain" in gsd.lib.gsd_last_error()
