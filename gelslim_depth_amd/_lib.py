@@ -23,7 +23,7 @@ class gsd_src(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("off_h", C.c_int32), ("off_w", C.c_int32), ("relu", C.c_int32),
-                ("w_stride", C.c_int32), ("reserved_", C.c_int32),
+                ("w_stride", C.c_int32), ("slack", C.c_int32),
                 ("n_stride", C.c_int64), ("c_stride", C.c_int64)]
 
 
@@ -185,9 +185,10 @@ def pitched_empty(shape, device, pitch_multiple: int = 4) -> torch.Tensor:
 
 def make_src(t: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
              relu: bool = False, c_off: int = 0, c_len: Optional[int] = None,
-             off: Tuple[int, int] = (0, 0)) -> gsd_src:
+             off: Tuple[int, int] = (0, 0), slack: int = 0) -> gsd_src:
     """Describe channels [c_off, c_off+c_len) of an NCHW tensor as a gsd_src segment.  The tensor may be a view of a
-    PITCHED buffer (rows padded to a multiple of 4 floats): any strides with stride(3) == 1 are accepted."""
+    PITCHED buffer (rows padded to a multiple of 4 floats): any strides with stride(3) == 1 are accepted.
+    slack: readable floats the caller vouches for before and after the tensor (slack_empty allocates such tensors)."""
     _chk_f32(t)
     _chk_nchw(t)
     n, ct, h, w = t.shape
@@ -200,9 +201,25 @@ def make_src(t: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optio
     s.off_h, s.off_w = off
     s.relu = 1 if relu else 0
     s.w_stride = t.stride(2)
+    s.slack = slack
     s.n_stride = t.stride(0)
     s.c_stride = t.stride(1)
     return s
+
+
+SLACK = 4   # floats of readable slack either side of a slack_empty tensor (gsd_src.slack)
+
+
+def slack_empty(shape, device) -> torch.Tensor:
+    """A contiguous fp32 tensor with SLACK readable floats in front of and behind it (16-byte aligned like any other): the
+    Winograd dW kernel's 16-byte window pieces may read up to 3 floats past either end (gsd_src.slack)."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    buf = torch.empty((numel + 2 * SLACK,), device=device, dtype=torch.float32)
+    buf[:SLACK].zero_()
+    buf[-SLACK:].zero_()
+    return buf[SLACK:SLACK + numel].view(*shape)
 
 
 def make_dst(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None, off: Tuple[int, int] = (0, 0)) -> gsd_dst:

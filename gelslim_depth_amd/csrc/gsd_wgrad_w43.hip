@@ -26,6 +26,8 @@
 
 __device__ const float gsd_pad_wg43[2] = {0.f, __builtin_nanf("")};
 __device__ __attribute__((aligned(16))) const float gsd_zero16_wg43[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float gsd_nan16_wg43[4] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
+                                                                         __builtin_nanf("")};
 
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 
@@ -97,13 +99,25 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // transform drops its 36 fma/max per k-step.  Measured with the transform forced plain: -3.8 % kernel time.  (Choosing per
 // BLOCK inside one kernel -- the upsampled half of a concat is plain too -- doubles the stage code and sends the
 // accumulators to scratch.)
-template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN>
+//
+// BX4: the activation windows move as 16-byte pieces too -- straight from the UNALIGNED rows (W = 427, 213, ...): a
+// global_load_lds_dwordx4 takes any 4-byte aligned global address at full rate (profiles/ubench/dma_global_align.hip).  The
+// block's BN window planes lie back to back in LDS (plane = WR rows x WCp/4 pieces + dummy pieces up to an ODD piece count, so
+// the 16 channels of a ds_read_b128 spread over all 8 bank groups) and an instruction's 64 lanes are 64 consecutive pieces of
+// that image, whichever channels and rows they fall into: 16 instead of 64 instructions per stage for 32 channels of a 6 x 20
+// window.  Pieces wholly outside the image come from a 16-byte sentinel; a piece that STRADDLES the left or right image edge
+// is loaded as it lies in memory (its outside part is the neighbouring row's data: the caller guarantees 4 readable floats
+// before and after the tensor, gsd_src.slack) and the block overwrites that part with the padding value after the fills have
+// landed -- one more barrier, on the stages that touch a vertical edge only.
+template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
   static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
+  static_assert(!BX4 || (AX4 && !R3), "16-byte window pieces come with 16-byte dy pieces and two LDS images");
   constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
-  const int BUF = BM * DS + BN * XS;
+  // BX4: the window image is whole 64-piece instructions long (the last one's surplus lanes write dummies behind the planes)
+  const int BUF = BX4 ? BM * DS + (((BN * (XS >> 2)) + 63) >> 6) * 256 : BM * DS + BN * XS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,15 +150,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   // issue path): a lane past the window re-reads the window origin into the slack behind it (XS >= npv*64).
   const int npv = (P.WR * P.WCp + 63) >> 6;
   int b_rr[4], b_cc[4], oA[4], oB[4];
+  if constexpr (!BX4) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int pos = p * 64 + lane;
-    b_rr[p] = pos / P.WCp;
-    b_cc[p] = pos - b_rr[p] * P.WCp;
-    const bool in_win = b_rr[p] < P.WR && b_cc[p] < P.WC;
-    if (!in_win) b_rr[p] = b_cc[p] = 0;
-    oA[p] = b_rr[p] * P.a0.ws + b_cc[p];
-    oB[p] = b_rr[p] * P.a1.ws + b_cc[p];
+    for (int p = 0; p < 4; ++p) {
+      const int pos = p * 64 + lane;
+      b_rr[p] = pos / P.WCp;
+      b_cc[p] = pos - b_rr[p] * P.WCp;
+      const bool in_win = b_rr[p] < P.WR && b_cc[p] < P.WC;
+      if (!in_win) b_rr[p] = b_cc[p] = 0;
+      oA[p] = b_rr[p] * P.a0.ws + b_cc[p];
+      oB[p] = b_rr[p] * P.a1.ws + b_cc[p];
+    }
   }
 
   // deferred BatchNorm+ReLU of this lane's input channel
@@ -176,8 +192,32 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   const int S_left = (b_seg1 ? P.a1.C : P.a0.C) - S_c0;                        // channel i of the wave exists iff NW * i < S_left
   const float* const S_sent = (b_seg1 ? P.a1.relu : P.a0.relu) ? &gsd_pad_wg43[1] : &gsd_pad_wg43[0];
   int oS[4];
+  if constexpr (!BX4) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) oS[p] = b_rr[p] * S_ws + b_cc[p];
+    for (int p = 0; p < 4; ++p) oS[p] = b_rr[p] * S_ws + b_cc[p];
+  }
+  // BX4: instruction i = wave + NW*k of the stage moves pieces 64 i .. 64 i + 63 of the block's [BN][XS/4] piece image; this
+  // lane's piece of instruction k: float offset from the first channel's window origin, and (row, first column, channel)
+  // packed for the edge stages (bit 31: a dummy piece or one past the image)
+  constexpr int KB = 4;   // instructions per wave at most (the host checks)
+  int x_off[KB], x_meta[KB];
+  const int NPr = P.WCp >> 2, NPc = XS >> 2, NI = (BN * NPc + 63) >> 6;
+  const int S_chan = (b_seg1 ? P.a1.C : P.a0.C) - (n0 - (b_seg1 ? P.a0.C : 0));   // channels of the segment from n0 on
+  const float padv = (b_seg1 ? P.a1.relu : P.a0.relu) ? __builtin_nanf("") : 0.f;
+  const float* const S_sent16 = (b_seg1 ? P.a1.relu : P.a0.relu) ? &gsd_nan16_wg43[0] : &gsd_zero16_wg43[0];
+  if constexpr (BX4) {
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int i = wave + NW * k;
+      const int pid = 64 * i + lane;
+      const int ch = pid / NPc, pp = pid - ch * NPc;
+      const int row = pp / NPr, pc = pp - row * NPr;
+      const bool dummy = i >= NI || ch >= BN || row >= P.WR;
+      x_off[k] = dummy ? 0 : (int)(ch * S_cs) + row * S_ws + 4 * pc;
+      x_meta[k] = dummy ? (int)0x80000000u : (row | (4 * pc) << 8 | ch << 16);
+    }
+  }
+  int fix0 = 0, fix1 = 0;   // per LDS image: the window columns [gl0, gl1) and [gr0, gr1) to overwrite with the padding value
 
   // Address arithmetic is kept out of the per-instruction path (the kernel is VALU-bound next to 144 MFMAs per stage): per
   // stage one scalar window origin per segment, per lane the constants above; a stage whose window lies inside the
@@ -253,6 +293,38 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       }
     }
     // ---- B: activation windows ----
+    if constexpr (BX4) {
+      const int hs = h0 - 1 - S_oh, ws = w0 - 1 - S_ow;
+      const float* cb = S_p + (long long)n * S_ns + (long long)(n0 - (b_seg1 ? P.a0.C : 0)) * S_cs + ((long long)hs * S_ws + ws);
+      const bool in = hs >= 0 && hs + P.WR <= S_H && ws >= 0 && ws + P.WCp <= S_W && S_chan >= BN;
+      int fx = 0;
+      if (in) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (wave + NW * k < NI) {
+            const float* gp = cb + x_off[k];
+            float* dstp = Bb + (wave + NW * k) * 256;
+            if (!skipB) __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (wave + NW * k < NI) {
+            const int m = x_meta[k];
+            const int r = hs + (m & 255), c0 = ws + (m >> 8 & 255), ch = m >> 16 & 255;
+            const bool ok = m >= 0 && ch < S_chan && (unsigned)r < (unsigned)S_H && c0 + 3 >= 0 && c0 < S_W;
+            const float* gp = ok ? cb + x_off[k] : S_sent16;
+            float* dstp = Bb + (wave + NW * k) * 256;
+            if (!skipB) __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+          }
+        // the outside part of a straddling piece: window columns [4 (cl / 4), cl) on the left, [cr, 4 ceil(cr / 4)) on the right
+        const int cl = ws < 0 ? -ws : 0, cr = S_W - ws;
+        if (cl & 3) fx |= (cl & ~3) | cl << 8;
+        if (cr > 0 && cr < P.WCp && (cr & 3)) fx |= cr << 16 | ((cr + 3) & ~3) << 24;
+      }
+      if (buf) fix1 = fx; else fix0 = fx;
+      return;
+    }
     if (b_one && !skipB) {
       // one segment for the whole block: a scalar plane pointer that advances by NW channels + the lanes' fixed window offsets;
       // interior stages need nothing else, border stages one validity bit per window position
@@ -466,6 +538,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     for (int it = 0; it < nst; ++it) {
       const int cur = it & 1;
       gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
+      if constexpr (BX4) {
+        const int fx = cur ? fix1 : fix0;
+        if (fx) {   // a stage at the left / right image edge: the outside part of its straddling pieces gets the padding value
+          float* Bb = smem + cur * BUF + BM * DS;
+          const int gl0 = fx & 255, gl1 = fx >> 8 & 255, gr0 = fx >> 16 & 255, gr1 = fx >> 24 & 255;
+          for (int idx = tid; idx < BN * P.WR; idx += 64 * NW) {
+            const int pl = idx / P.WR, row = idx - pl * P.WR;
+            float* rp = Bb + pl * XS + row * P.WCp;
+            for (int c = gl0; c < gl1; ++c) rp[c] = padv;
+            for (int c = gr0; c < gr1; ++c) rp[c] = padv;
+          }
+          __syncthreads();
+        }
+      }
       WG43_STAMP(0)
       // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
       // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
@@ -635,7 +721,22 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   // cycles per MFMA in its multiply phase -- hipcc sinks the operand reads to their uses at 229 of 256 registers -- so the
   // partner's fills do not lie beside idle pipe time)
   const bool eight = pl.BM == 128 || pl.BN == 64;
-  const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + pl.BN * pl.XS) * sizeof(float);
+  // activation windows as 16-byte pieces from the unaligned rows: every block's channels lie in one segment, the caller
+  // vouches for 4 readable floats around each segment tensor (straddling pieces), at most 4 instructions per wave
+  bool bx4 = gsd_env_int("GSD_WG43_BX4", 1) != 0 && ax4 && gsd_env_int("GSD_WG43_R3", 0) == 0 &&
+             (nsrc == 1 || a[0].C % pl.BN == 0);
+  for (int i = 0; i < nsrc; ++i) bx4 = bx4 && a[i].slack >= 4;
+  if (bx4) {
+    int xs = pl.WR * pl.WCp;          // WCp % 4 == 0
+    if ((xs / 4) % 2 == 0) xs += 4;   // an odd number of pieces per plane
+    const int nw = (pl.BM == 128 || pl.BN == 64) ? 8 : 4;
+    const int ni = (pl.BN * (xs / 4) + 63) / 64;
+    bool fits = (ni + nw - 1) / nw <= 4 && pl.WR < 256 && pl.WCp < 256;
+    for (int i = 0; i < nsrc; ++i) fits = fits && (int64_t)pl.BN * a[i].c_stride < (1LL << 31);
+    if (fits) P.XS = xs;
+    else bx4 = false;
+  }
+  const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + (bx4 ? (pl.BN * (P.XS / 4) + 63) / 64 * 256 : pl.BN * P.XS)) * sizeof(float);
   const bool r3 = gsd_env_int("GSD_WG43_R3", 0) != 0 && eight && 3 * img <= 160 * 1024;
   const size_t lds = (r3 ? 3 : 2) * img;
   bool plain = gsd_env_int("GSD_WG43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any activation segment
@@ -643,32 +744,38 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
   // one launcher per instantiation: the kernel's address keys the per-device cache of the launch attribute (gsd_common.h)
-#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_, PL_)                                                                            \
+#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_, PL_, BX_)                                                                          \
   do {                                                                                                                  \
     static gsd_attr_once once;                                                                                          \
-    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_>);                          \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_>);                          \
     if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                                  \
       gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                                \
       return GSD_ERR_HIP;                                                                                               \
     }                                                                                                                   \
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
   } while (0)
   if (pl.BM == 128) {
-    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false);
-    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true);
-    else if (ax4) WG43_LAUNCH(4, 2, true, false, false);
-    else if (r3) WG43_LAUNCH(4, 2, false, true, false);
-    else WG43_LAUNCH(4, 2, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false, false);
+    else if (bx4 && plain) WG43_LAUNCH(4, 2, true, false, true, true);
+    else if (bx4) WG43_LAUNCH(4, 2, true, false, false, true);
+    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true, false);
+    else if (ax4) WG43_LAUNCH(4, 2, true, false, false, false);
+    else if (r3) WG43_LAUNCH(4, 2, false, true, false, false);
+    else WG43_LAUNCH(4, 2, false, false, false, false);
   } else if (pl.BN == 64) {
-    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false);
-    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true);
-    else if (ax4) WG43_LAUNCH(2, 4, true, false, false);
-    else if (r3) WG43_LAUNCH(2, 4, false, true, false);
-    else WG43_LAUNCH(2, 4, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false, false);
+    else if (bx4 && plain) WG43_LAUNCH(2, 4, true, false, true, true);
+    else if (bx4) WG43_LAUNCH(2, 4, true, false, false, true);
+    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true, false);
+    else if (ax4) WG43_LAUNCH(2, 4, true, false, false, false);
+    else if (r3) WG43_LAUNCH(2, 4, false, true, false, false);
+    else WG43_LAUNCH(2, 4, false, false, false, false);
   } else {
-    if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true);
-    else if (ax4) WG43_LAUNCH(2, 2, true, false, false);
-    else WG43_LAUNCH(2, 2, false, false, false);
+    if (bx4 && plain) WG43_LAUNCH(2, 2, true, false, true, true);
+    else if (bx4) WG43_LAUNCH(2, 2, true, false, false, true);
+    else if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true, false);
+    else if (ax4) WG43_LAUNCH(2, 2, true, false, false, false);
+    else WG43_LAUNCH(2, 2, false, false, false, false);
   }
 #undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");

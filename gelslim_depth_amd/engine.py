@@ -143,7 +143,7 @@ class UNetEngine:
         for u in self.units:
             lh, lw = hs[u.level], ws[u.level]
             if u.raw is None:
-                u.raw = torch.empty((n, u.cout, lh, lw), **f32)
+                u.raw = L.slack_empty((n, u.cout, lh, lw), dev)   # dW reads it as 16-byte window pieces
             if train and u.g is None:
                 u.g = torch.empty((n, u.cout, lh, lw), **f32)
             if u.scale is None or u.scale.device != dev:
@@ -178,7 +178,7 @@ class UNetEngine:
         for up in self.ups:
             li = up.level_in
             if up.out is None:
-                up.out = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
+                up.out = L.slack_empty((n, up.cout, 2 * hs[li], 2 * ws[li]), dev)
             if train and up.dout is None:
                 up.dout = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
             if up.wt_f is None or up.wt_f.device != dev:
@@ -186,7 +186,7 @@ class UNetEngine:
                 up.wt_d = torch.empty((lib.gsd_weight_layout_size(3, up.cout, up.cin),), **f32)
             if train:
                 max_ws = max(max_ws, lib.gsd_convT2x2_wgrad_workspace(n, hs[li], ws[li], up.cin, up.cout))
-        self.pooled = [None] + [torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32) for l in range(1, self.L + 1)]
+        self.pooled = [None] + [L.slack_empty((n, self.dims[l - 1], hs[l], ws[l]), dev) for l in range(1, self.L + 1)]
         self.dpooled = [None] + ([torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32)
                                  for l in range(1, self.L + 1)] if train else [None] * self.L)
         self.gp = torch.empty((max_gp,), **f32) if (train and max_gp) else None   # pitched d_raw scratch, one unit at a time
@@ -196,7 +196,7 @@ class UNetEngine:
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _act_src(u: _Unit) -> L.gsd_src:
-        return L.make_src(u.raw, u.scale, u.shift, relu=True)
+        return L.make_src(u.raw, u.scale, u.shift, relu=True, slack=L.SLACK)
 
     def _run_unit(self, u: _Unit, srcs: List[L.gsd_src], P: Dict[str, torch.Tensor], train: bool, st: int) -> None:
         n = u.raw.shape[0]
@@ -284,7 +284,7 @@ class UNetEngine:
                 s = self._act_src(prev)
                 check(lib.gsd_maxpool2(C.byref(s), self.pooled[lvl].data_ptr(), n, prev.cout, self.hs[lvl - 1],
                                        self.ws[lvl - 1], st), "maxpool2")
-                srcs = [L.make_src(self.pooled[lvl])]
+                srcs = [L.make_src(self.pooled[lvl], slack=L.SLACK)]
             self._run_unit(u0, srcs, P, train, st)
             self._run_unit(u1, [self._act_src(u0)], P, train, st)
         cur = self.enc[self.L][1]
@@ -298,7 +298,7 @@ class UNetEngine:
                                    self.hs[lvl + 1], self.ws[lvl + 1], st), "convT2x2")
             skip = self.enc[lvl][1]
             u0, u1 = self.dec[j]
-            self._run_unit(u0, [self._act_src(skip), L.make_src(up.out, off=self._pad_off(lvl))], P, train, st)
+            self._run_unit(u0, [self._act_src(skip), L.make_src(up.out, off=self._pad_off(lvl), slack=L.SLACK)], P, train, st)
             self._run_unit(u1, [self._act_src(u0)], P, train, st)
             cur = u1
         if out is None:

@@ -68,7 +68,12 @@ typedef struct {
                            a multiple of 4 floats (and 16-byte aligned strides) the Winograd kernels
                            move the operand as aligned 16-byte LDS-DMA pieces; columns W .. pitch-1
                            must then hold the operand's padding value (0 for a plain tensor).      */
-  int32_t reserved_;    /* keeps the 64-bit members aligned; 0                                  */
+  int32_t slack;        /* the caller vouches for this many READABLE floats before the first and after
+                           the last element of the stored tensor (0: none).  With slack >= 4 the Winograd
+                           dW kernel moves activation windows as 16-byte pieces straight from unaligned
+                           rows -- a piece that straddles an image edge reads up to 3 floats of the
+                           neighbouring row, at the tensor's two ends of the slack -- a quarter of the
+                           fill instructions.  (Keeps the 64-bit members aligned.)                  */
   int64_t n_stride;     /* elements between images                                              */
   int64_t c_stride;     /* elements between channels                                            */
 } gsd_src;

@@ -20,14 +20,15 @@ for lvl, c in enumerate([64, 128, 256, 512, 1024]):
 st = L.stream_ptr()
 tot = 0.0
 for lvl, ci, co, h, w in shapes:
-    x = torch.randn(B, ci, h, w, device="cuda")
+    x = L.slack_empty((B, ci, h, w), "cuda")   # 4 readable floats either side: the dW kernel may move windows as 16-byte pieces
+    x.copy_(torch.randn(B, ci, h, w, device="cuda"))
     sc, sh = torch.rand(ci, device="cuda") + 0.5, torch.randn(ci, device="cuda") * 0.1
     dy = L.pitched_empty((B, co, h, w), "cuda")
     dy.copy_(torch.randn(B, co, h, w, device="cuda"))
     dw = torch.empty(co, ci, 3, 3, device="cuda")
     need = lib.gsd_conv3x3_wgrad_workspace(B, h, w, ci, co)
     ws = torch.empty(need, device="cuda")
-    a_src, dy_src = L.src_array([L.make_src(x, sc, sh, relu=True)]), L.make_src(dy)
+    a_src, dy_src = L.src_array([L.make_src(x, sc, sh, relu=True, slack=L.SLACK)]), L.make_src(dy)
 
     def run():
         check(lib.gsd_conv3x3_wgrad(a_src, 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need, B, h, w, st), "wgrad")

@@ -32,10 +32,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from gelslim_depth_amd import _lib
-    # gsd_src: 3 pointers, 8 int32 (w_stride + reserved), 2 int64 ; gsd_dst: 1 pointer, 6 int32 (w_stride), 2 int64
+    # gsd_src: 3 pointers, 8 int32 (w_stride + slack), 2 int64 ; gsd_dst: 1 pointer, 6 int32 (w_stride), 2 int64
     assert ctypes.sizeof(_lib.gsd_src) == 3 * 8 + 8 * 4 + 2 * 8
     assert ctypes.sizeof(_lib.gsd_dst) == 8 + 6 * 4 + 2 * 8
-    assert _lib.gsd_src.w_stride.offset == 48 and _lib.gsd_src.n_stride.offset == 56
+    assert _lib.gsd_src.w_stride.offset == 48 and _lib.gsd_src.slack.offset == 52 and _lib.gsd_src.n_stride.offset == 56
     assert _lib.gsd_dst.w_stride.offset == 28 and _lib.gsd_dst.n_stride.offset == 32
     assert ctypes.sizeof(_lib.gsd_nhwc) == 8 + 8 + 4 * 4 and _lib.gsd_nhwc.N.offset == 16
 

@@ -676,3 +676,55 @@ def test_conv3x3_wgrad_bn_first_layer(gsd, n, ci, co, h, w, bn):
     rc = gsd.lib.gsd_conv3x3_wgrad_bn(C.byref(aff), dzd.data_ptr(), rawd.data_ptr() if bn else None, *ptrs, ci, co,
                                       dw.data_ptr(), ws.data_ptr(), need, n, h, w, gsd.stream_ptr())
     assert rc != 0 and b"plain" in gsd.lib.gsd_last_error()
+
+
+def with_slack(t, poison=float("nan")):
+    """Copy of a contiguous device tensor with 4 POISONED floats in front of and behind it (what gsd_src.slack = 4 promises to
+    be readable: a value that leaked from there into a result would show)."""
+    buf = torch.full((t.numel() + 8,), poison, device=t.device, dtype=t.dtype)
+    v = buf[4:4 + t.numel()].view(*t.shape)
+    v.copy_(t)
+    return v
+
+
+@pytest.mark.parametrize("n,c0,c1,co,h,w,uh,uw", [(2, 32, 0, 64, 9, 37, 0, 0), (1, 64, 0, 128, 21, 53, 0, 0),
+                                                  (2, 64, 64, 64, 13, 26, 12, 26), (1, 32, 32, 32, 10, 106, 10, 105),
+                                                  (3, 16, 0, 16, 5, 16, 0, 0), (2, 128, 0, 64, 8, 213, 0, 0),
+                                                  (1, 64, 64, 128, 7, 427, 6, 426), (1, 48, 0, 80, 6, 19, 0, 0)])
+def test_conv3x3_wgrad_window_pieces(gsd, n, c0, c1, co, h, w, uh, uw):
+    """Activation windows as 16-byte pieces from unaligned rows (gsd_src.slack >= 4): image widths of every residue mod 4,
+    images narrower than a tile row, two segments with an F.pad offset -- the same bits as the dword-gather form (same
+    products in the same order) and the oracle's numbers; the slack floats are NaN and must not leak."""
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(c0 * 3 + c1 + w)
+    raw0 = rnd(rng, n, c0, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, c0).astype(np.float32), rnd(rng, c0, scale=0.3)
+    a = np.maximum(raw0 * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    r0d, r0s, scd, shd = dev(raw0), with_slack(dev(raw0)), dev(sc), dev(sh)
+    segs = [gsd.make_src(r0d, scd, shd, relu=True)]
+    keep = [r0d]
+    segs_s = [gsd.make_src(r0s, scd, shd, relu=True, slack=4)]
+    if c1:
+        up = rnd(rng, n, c1, uh, uw)
+        upp, (top, left) = on.pad_to(up, h, w)
+        a = np.concatenate([a, upp], 1)
+        upd, ups = dev(up), with_slack(dev(up))
+        segs.append(gsd.make_src(upd, off=(top, left)))
+        segs_s.append(gsd.make_src(ups, off=(top, left), slack=4))
+        keep += [upd, ups]
+    ci = c0 + c1
+    dy = rnd(rng, n, co, h, w)
+    _, dwr = on.conv3x3_bwd(a, np.zeros((co, ci, 3, 3), np.float32), dy, need_dx=False)
+    dyp = pitched(dev(dy))
+    dy_src = gsd.make_src(dyp)
+    need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    outs = []
+    for ss in (segs, segs_s):
+        dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_wgrad(gsd.src_array(ss), len(ss), C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(),
+                                            need, n, h, w, gsd.stream_ptr()))
+        outs.append(dw.cpu().numpy())
+    assert np.isfinite(outs[1]).all()
+    assert rel_l1(outs[1], dwr) < 5e-5
+    assert np.array_equal(outs[0], outs[1])
