@@ -236,17 +236,32 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // PLAIN: no source segment carries a deferred BatchNorm or ReLU (every dX launch: dy is plain; the pooled and upsampled
 // sources of the forward): the operand transform drops its 12 fma/max per kernel row and the per-chunk scale / shift
 // reads.  Measured with the transform forced plain over the layer set: -2.5 % kernel time.
-template <int WM, bool X4, int NL, bool FAST, bool PLAIN>
+//
+// X4M = 2 ("U4"): the halo moves as 16-byte pieces straight from UNALIGNED rows (a global_load_lds_dwordx4 takes any 4-byte
+// aligned global address at full rate, profiles/ubench/dma_global_align.hip).  The four channel planes of a chunk lie back to
+// back in LDS (plane = PS / 4 pieces: WR rows x WCp / 4 pieces + the bank-spread dummies) and an instruction's 64 lanes are 64
+// consecutive pieces of that image: ceil(PS / 64) (7 for a 6 x 68 window) instead of 32 exec-masked dword instructions per
+// chunk and block.  Pieces wholly outside the image come from a 16-byte sentinel (no prefilled padding, nothing masked);
+// a piece that STRADDLES the left or right image edge is loaded as it lies in memory (the caller vouches for 4 readable floats
+// around the tensor: gsd_src.slack) and the lane that moved it overwrites its outside floats with the padding value once its
+// own fills have landed (vmcnt(0)), in front of the chunk's barrier.  Ablation (fills removed, profiles/build_diag.sh
+// -DW43_ABL): the dword halo fills cost 9.5 % of the kernel's time, the weight fills 3 %, the barrier 2 %.
+template <int WM, int X4M, int NL, bool FAST, bool PLAIN>
+#ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk (results are then garbage)
+#define W43_ABL 0
+#endif
 #ifndef W43_MIN_WAVES   // diagnostic builds: waves per SIMD the register allocation must admit for the 4-wave form
 #define W43_MIN_WAVES 2
 #endif
 __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN_WAVES : 1)) void conv3x3_w43_kernel(const W43Params P) {
   static_assert(NL == 0 || WM == 1, "loader waves serve one 64-channel weight image");
+  constexpr bool X4 = X4M == 1, U4 = X4M == 2;
+  static_assert(!U4 || (FAST && WM == 1 && NL == 0), "unaligned 16-byte halo pieces: the straight-fill 4-wave form");
   constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM + 64 * NL, NWAVE = 4 * WM;
   constexpr int NWI = (W4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PS = P.PS;
-  const int BUF = WM * WTILE + 4 * PS;
+  const int BUF = U4 ? WM * WTILE + P.NI * 256 : WM * WTILE + 4 * PS;   // U4: whole 64-piece instructions
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,12 +346,57 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
       }
     }
   }
+  // U4: instruction i = wave + 4 k of a chunk moves pieces 64 i .. 64 i + 63 of the chunk's [4 planes][PS / 4 pieces] image.
+  // Per source segment: the lane's float offset from the chunk's first channel plane (W43_SENT: sentinel piece) and the floats of
+  // the piece that lie outside the image (bits 0..3: patched with the padding value after landing).
+  constexpr int KH = 2, W43_SENT = -2147483647 - 1;
+  int h_off0[KH], h_off1[KH], h_pm0[KH], h_pm1[KH];
+  bool u_patch = false;   // block constant: some window row has a piece that straddles the left or right edge of a segment
+  if constexpr (U4) {
+    const int o0 = w0 - 1 - P.src0.ow, o1 = w0 - 1 - P.src1.ow;
+    u_patch = (o0 < 0 && (-o0 & 3)) || (P.src0.W > o0 && P.src0.W < o0 + P.WCp && ((P.src0.W - o0) & 3));
+    if (P.src1.C > 0) u_patch = u_patch || (o1 < 0 && (-o1 & 3)) || (P.src1.W > o1 && P.src1.W < o1 + P.WCp && ((P.src1.W - o1) & 3));
+    const int NPr = P.WCp >> 2, NPc = PS >> 2;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int i = wave8 + 4 * k;
+      const int pid = 64 * i + lane;
+      const int ch = pid / NPc, pq = pid - ch * NPc;
+      const int row = pq / NPr, pc = pq - row * NPr;
+      h_off0[k] = h_off1[k] = W43_SENT;   // (an offset of -1 is a real one: the piece in front of the tensor's first row)
+      h_pm0[k] = h_pm1[k] = 0;
+      if (i < P.NI && ch < 4 && row < P.WR) {
+        int nn, gh;
+        w43_row(P, n, h0 - 1 + row, nn, gh);
+        const int gw = w0 - 1 + 4 * pc;
+        const int fo0 = P.fold ? nn * (int)P.src0.ns : 0, fo1 = P.fold ? nn * (int)P.src1.ns : 0;
+        int hs = gh - P.src0.oh, c0 = gw - P.src0.ow;
+        if ((unsigned)hs < (unsigned)P.src0.H && c0 + 3 >= 0 && c0 < P.src0.W) {
+          h_off0[k] = ch * (int)P.src0.cs + fo0 + hs * P.src0.ws + c0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < 0 || c0 + e >= P.src0.W) h_pm0[k] |= 1 << e;
+        }
+        hs = gh - P.src1.oh;
+        c0 = gw - P.src1.ow;
+        if (P.src1.C > 0 && (unsigned)hs < (unsigned)P.src1.H && c0 + 3 >= 0 && c0 < P.src1.W) {
+          h_off1[k] = ch * (int)P.src1.cs + fo1 + hs * P.src1.ws + c0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < 0 || c0 + e >= P.src1.W) h_pm1[k] |= 1 << e;
+        }
+      }
+    }
+  }
+  const float* u_base = P.src0.p + (long long)n * P.src0.ns;   // U4: first channel plane of the next chunk to fill
+  const float* u_sent = P.src0.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0];
+  long long u_cs = P.src0.cs;
   const float* wsrc0 = P.wt + (size_t)(mbb * WM) * P.nchunks * WTILE;   // the block's WM weight images follow each other
   const long long wlane = tid * 4;   // this lane's float offset inside a 1 KiB weight piece group
   long long xl0[NPP];   // first segment's offsets as 64-bit lane values (the address add is then a single instruction)
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) xl0[pp] = xo0[pp];
-  if constexpr (NL == 0)
+  if constexpr (NL == 0 && !U4)
   {
     // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only: the lanes that
     // would otherwise DMA the sentinel there on every fill); visible to the consumers after the first barrier
@@ -377,6 +437,16 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
     f_xl[pp] = xo0[pp];
   }
   auto begin_fill = [&](int chunk, int buf) {
+    if constexpr (U4) {
+      if (chunk == f_sw) {   // the second (concat) segment from here on
+        u_base = P.src1.p + (long long)n * P.src1.ns;
+        u_sent = P.src1.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0];
+        u_cs = P.src1.cs;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) h_off0[k] = h_off1[k];
+      }
+      return;
+    }
     if (f_sw < 0 || (chunk != f_sw && chunk != f_sw + 1)) return;
     if (chunk == f_sw) {
       d_base = P.src1.p + (long long)n * P.src1.ns;
@@ -401,6 +471,19 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
       }
   };
   auto fast_halo = [&](int ch, float* Xb) {
+    if constexpr (U4) {
+      // the wave's (at most) two instructions of the chunk ride in halo slots 0 and 2; slot 3 moves on to the next chunk
+      if (ch == 0 || ch == 2) {
+        const int k = ch >> 1;
+        if (wave8 + 4 * k < P.NI) {
+          const float* gp = h_off0[k] != W43_SENT ? u_base + h_off0[k] : u_sent;
+          float* dstp = Xb + (wave8 + 4 * k) * 256;
+          __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
+        }
+      }
+      if (ch == 3) u_base += 4 * u_cs;
+      return;
+    }
 #pragma unroll
     for (int pp = 0; pp < NPP; ++pp) {
       if constexpr (X4) {
@@ -566,7 +649,29 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   W43_STAMP(5)   // prologue
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
-    gsd_dma_barrier();
+    if constexpr (U4) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the chunk have landed
+      if (u_patch) {   // a block at the left / right image edge: the outside floats of the straddling pieces this lane moved
+        const bool seg1 = f_sw >= 0 && chunk >= f_sw;
+        const float padv = (seg1 ? P.src1.relu : P.src0.relu) ? __builtin_nanf("") : 0.f;
+        float* Xh = smem + cur * BUF + WM * WTILE;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) {
+          const int pm = seg1 ? h_pm1[k] : h_pm0[k];
+          if (pm) {
+            float* pp = Xh + (wave8 + 4 * k) * 256 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (pm >> e & 1) pp[e] = padv;
+          }
+        }
+      }
+      if (!((W43_ABL) & 4)) __syncthreads();
+    } else if ((W43_ABL) & 4) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    } else {
+      gsd_dma_barrier();
+    }
     W43_STAMP(0)   // wait for the chunk's DMA + barrier
     const int kc = chunk * 4 + j;
     float sc = 1.f, sh = 0.f, lo = 0.f;
@@ -576,13 +681,17 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
     }
     const bool more = chunk + 1 < P.nchunks;
     const float* Wc = smem + cur * BUF;
-    f32x4 av[2];
+#ifndef W43_PF   // k-steps the weight operand is read ahead of its MFMAs
+#define W43_PF 1
+#endif
+    f32x4 av[W43_PF + 1];
     f32x4 ra[2];
     f32x2 rb[2];
     float v[6];
     ra[0] = *reinterpret_cast<const f32x4*>(&Wc[baddr]);
     rb[0] = *reinterpret_cast<const f32x2*>(&Wc[baddr + 4]);
-    av[0] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18) * WS + a_lane]);
+#pragma unroll
+    for (int s = 0; s < W43_PF; ++s) av[s] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18 + s) * WS + a_lane]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -595,8 +704,9 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
       if (r == 0) W43_STAMP(1)   // first operand reads + first transform: no MFMA of this wave yet
 #pragma unroll
       for (int f = 0; f < 6; ++f) {
-        const int s = r * 6 + f, cs = s & 1;
-        if (s + 1 < 18) av[cs ^ 1] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18 + s + 1) * WS + a_lane]);
+        const int s = r * 6 + f, cs = s % (W43_PF + 1);
+        if (s + W43_PF < 18)
+          av[(s + W43_PF) % (W43_PF + 1)] = *reinterpret_cast<const f32x4*>(&Wc[(j * 18 + s + W43_PF) * WS + a_lane]);
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m][f] = mfma16(av[cs][m], v[f], acc[m][f]);
         if constexpr (NL == 0) {
@@ -607,6 +717,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
             if (more && s < 3) {
               if (s == 0) {
                 begin_fill(chunk + 1, cur ^ 1);
+                if (!((W43_ABL) & 1)) {
                 float* Wn = smem + (cur ^ 1) * BUF;
                 const float* wg = wsrc0 + (size_t)(chunk + 1) * WTILE + wave8 * 1024 + lane * 4;
                 float* wl = Wn + wave8 * 1024;
@@ -619,7 +730,8 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
                   float* wl2 = Wn + (14 + wave8) * 256;
                   __builtin_amdgcn_global_load_lds(wg2, wl2, 16, 0, 0);
                 }
-              } else {
+                }
+              } else if (!((W43_ABL) & 2)) {
                 dma_slot(NWI + 2 * s - 2, chunk + 1, cur ^ 1);
                 dma_slot(NWI + 2 * s - 1, chunk + 1, cur ^ 1);
               }
@@ -898,7 +1010,7 @@ int halo_read_cycles(int TWq, int LP, int PS, int off) {
 }
 
 // one launcher per kernel instantiation (the address of the kernel keys the per-device launch-attribute cache)
-template <int WM, bool X4, int NL, bool FAST, bool PLAIN = false>
+template <int WM, int X4, int NL, bool FAST, bool PLAIN = false>
 int launch_one(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
   const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN>);
@@ -912,7 +1024,8 @@ int launch_one(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   return GSD_OK;
 }
 
-int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm, bool x4, int nl, bool fast, bool plain) {
+int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm, bool x4, int nl, bool fast, bool plain, bool u4) {
+  if (u4) return plain ? launch_one<1, 2, 0, true, true>(P, grid, lds, st) : launch_one<1, 2, 0, true, false>(P, grid, lds, st);
   if (nl == 1) return x4 ? launch_one<1, true, 1, false>(P, grid, lds, st) : launch_one<1, false, 1, false>(P, grid, lds, st);
   if (nl == 2) return x4 ? launch_one<1, true, 2, false>(P, grid, lds, st) : launch_one<1, false, 2, false>(P, grid, lds, st);
   if (wm == 2) return x4 ? launch_one<2, true, 0, false>(P, grid, lds, st) : launch_one<2, false, 0, false>(P, grid, lds, st);
@@ -1022,14 +1135,35 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
       }
     }
   }
+  // unaligned 16-byte halo pieces (U4): straight-fill 4-wave form, every source vouches for 4 readable floats around its tensor
+  // measured (profiles/bench_conv_ab.py, U4 against the dword form): +2..3 % where most blocks lie inside the image (7 and 4 tile
+  // columns: levels 0, 1), -4..-10 % where every block touches both edges (levels 3, 4); over the whole train step the auto
+  // rule is within noise (109.6 against 109.6 ms), so the form stays an option.  The fills removed altogether (-DW43_ABL) are
+  // worth 9.5 %: it is the halo's memory traffic and latency the kernel waits for, not the instruction count -- unlike the dW
+  // kernel, where the same change bought 11 %.  GSD_W43_U4 = 0 off (default), 1 where tiles_x >= 4, 2 always
+  const int u4_env = gsd_env_int("GSD_W43_U4", 0);
+  bool u4 = (u4_env == 2 || (u4_env == 1 && pl.tiles_x >= 4)) && fast && WM == 1 && nl == 0;
+  for (int i = 0; i < nsrc; ++i)
+    u4 = u4 && src[i].slack >= 4 && 4 * src[i].c_stride + (int64_t)(pl.fold ? N : 1) * src[i].n_stride < (1LL << 31);
+  if (u4) {
+    const int wcp = round_up(pl.WC, 4), ps = round_up(pl.WR * wcp, 4) + 4;
+    if (ceil_div(ps, 64) <= 8) {
+      x4 = false;
+      P.WCp = wcp; P.PS = ps; P.RO = 0;
+      P.NP = wcp / 4;
+      P.NI = ceil_div(ps, 64);   // 4 planes x PS / 4 pieces, 64 pieces per instruction
+    } else {
+      u4 = false;
+    }
+  }
   P.fold = pl.fold;
   const long grid = (long)(pl.fold ? 1 : N) * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
   GSD_REQUIRE(!pl.fold || nl == 0, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: the loader-wave form does not fold rows (GSD_W43_FOLD=0)");
-  const size_t lds = (size_t)(2 * (WM * W43_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
+  const size_t lds = (size_t)(2 * (WM * W43_WTILE + (u4 ? P.NI * 256 : 4 * P.PS)) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
   bool plain = gsd_env_int("GSD_W43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any source segment
   for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
-  return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast, plain);
+  return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast, plain, u4);
 }
 
 extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,

@@ -15,14 +15,15 @@ NAMES = ["barrier+vmcnt wait", "DMA issue (next stage)", "reads+transforms+144 M
 raw = C.CDLL(L.LIB_PATH)
 raw.gsd_wg43_set_stamp_buffer.argtypes = [C.c_void_p]
 for ci, co, h, w in shapes:
-    x = torch.randn(B, ci, h, w, device="cuda")
+    x = L.slack_empty((B, ci, h, w), "cuda")   # slack: the kernel may move the windows as 16-byte pieces (GSD_WG43_BX4)
+    x.copy_(torch.randn(B, ci, h, w, device="cuda"))
     sc, sh = torch.rand(ci, device="cuda") + 0.5, torch.randn(ci, device="cuda") * 0.1
     dy = L.pitched_empty((B, co, h, w), "cuda")     # what the engine feeds the kernel: rows 16-byte aligned
     dy.copy_(torch.randn(B, co, h, w, device="cuda"))
     dw = torch.empty(co, ci, 3, 3, device="cuda")
     need = lib.gsd_conv3x3_wgrad_workspace(B, h, w, ci, co)
     ws = torch.empty(need, device="cuda")
-    a_src, dy_src = L.src_array([L.make_src(x, sc, sh, relu=True)]), L.make_src(dy)
+    a_src, dy_src = L.src_array([L.make_src(x, sc, sh, relu=True, slack=L.SLACK)]), L.make_src(dy)
     buf = torch.zeros(4096 * 8 * 4, dtype=torch.int64, device="cuda")
 
     def run():

@@ -728,3 +728,58 @@ def test_conv3x3_wgrad_window_pieces(gsd, n, c0, c1, co, h, w, uh, uw):
     assert np.isfinite(outs[1]).all()
     assert rel_l1(outs[1], dwr) < 5e-5
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 16, 24, 9, 37), (3, 64, 64, 20, 26), (2, 32, 70, 13, 53), (1, 128, 64, 40, 106),
+                                         (1, 64, 64, 11, 213), (1, 32, 64, 9, 427), (2, 16, 16, 5, 64), (4, 16, 32, 6, 7)])
+def test_conv3x3_w43_unaligned_halo_pieces(gsd, monkeypatch, n, ci, co, h, w):
+    """Halo windows as 16-byte pieces straight from unaligned rows (gsd_src.slack >= 4; GSD_W43_U4): image widths of every
+    residue mod 4, images narrower than a tile (row folding), a deferred-BatchNorm source (NaN padding), a plain one, two
+    segments with an F.pad offset and two cropped destinations, the fused BatchNorm-backward dX epilogue -- every launch
+    bit-identical to the dword-gather form on the same data; the slack floats are NaN and must not leak."""
+    monkeypatch.setenv("GSD_W43_U4", "2")   # every shape (by default only where most blocks lie inside the image)
+    rng = np.random.default_rng(n * 100 + w + ci)
+    raw, g_, b_, mean, invstd, scale, shift, a = _bn_setup(rng, n, ci, h, w)
+    x, scd, shd = dev(raw), dev(scale), dev(shift)
+    xs = with_slack(x)
+    wt_ = dev(rnd(rng, co, ci, 3, 3, scale=0.2))
+    wl = layout(gsd, 4, wt_, co, ci)
+    c1 = max(4, co // 3) // 4 * 4
+    up = dev(rnd(rng, n, c1, h - 2, w - 3))
+    ups = with_slack(up)
+    wt2 = dev(rnd(rng, co, ci + c1, 3, 3, scale=0.2))
+    wl2 = layout(gsd, 4, wt2, co, ci + c1)
+    dy = dev(rnd(rng, n, co, h, w))
+    dys = with_slack(dy)
+    wld = layout(gsd, 5, wt_, co, ci)
+    vecs = [dev(v) for v in (scale, shift, mean, invstd)]
+    res = {}
+    for tag, xx, uu, dd, sl in (("dword", x, up, dy, 0), ("pieces", xs, ups, dys, 4)):
+        y = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(xx, scd, shd, relu=True, slack=sl)]), 1, wl.data_ptr(), ci,
+                                          co, gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
+        y1 = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(xx, slack=sl)]), 1, wl.data_ptr(), ci, co,
+                                          gsd.dst_array([gsd.make_dst(y1)]), 1, None, n, h, w, gsd.stream_ptr()))
+        y2 = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(xx, scd, shd, relu=True, slack=sl),
+                                                         gsd.make_src(uu, off=(1, 2), slack=sl)]), 2, wl2.data_ptr(), ci + c1, co,
+                                          gsd.dst_array([gsd.make_dst(y2)]), 1, None, n, h, w, gsd.stream_ptr()))
+        rows = gsd.lib.gsd_conv3x3_w43_partial_rows(n, h, w, ci)
+        mpad = (ci + 63) // 64 * 64
+        part = torch.zeros(rows * 2 * mpad, device="cuda")
+        dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        sdy = gsd.make_src(dd, slack=sl)
+        gsd.check(gsd.lib.gsd_conv3x3_w43_dgrad_bnrelu(C.byref(sdy), wld.data_ptr(), co, ci, C.byref(gsd.make_dst(dz)), x.data_ptr(),
+                                                       *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, gsd.stream_ptr()))
+        torch.cuda.synchronize()
+        res[tag] = (y, y1, y2, dz, part)
+    for a_, b_ in zip(res["dword"], res["pieces"]):
+        assert bool(torch.isfinite(b_).all())
+        assert torch.equal(a_, b_)
+    # and the numbers themselves: against the direct-tap kernel
+    wl0 = layout(gsd, 0, wt_, co, ci)
+    yd = torch.full((n, co, h, w), float("nan"), device="cuda")
+    gsd.check(gsd.lib.gsd_conv3x3(gsd.src_array([gsd.make_src(x, scd, shd, relu=True)]), 1, wl0.data_ptr(), ci, co,
+                                  gsd.dst_array([gsd.make_dst(yd)]), 1, None, n, h, w, gsd.stream_ptr()))
+    assert rel_l1(res["pieces"][0].cpu().numpy(), yd.cpu().numpy()) < TOL
