@@ -247,7 +247,7 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // own fills have landed (vmcnt(0)), in front of the chunk's barrier.  Ablation (fills removed, profiles/build_diag.sh
 // -DW43_ABL): the dword halo fills cost 9.5 % of the kernel's time, the weight fills 3 %, the barrier 2 %.
 template <int WM, int X4M, int NL, bool FAST, bool PLAIN>
-#ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk (results are then garbage)
+#ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk, 8 no wait for the fills (results are then garbage)
 #define W43_ABL 0
 #endif
 #ifndef W43_MIN_WAVES   // diagnostic builds: waves per SIMD the register allocation must admit for the 4-wave form
@@ -669,6 +669,8 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
       if (!((W43_ABL) & 4)) __syncthreads();
     } else if ((W43_ABL) & 4) {
       __builtin_amdgcn_s_waitcnt(0x0F70);
+    } else if ((W43_ABL) & 8) {   // barrier without waiting for the fills: what their latency costs
+      __syncthreads();
     } else {
       gsd_dma_barrier();
     }
