@@ -811,10 +811,13 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
         const int sm = co_ok ? (first ? sm0 : sm1) : 0;
         float y[4];
         out_transform(m, reg, y);
+        // statistics over the pixels that are STORED (the destination's window: for a cropped second destination -- the
+        // backward of F.pad -- the sums are those of the crop, e.g. the ConvT bias gradient; the same pixels as `vmask` for a
+        // full-size destination)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (vmask >> i & 1) {
+          if (sm >> i & 1) {
             s1 += y[i];
             s2 = fmaf(y[i], y[i], s2);
           }

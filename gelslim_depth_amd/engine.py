@@ -191,6 +191,8 @@ class UNetEngine:
                                  for l in range(1, self.L + 1)] if train else [None] * self.L)
         self.gp = torch.empty((max_gp,), **f32) if (train and max_gp) else None   # pitched d_raw scratch, one unit at a time
         self.partials = torch.empty((max_part,), **f32)
+        # fp64 column sums of a dX launch's statistics (ConvT bias gradients): gsd_bn_reduce_partials wants (1 + 64) x 2 C doubles
+        self.db_sums = torch.empty((65 * 2 * max(u.cin for u in self.units),), device=dev, dtype=torch.float64) if train else None
         self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
 
     # ------------------------------------------------------------------ helpers
@@ -361,15 +363,18 @@ class UNetEngine:
                                     self.n_classes, u.g.data_ptr(), self.partials.data_ptr(), n, u.cout, lh, lw, st),
               "bn_bwd_reduce")
 
-    def _dgrad(self, u: _Unit, P, dsts: List[L.gsd_dst], st: int) -> None:
+    def _dgrad(self, u: _Unit, P, dsts: List[L.gsd_dst], st: int, stats: bool = False) -> int:
+        """dX of unit u into the destination segments.  stats: the launch also leaves per-channel partial sums of what it
+        stored in self.partials (the conv epilogue's BatchNorm-statistics path); returns their row count."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
         check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.src_array([L.make_src(u.dsrc)])
         ev = self._log_begin()
-        check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts), None, n, lh, lw, st),
-              "conv3x3 dgrad")
+        check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts),
+                            self.partials.data_ptr() if stats else None, n, lh, lw, st), "conv3x3 dgrad")
         self._log_end(ev, u.cin, u.cout, n, lh, lw, u.form_d.algo)
+        return u.form_d.partial_rows(n, lh, lw, u.cin) if stats else 0
 
     def _dgrad_fused(self, u: _Unit, prev: _Unit, P, st: int) -> None:
         """dX of unit u straight into prev.g as dz of prev's relu(bn(.)) (+ partial sums): u's input is prev's output."""
@@ -408,14 +413,21 @@ class UNetEngine:
             self._dgrad_fused(u1, u0, P, st)
             self._bn_bwd_tail(u0, P, G, st, fused=True)
             skip = self.enc[lvl][1]
-            self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st)
+            # the ConvT bias gradient is the per-channel sum of up.dout: the Winograd dX launch that writes up.dout leaves it
+            # as statistics of its second (cropped) destination -- no second pass over up.dout
+            db_fused = u0.form_d.algo == 1
+            rows = self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st, stats=db_fused)
+            if db_fused:
+                check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u0.cin), u0.cin, self.db_sums.data_ptr(),
+                                                 st), "bn_reduce_partials")
+                G[up.bname].copy_(self.db_sums[skip.cout:skip.cout + up.cout])
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
             xs = self._act_src(prev)
             dys = L.make_src(up.dout)
             check(lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
-                                         G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, hi, wi,
-                                         st), "convT2x2_wgrad")
+                                         None if db_fused else G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(),
+                                         self.wgrad_ws.numel(), n, hi, wi, st), "convT2x2_wgrad")
             check(lib.gsd_weight_layout(3, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
             check(lib.gsd_convT2x2_dgrad(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
