@@ -109,10 +109,16 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // is loaded as it lies in memory (its outside part is the neighbouring row's data: the caller guarantees 4 readable floats
 // before and after the tensor, gsd_src.slack) and the block overwrites that part with the padding value after the fills have
 // landed -- one more barrier, on the stages that touch a vertical edge only.
-template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4>
+//
+// RR (the 4 x 16 stage, TWq == 4: k-step ks is tile row ks, lane group j tile column j): window row w feeds tile rows w-2, w-1, w
+// -- as kernel rows 2, 1, 0 -- with the SAME six values for a lane, so its B^T relu(bn(.)) is computed once and kept across
+// the k-steps (a ring of three rows): 6 row transforms and window reads per stage instead of 12; same products in the same
+// order, bit-identical.
+template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4, bool RR>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
   static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
   static_assert(!BX4 || (AX4 && !R3), "16-byte window pieces come with 16-byte dy pieces and two LDS images");
+  static_assert(!RR || BX4, "row reuse is instantiated for the 16-byte-piece form only");
   constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
           rbase += rstep;
         }
       } else {
-#pragma unroll 4
+#pragma unroll 1
         for (int i = 0; i < ninstr; ++i) {
           const float* g = (pix_ok && m0 + 4 * (wave + NW * i) + a_lr < P.M) ? rbase : &gsd_zero16_wg43[0];
           __builtin_amdgcn_global_load_lds(g, Ab + (wave + NW * i) * (4 * DS), 16, 0, 0);
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
             if (!skipB) __builtin_amdgcn_global_load_lds(gp, dstp, 16, 0, 0);
           }
       } else {
-#pragma unroll
+#pragma unroll 1   // (edge stages: one piece at a time keeps the address temporaries of four out of the register budget)
         for (int k = 0; k < KB; ++k)
           if (wave + NW * k < NI) {
             const int m = x_meta[k];
@@ -439,8 +445,83 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   }
 
   // `late`: issue the next stage's DMA after the first k-step instead of in front of the stage (see the stage loop)
+  auto row_transform = [&](const f32x4& xa, const f32x2w& xb, float (&v)[6]) {   // B^T relu(bn(raw)) of one window row
+    float d0 = xa[0], d1 = xa[1], d2 = xa[2], d3 = xa[3], d4 = xb[0], d5 = xb[1];
+    if constexpr (!PLAIN) {
+      d0 = fmaxf(fmaf(d0, sc, sh), lo), d1 = fmaxf(fmaf(d1, sc, sh), lo), d2 = fmaxf(fmaf(d2, sc, sh), lo);
+      d3 = fmaxf(fmaf(d3, sc, sh), lo), d4 = fmaxf(fmaf(d4, sc, sh), lo), d5 = fmaxf(fmaf(d5, sc, sh), lo);
+    }
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = 2.f * (d3 - d1);
+    v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    v[1] = a + b;
+    v[2] = a - b;
+    v[3] = c + e;
+    v[4] = c - e;
+    v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  };
   auto compute = [&](int cur, bool late, int next_stage, bool more) {
     const float* Sb = smem + cur * BUF;
+    if constexpr (RR) {
+      // b_off[0] = this lane's channel plane + 4 j: window row w of tile column j is at + w * WCp
+      f32x4 ya[2][MT];
+      f32x4 xa;
+      f32x2w xb;
+      float V[3][6];   // V[w % 3]: window row w
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ya[0][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[0] + m * 16 * DS]);
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        xa = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + w * P.WCp]);
+        xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + w * P.WCp + 4]);
+        row_transform(xa, xb, V[w]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cb = ks & 1, nb2 = cb ^ 1;
+        if (ks + 1 < 4) {   // the next k-step's dy tile and the one new window row fly during this k-step's MFMAs
+#pragma unroll
+          for (int m = 0; m < MT; ++m) ya[nb2][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[ks + 1] + m * 16 * DS]);
+#ifndef WG43_RR_LATE_READ
+          xa = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + (ks + 3) * P.WCp]);
+          xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (ks + 3) * P.WCp + 4]);
+#endif
+        }
+        float U[MT][6];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {   // U = A dy
+          const float y0 = ya[cb][m][0], y1 = ya[cb][m][1], y2 = ya[cb][m][2], y3 = ya[cb][m][3];
+          const float p = y0 + y2, q = y1 + y3;
+          const float a = fmaf(4.f, y2, y0), b = 2.f * fmaf(4.f, y3, y1);
+          U[m][0] = y0;
+          U[m][1] = p + q;
+          U[m][2] = p - q;
+          U[m][3] = a + b;
+          U[m][4] = a - b;
+          U[m][5] = y3;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[(ks + r) % 3][f], acc[m][r * 6 + f]);
+#ifdef WG43_RR_LATE_READ
+        if (ks + 1 < 4) {
+          xa = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + (ks + 3) * P.WCp]);
+          xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (ks + 3) * P.WCp + 4]);
+        }
+#endif
+        if (ks + 1 < 4) row_transform(xa, xb, V[ks % 3]);   // window row ks + 3 takes the place of row ks
+        if (ks == 0 && late && more) {
+          WG43_STAMP(2)
+          issue_dma(next_stage, cur ^ 1);
+          WG43_STAMP(1)
+        }
+      }
+      WG43_STAMP(2)
+      return;
+    }
     f32x4 ya[2][MT];
     f32x4 ra[2][3];
     f32x2w rb[2][3];
@@ -736,6 +817,8 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
     if (fits) P.XS = xs;
     else bx4 = false;
   }
+  // row reuse: the 4 x 16 stage (k-step = tile row)
+  const bool rr = bx4 && gsd_env_int("GSD_WG43_RR", 1) != 0 && pl.TW == 16 && pl.TH == 4;
   const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + (bx4 ? (pl.BN * (P.XS / 4) + 63) / 64 * 256 : pl.BN * P.XS)) * sizeof(float);
   const bool r3 = gsd_env_int("GSD_WG43_R3", 0) != 0 && eight && 3 * img <= 160 * 1024;
   const size_t lds = (r3 ? 3 : 2) * img;
@@ -744,38 +827,44 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
   // one launcher per instantiation: the kernel's address keys the per-device cache of the launch attribute (gsd_common.h)
-#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_, PL_, BX_)                                                                          \
+#define WG43_LAUNCH(NWM_, NWN_, AX4_, R3_, PL_, BX_, RR_)                                                                          \
   do {                                                                                                                  \
     static gsd_attr_once once;                                                                                          \
-    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_>);                          \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_, RR_>);                          \
     if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                                  \
       gsd_set_error("gsd_conv3x3_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));                                \
       return GSD_ERR_HIP;                                                                                               \
     }                                                                                                                   \
-    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
+    hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_, RR_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
   } while (0)
   if (pl.BM == 128) {
-    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false, false);
-    else if (bx4 && plain) WG43_LAUNCH(4, 2, true, false, true, true);
-    else if (bx4) WG43_LAUNCH(4, 2, true, false, false, true);
-    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true, false);
-    else if (ax4) WG43_LAUNCH(4, 2, true, false, false, false);
-    else if (r3) WG43_LAUNCH(4, 2, false, true, false, false);
-    else WG43_LAUNCH(4, 2, false, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false, false, false);
+    else if (bx4 && rr && plain) WG43_LAUNCH(4, 2, true, false, true, true, true);
+    else if (bx4 && rr) WG43_LAUNCH(4, 2, true, false, false, true, true);
+    else if (bx4 && plain) WG43_LAUNCH(4, 2, true, false, true, true, false);
+    else if (bx4) WG43_LAUNCH(4, 2, true, false, false, true, false);
+    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true, false, false);
+    else if (ax4) WG43_LAUNCH(4, 2, true, false, false, false, false);
+    else if (r3) WG43_LAUNCH(4, 2, false, true, false, false, false);
+    else WG43_LAUNCH(4, 2, false, false, false, false, false);
   } else if (pl.BN == 64) {
-    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false, false);
-    else if (bx4 && plain) WG43_LAUNCH(2, 4, true, false, true, true);
-    else if (bx4) WG43_LAUNCH(2, 4, true, false, false, true);
-    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true, false);
-    else if (ax4) WG43_LAUNCH(2, 4, true, false, false, false);
-    else if (r3) WG43_LAUNCH(2, 4, false, true, false, false);
-    else WG43_LAUNCH(2, 4, false, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false, false, false);
+    else if (bx4 && rr && plain) WG43_LAUNCH(2, 4, true, false, true, true, true);
+    else if (bx4 && rr) WG43_LAUNCH(2, 4, true, false, false, true, true);
+    else if (bx4 && plain) WG43_LAUNCH(2, 4, true, false, true, true, false);
+    else if (bx4) WG43_LAUNCH(2, 4, true, false, false, true, false);
+    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true, false, false);
+    else if (ax4) WG43_LAUNCH(2, 4, true, false, false, false, false);
+    else if (r3) WG43_LAUNCH(2, 4, false, true, false, false, false);
+    else WG43_LAUNCH(2, 4, false, false, false, false, false);
   } else {
-    if (bx4 && plain) WG43_LAUNCH(2, 2, true, false, true, true);
-    else if (bx4) WG43_LAUNCH(2, 2, true, false, false, true);
-    else if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true, false);
-    else if (ax4) WG43_LAUNCH(2, 2, true, false, false, false);
-    else WG43_LAUNCH(2, 2, false, false, false, false);
+    if (bx4 && rr && plain) WG43_LAUNCH(2, 2, true, false, true, true, true);
+    else if (bx4 && rr) WG43_LAUNCH(2, 2, true, false, false, true, true);
+    else if (bx4 && plain) WG43_LAUNCH(2, 2, true, false, true, true, false);
+    else if (bx4) WG43_LAUNCH(2, 2, true, false, false, true, false);
+    else if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true, false, false);
+    else if (ax4) WG43_LAUNCH(2, 2, true, false, false, false, false);
+    else WG43_LAUNCH(2, 2, false, false, false, false, false);
   }
 #undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
