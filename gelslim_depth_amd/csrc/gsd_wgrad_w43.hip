@@ -107,8 +107,8 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // that image, whichever channels and rows they fall into: 16 instead of 64 instructions per stage for 32 channels of a 6 x 20
 // window.  Pieces wholly outside the image come from a 16-byte sentinel; a piece that STRADDLES the left or right image edge
 // is loaded as it lies in memory (its outside part is the neighbouring row's data: the caller guarantees 4 readable floats
-// before and after the tensor, gsd_src.slack) and the block overwrites that part with the padding value after the fills have
-// landed -- one more barrier, on the stages that touch a vertical edge only.
+// before and after the tensor, gsd_src.slack) and the lane that moved it overwrites that part with the padding value once its
+// own fills have landed (vmcnt(0)), in front of the stage's barrier.
 //
 // RR (the 4 x 16 stage, TWq == 4: k-step ks is tile row ks, lane group j tile column j): window row w feeds tile rows w-2, w-1, w
 // -- as kernel rows 2, 1, 0 -- with the SAME six values for a lane, so its B^T relu(bn(.)) is computed once and kept across
@@ -618,20 +618,28 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     WG43_STAMP(3)   // prologue
     for (int it = 0; it < nst; ++it) {
       const int cur = it & 1;
-      gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
       if constexpr (BX4) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the stage have landed
         const int fx = cur ? fix1 : fix0;
-        if (fx) {   // a stage at the left / right image edge: the outside part of its straddling pieces gets the padding value
+        if (fx) {   // a stage at the left / right image edge: the outside floats of the straddling pieces THIS lane moved get the
+                    // padding value (behind the lane's own fills, in front of the barrier: no second barrier)
           float* Bb = smem + cur * BUF + BM * DS;
           const int gl0 = fx & 255, gl1 = fx >> 8 & 255, gr0 = fx >> 16 & 255, gr1 = fx >> 24 & 255;
-          for (int idx = tid; idx < BN * P.WR; idx += 64 * NW) {
-            const int pl = idx / P.WR, row = idx - pl * P.WR;
-            float* rp = Bb + pl * XS + row * P.WCp;
-            for (int c = gl0; c < gl1; ++c) rp[c] = padv;
-            for (int c = gr0; c < gr1; ++c) rp[c] = padv;
+#pragma unroll
+          for (int k = 0; k < KB; ++k) {
+            const int m = x_meta[k];
+            if (wave + NW * k < NI && m >= 0) {
+              const int c0 = m >> 8 & 255;
+              float* pp = Bb + (wave + NW * k) * 256 + lane * 4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if ((c0 + e >= gl0 && c0 + e < gl1) || (c0 + e >= gr0 && c0 + e < gr1)) pp[e] = padv;
+            }
           }
-          __syncthreads();
         }
+        __syncthreads();   // everyone's fills (and patches) are in; everyone has left the other image
+      } else {
+        gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
       }
       WG43_STAMP(0)
       // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
