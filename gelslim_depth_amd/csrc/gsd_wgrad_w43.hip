@@ -512,7 +512,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
           xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (ks + 3) * P.WCp + 4]);
         }
 #endif
+#if defined(WG43_ABL) && ((WG43_ABL) & 8)   // diagnostic: no row transform after the first three
+        if (ks + 1 < 4) { V[ks % 3][0] = xa[0]; V[ks % 3][1] = xa[1]; V[ks % 3][2] = xa[2]; V[ks % 3][3] = xa[3]; V[ks % 3][4] = xb[0]; V[ks % 3][5] = xb[1]; }
+#else
         if (ks + 1 < 4) row_transform(xa, xb, V[ks % 3]);   // window row ks + 3 takes the place of row ks
+#endif
         if (ks == 0 && late && more) {
           WG43_STAMP(2)
           issue_dma(next_stage, cur ^ 1);
@@ -637,7 +641,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
             }
           }
         }
+#if defined(WG43_ABL) && ((WG43_ABL) & 4)   // diagnostic: no barrier per stage (results are then garbage)
+#else
         __syncthreads();   // everyone's fills (and patches) are in; everyone has left the other image
+#endif
       } else {
         gsd_dma_barrier();   // this stage's DMA has landed; everyone has left the other image
       }
