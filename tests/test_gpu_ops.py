@@ -783,3 +783,38 @@ def test_conv3x3_w43_unaligned_halo_pieces(gsd, monkeypatch, n, ci, co, h, w):
     gsd.check(gsd.lib.gsd_conv3x3(gsd.src_array([gsd.make_src(x, scd, shd, relu=True)]), 1, wl0.data_ptr(), ci, co,
                                   gsd.dst_array([gsd.make_dst(yd)]), 1, None, n, h, w, gsd.stream_ptr()))
     assert rel_l1(res["pieces"][0].cpu().numpy(), yd.cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 32, 64, 12, 37), (1, 64, 128, 8, 64), (2, 128, 64, 9, 50)])
+def test_winograd_instantiation_switches_are_bit_identical(gsd, monkeypatch, n, ci, co, h, w):
+    """The tuning switches only choose between instantiations that multiply the same numbers in the same order: window-row
+    reuse in the dW kernel (GSD_WG43_RR), plain-source transforms in dW and conv (GSD_WG43_PLAIN / GSD_W43_PLAIN)."""
+    rng = np.random.default_rng(ci + co + w)
+    x = with_slack(dev(rnd(rng, n, ci, h, w)), poison=0.0)
+    sc, sh = dev(rng.uniform(0.5, 1.5, ci).astype(np.float32)), dev(rnd(rng, ci, scale=0.3))
+    dy = pitched(dev(rnd(rng, n, co, h, w)))
+    dy_src = gsd.make_src(dy)
+    need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, ci, co)
+    ws = torch.zeros(need, device="cuda")
+    wl = layout(gsd, 4, dev(rnd(rng, co, ci, 3, 3, scale=0.2)), co, ci)
+
+    def dw_of(src):
+        dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_wgrad(gsd.src_array([src]), 1, C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need,
+                                            n, h, w, gsd.stream_ptr()))
+        return dw
+
+    def conv_of(src):
+        y = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w43(gsd.src_array([src]), 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None,
+                                          n, h, w, gsd.stream_ptr()))
+        return y
+
+    bn_src, plain_src = gsd.make_src(x, sc, sh, relu=True, slack=4), gsd.make_src(x, slack=4)
+    ref = dw_of(bn_src), dw_of(plain_src), conv_of(plain_src)
+    for var in ("GSD_WG43_RR", "GSD_WG43_PLAIN", "GSD_W43_PLAIN"):
+        monkeypatch.setenv(var, "0")
+        got = dw_of(bn_src), dw_of(plain_src), conv_of(plain_src)
+        monkeypatch.delenv(var)
+        for a_, b_ in zip(ref, got):
+            assert bool(torch.isfinite(a_).all()) and torch.equal(a_, b_), var
