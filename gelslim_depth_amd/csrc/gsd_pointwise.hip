@@ -468,9 +468,145 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P)
   }
 }
 
+// Modes 0 and 2 with 16-byte accesses (planes of a multiple of 4 elements, 16-byte aligned operands): a thread owns four
+// consecutive elements.  Same sums as the scalar kernel up to the order of addition.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BnBwdParams P) {
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int HW = P.H * P.W;
+  const size_t plane = ((size_t)n * P.C + c) * HW;
+  const float sc = P.scale[c], sh = P.shift[c], mu = P.mean[c], is = P.invstd[c];
+  const float wo = MODE == 2 ? P.wout[c] : 0.f;
+  const float* gsrc = MODE == 2 ? P.dout + (size_t)n * HW : P.da.p + (size_t)n * P.da.ns + (size_t)c * P.da.cs;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int e_end = min((chunk + 1) * BWD_CHUNK, HW);
+  for (int e = chunk * BWD_CHUNK + threadIdx.x * 4; e < e_end; e += 1024) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(P.raw + plane + e);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(gsrc + e);
+    f32x4 dz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = fmaf(x[i], sc, sh);
+      float g = d[i];
+      if (MODE == 2) {
+        s3 = fmaf(d[i], fmaxf(y, 0.f), s3);   // dW_out[0][c]
+        g = d[i] * wo;
+      }
+      dz[i] = y > 0.f ? g : 0.f;
+      s1 += dz[i];
+      s2 = fmaf(dz[i], (x[i] - mu) * is, s2);
+    }
+    *reinterpret_cast<f32x4*>(P.dz + plane + e) = dz;
+  }
+  __shared__ float red[3][4];
+  s1 = wave_sum_f(s1);
+  s2 = wave_sum_f(s2);
+  s3 = wave_sum_f(s3);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+    red[2][threadIdx.x >> 6] = s3;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int row = n * P.chunks + chunk;
+    P.partials[(size_t)row * 3 * P.C + threadIdx.x * P.C + c] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
+// Mode 1 (gradient = da + the max-pool backward of dpool), one thread per 2x2 POOLING WINDOW: its four raw values are read once
+// (two 8-byte loads) and serve both the arg-max and the four dz -- the element-per-thread kernel re-read the window for every
+// element (3.7 TB/s).  Windows cut by an odd H / W keep the elements that exist and get no pooled gradient (floor mode).
+constexpr int BWD_WCHUNK = BWD_CHUNK / 4;   // windows per block
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdParams P) {
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int HW = P.H * P.W;
+  const size_t plane = ((size_t)n * P.C + c) * HW;
+  const float sc = P.scale[c], sh = P.shift[c], mu = P.mean[c], is = P.invstd[c];
+  const int Hp = P.H >> 1, Wp = P.W >> 1, Hc = (P.H + 1) >> 1, Wc = (P.W + 1) >> 1;
+  const float* xr = P.raw + plane;
+  const float* ga = P.da.p != nullptr ? P.da.p + (size_t)n * P.da.ns + (size_t)c * P.da.cs : nullptr;
+  const float* dp = P.dpool + ((size_t)n * P.C + c) * Hp * Wp;
+  float* dzp = P.dz + plane;
+  float s1 = 0.f, s2 = 0.f;
+  const int q_end = min((chunk + 1) * BWD_WCHUNK, Hc * Wc);
+  for (int q = chunk * BWD_WCHUNK + threadIdx.x; q < q_end; q += 256) {
+    const int hp = q / Wc, wp = q - hp * Wc;
+    const int o0 = 2 * hp * P.W + 2 * wp, o1 = o0 + P.W;
+    const bool col1 = 2 * wp + 1 < P.W, row1 = 2 * hp + 1 < P.H;
+    float x[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col1) {
+      const f32x2u t = *reinterpret_cast<const f32x2u*>(xr + o0);
+      x[0] = t[0], x[1] = t[1];
+      if (ga != nullptr) { const f32x2u u = *reinterpret_cast<const f32x2u*>(ga + o0); g[0] = u[0], g[1] = u[1]; }
+      if (row1) {
+        const f32x2u t1 = *reinterpret_cast<const f32x2u*>(xr + o1);
+        x[2] = t1[0], x[3] = t1[1];
+        if (ga != nullptr) { const f32x2u u = *reinterpret_cast<const f32x2u*>(ga + o1); g[2] = u[0], g[3] = u[1]; }
+      }
+    } else {
+      x[0] = xr[o0];
+      if (ga != nullptr) g[0] = ga[o0];
+      if (row1) {
+        x[2] = xr[o1];
+        if (ga != nullptr) g[2] = ga[o1];
+      }
+    }
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = fmaf(x[i], sc, sh);
+    if (col1 && row1) {   // a whole window: the first maximum of relu(bn(raw)) in (0,0),(0,1),(1,0),(1,1) order takes dpool
+      float best = fmaxf(y[0], 0.f);
+      int bi = 0;
+#pragma unroll
+      for (int i = 1; i < 4; ++i) {
+        const float v = fmaxf(y[i], 0.f);
+        if (v > best) { best = v; bi = i; }
+      }
+      const float dpv = dp[hp * Wp + wp];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (bi == i) g[i] += dpv;
+    }
+    float dz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ex = (i & 1 ? col1 : true) && (i & 2 ? row1 : true);
+      dz[i] = (ex && y[i] > 0.f) ? g[i] : 0.f;
+      s1 += dz[i];
+      s2 = fmaf(dz[i], (x[i] - mu) * is, s2);
+    }
+    if (col1) {
+      *reinterpret_cast<f32x2u*>(dzp + o0) = f32x2u{dz[0], dz[1]};
+      if (row1) *reinterpret_cast<f32x2u*>(dzp + o1) = f32x2u{dz[2], dz[3]};
+    } else {
+      dzp[o0] = dz[0];
+      if (row1) dzp[o1] = dz[2];
+    }
+  }
+  __shared__ float red[2][4];
+  s1 = wave_sum_f(s1);
+  s2 = wave_sum_f(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int row = n * P.chunks + chunk;
+    P.partials[(size_t)row * 3 * P.C + threadIdx.x * P.C + c] =
+        threadIdx.x < 2 ? red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3] : 0.f;
+  }
+}
+
+// partial rows of one launch: per image, the blocks of the window-per-thread form (>= those of the element forms, whose
+// surplus blocks write zeros)
+static int bwd_chunks(int H, int W) { return ceil_div(((H + 1) / 2) * ((W + 1) / 2), BWD_WCHUNK); }
 extern "C" int gsd_bn_bwd_partial_rows(int N, int C, int H, int W) {
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-  return N * ceil_div(H * W, BWD_CHUNK);
+  return N * bwd_chunks(H, W);
 }
 
 extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale, const float* shift, const float* mean,
@@ -499,9 +635,16 @@ extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale,
   P.dpool = dpool; P.dout = dout; P.wout = wout; P.K = K;
   P.dz = dz; P.partials = partials;
   P.N = N; P.C = C; P.H = H; P.W = W;
-  P.chunks = ceil_div(H * W, BWD_CHUNK);
+  P.chunks = bwd_chunks(H, W);
   dim3 grid(P.chunks, C, N);
-  if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  const bool scalar = gsd_env_int("GSD_BN_BWD_SCALAR", 0) != 0;   // the element-per-thread kernels (A/B, tests)
+  const float* gsrc = mode == 2 ? dout : P.da.p;
+  const bool vec = !scalar && (H * W) % 4 == 0 && (((uintptr_t)raw | (uintptr_t)dz | (uintptr_t)gsrc) & 15) == 0 &&
+                   (mode == 2 || (P.da.ns % 4 == 0 && P.da.cs % 4 == 0));
+  if (mode == 1 && !scalar) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, P);
+  else if (mode == 0 && vec) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  else if (mode == 2 && vec) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  else if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
   else if (mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, P);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
   GSD_LAUNCH_CHECK("gsd_bn_bwd_reduce");
