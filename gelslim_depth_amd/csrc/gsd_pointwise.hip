@@ -132,10 +132,48 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
     wt[e] = v;
   }
 }
+// Modes 4 / 5 (Winograd U = G g), one thread per (m-block, k channel, kernel row, column): the three taps are read once and
+// the six transformed values written (the generic kernel reads them, and divides its way to them, once per OUTPUT element).
+__global__ __launch_bounds__(256) void weight_layout_w43_kernel(int mode, const float* __restrict__ w, int Co, int Ci,
+                                                                 float* __restrict__ wt, int kpad, int M, int mblocks) {
+  const long long total = (long long)mblocks * kpad * 3 * 64;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(e & 63);
+    long long t = e >> 6;
+    const int r = (int)(t % 3);
+    t /= 3;
+    const int kch = (int)(t % kpad);
+    const int mb = (int)(t / kpad);
+    const int m = mb * 64 + (col & 3) * 16 + (col >> 2);   // slot l*4 + t of a 64-column group holds column t*16 + l
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (m < M && kch < (mode == 4 ? Ci : Co)) {
+      const float* g = mode == 4 ? w + ((size_t)m * Ci + kch) * 9 + r * 3 : w + ((size_t)kch * Ci + m) * 9 + (2 - r) * 3;
+      g0 = mode == 4 ? g[0] : g[2];
+      g1 = g[1];
+      g2 = mode == 4 ? g[2] : g[0];
+    }
+    float* o = wt + (((size_t)mb * kpad + kch) * 18 + r * 6) * 64 + col;
+    o[0] = g0 * 0.25f;
+    o[64] = -(g0 + g1 + g2) * (1.f / 6.f);
+    o[128] = -(g0 - g1 + g2) * (1.f / 6.f);
+    o[192] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+    o[256] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+    o[320] = g2;
+  }
+}
 extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
   GSD_REQUIRE(w && wt && mode >= 0 && mode <= 6 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
+  if (mode == 4 || mode == 5) {
+    const int kpad = rows / 18;
+    const long long threads = (long long)mblocks * kpad * 3 * 64;
+    const int grid = (int)(ceil_div64(threads, 256) < 16384 ? ceil_div64(threads, 256) : 16384);
+    hipLaunchKernelGGL(weight_layout_w43_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, kpad, M,
+                       mblocks);
+    GSD_LAUNCH_CHECK("gsd_weight_layout (w43)");
+    return GSD_OK;
+  }
   const long long total = (long long)mblocks * rows * pitch;
   const int grid = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
   hipLaunchKernelGGL(weight_layout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, rows, M, BM,
