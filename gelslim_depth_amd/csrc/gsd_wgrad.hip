@@ -380,8 +380,14 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
 // flat pixel -> (h, w) map live in the per-lane source address), one LDS image per block and two blocks per CU, so one
 // block's DMA issue + flight is covered by the other's MFMAs.  The deferred BatchNorm+ReLU of x is applied after the
 // ds_read (a lane owns four fixed input channels).  Measured against the register-staged kernel: see DESIGN.md.
+// BX: the activation operand as aligned 16-byte pieces -- 64 consecutive pixels of a channel plane are 256 contiguous bytes
+// (H * W % 4 == 0, 16-byte aligned strides): an instruction fills four channel rows, 8 instead of 32 instructions per wave and
+// stage.  The rows are then contiguous in LDS (pitch 64), so piece q of row r is stored at slot q ^ (r & 15) (swizzle on the
+// DMA's source piece and on the read) to keep the 16 rows of a read off one bank.
+__device__ __attribute__((aligned(16))) const float gsd_zero16_wg[4] = {0.f, 0.f, 0.f, 0.f};
+template <bool BX>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradParams P) {
-  constexpr int MT = 4, NTB = 4, BMw = 128, BNw = 128, DS = 66;
+  constexpr int MT = 4, NTB = 4, BMw = 128, BNw = 128, DS = 66, DSB = BX ? 64 : DS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Al = smem;
   float* Bl = smem + BMw * DS;
@@ -418,7 +424,11 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
     for (int t = 0; t < NTB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int a_off = (wm * 64 + l16) * DS + j;
-  const int b_off = (wn * 64 + l16) * DS + j;
+  const int b_off = (wn * 64 + l16) * DSB + j;   // BX: rows wn*64 + t*16 + l16: (row & 15) == l16
+  // BX loader role: lane = (row lr of the instruction's four, slot q); the wave's instructions cover rows 4*(wave + 4 i) + lr,
+  // so (row & 15) == (4 * wave + lr) & 15 for all of them; the lane fetches source piece q ^ (row & 15)
+  const int b_lr = lane >> 4;
+  const int b_piece = (lane & 15) ^ ((4 * wave + b_lr) & 15);
   for (int stage = s_begin; stage < s_end; ++stage) {
     const int n = stage / P.tiles_flat;
     const int p = (stage - n * P.tiles_flat) * 64 + lane;
@@ -434,20 +444,34 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
       const float* gsrc = (pix_ok && m < P.M) ? abase + (long long)(m >> 2) * P.dy.cs + ((m >> 1) & 1) * P.dy.W + (m & 1) : &gsd_pad[0];
       __builtin_amdgcn_global_load_lds(gsrc, Al + row * DS, 4, 0, 0);
     }
-    const float* bbase = P.a0.p + (long long)n * P.a0.ns + p;
+    if constexpr (BX) {
+      const int p0 = (stage - n * P.tiles_flat) * 64 + 4 * b_piece;   // first pixel of this lane's piece (H * W % 4 == 0)
+      const bool pc_ok = p0 < HW;
+      const float* bbase = P.a0.p + (long long)n * P.a0.ns + p0;
 #pragma unroll 4
-    for (int i = 0; i < BNw / 4; ++i) {
-      const int ch = wave + 4 * i;
-      const int c = n0 + ch;
-      const float* gsrc = (pix_ok && c < P.a0.C) ? bbase + (long long)c * P.a0.cs : &gsd_pad[0];
-      __builtin_amdgcn_global_load_lds(gsrc, Bl + ch * DS, 4, 0, 0);
+      for (int i = 0; i < BNw / 16; ++i) {
+        const int ch = 4 * (wave + 4 * i) + b_lr;
+        const int c = n0 + ch;
+        const float* gsrc = (pc_ok && c < P.a0.C) ? bbase + (long long)c * P.a0.cs : &gsd_zero16_wg[0];
+        float* dstp = Bl + (wave + 4 * i) * (4 * DSB);
+        __builtin_amdgcn_global_load_lds(gsrc, dstp, 16, 0, 0);
+      }
+    } else {
+      const float* bbase = P.a0.p + (long long)n * P.a0.ns + p;
+#pragma unroll 4
+      for (int i = 0; i < BNw / 4; ++i) {
+        const int ch = wave + 4 * i;
+        const int c = n0 + ch;
+        const float* gsrc = (pix_ok && c < P.a0.C) ? bbase + (long long)c * P.a0.cs : &gsd_pad[0];
+        __builtin_amdgcn_global_load_lds(gsrc, Bl + ch * DS, 4, 0, 0);
+      }
     }
     gsd_dma_barrier();   // vmcnt(0) + barrier: the image is complete
     float an[MT], bn[NTB];
 #pragma unroll
     for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS];
 #pragma unroll
-    for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DS];
+    for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DSB + (BX ? 4 * l16 : 0)];   // BX: piece 0 sits in slot 0 ^ l16
     for (int s = 0; s < 16; ++s) {
       float a[MT], b[NTB];
 #pragma unroll
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
 #pragma unroll
       for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS + 4 * sn];
 #pragma unroll
-      for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DS + 4 * sn];
+      for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DSB + 4 * (BX ? (sn ^ l16) : sn)];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -802,12 +826,18 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
   if (pl.wide) {   // M = 4*Cout <= 64: never the case for this network; the register-staged kernel keeps it working
     rc = launch_convT_wgrad<1, 4>(P, grid, lds, (hipStream_t)stream);
   } else {
-    static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-    if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_wgrad_dma_kernel)); e != hipSuccess) {
+    // activation rows as aligned 16-byte pieces when 64 consecutive pixels of a plane are 256 aligned bytes
+    const bool bx = gsd_env_int("GSD_CONVT_WG_BX", 1) != 0 && (H * W) % 4 == 0 && ((uintptr_t)x->ptr & 15) == 0 &&
+                    x->c_stride % 4 == 0 && x->n_stride % 4 == 0;
+    static gsd_attr_once big_lds_bx, big_lds;   // per-device caches of an idempotent launch attribute (gsd_common.h)
+    const void* fn = bx ? reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<true>)
+                        : reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<false>);
+    if (hipError_t e = gsd_allow_big_lds(bx ? big_lds_bx : big_lds, fn); e != hipSuccess) {
       gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return GSD_ERR_HIP;
     }
-    hipLaunchKernelGGL(convT_wgrad_dma_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    if (bx) hipLaunchKernelGGL(convT_wgrad_dma_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(convT_wgrad_dma_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
     GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");
     rc = GSD_OK;
   }
