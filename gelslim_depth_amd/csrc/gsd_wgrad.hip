@@ -385,8 +385,16 @@ __global__ __launch_bounds__(NBUF == 3 ? 512 : 256, NBUF == 2 ? 1 : 2) void wgra
 // stage.  The rows are then contiguous in LDS (pitch 64), so piece q of row r is stored at slot q ^ (r & 15) (swizzle on the
 // DMA's source piece and on the read) to keep the 16 rows of a read off one bank.
 __device__ __attribute__((aligned(16))) const float gsd_zero16_wg[4] = {0.f, 0.f, 0.f, 0.f};
-template <bool BX>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// AX (XM == 2): the gradient operand as 16-byte pieces too.  Rows m = (co, kh, kw = 0 / 1) read the same stretch of dy row
+// 2h + kh interleaved, so an LDS row holds a (co, kh) PAIR of m rows: 128 floats = 64 pixels x (kw 0, kw 1), a piece = two
+// pixels; an instruction fills two such rows (four m rows): 8 instead of 32 instructions per wave and stage.  Slot q of row R
+// holds source piece q ^ (R & 7) (eight rows a read touches -> eight bank groups).  A pixel pair that straddles the end of an
+// image row (odd W only) gets its second pixel's two floats from a plain load issued beside the fills and written over the
+// piece by the same lane once its fills have landed.
+template <int XM>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradParams P) {
+  constexpr bool BX = XM >= 1, AX = XM == 2;
   constexpr int MT = 4, NTB = 4, BMw = 128, BNw = 128, DS = 66, DSB = BX ? 64 : DS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Al = smem;
@@ -423,7 +431,11 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
 #pragma unroll
     for (int t = 0; t < NTB; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int a_off = (wm * 64 + l16) * DS + j;
+  const int a_off = AX ? (wm * 32 + (l16 >> 1)) * 128 + 2 * (j & 1) + (l16 & 1) : (wm * 64 + l16) * DS + j;
+  // AX loader role: lane = (row lr of the instruction's two (co, kh) rows, slot q of 32); rows R = 2 * (wave + 4 i) + lr, so
+  // (R & 7) == (2 * wave + lr) & 7 for all of the wave's instructions
+  const int a_lr = lane >> 5, a_q = lane & 31;
+  const int a_sp = a_q ^ ((2 * wave + a_lr) & 7);   // source piece = pixel pair of the stage
   const int b_off = (wn * 64 + l16) * DSB + j;   // BX: rows wn*64 + t*16 + l16: (row & 15) == l16
   // BX loader role: lane = (row lr of the instruction's four, slot q); the wave's instructions cover rows 4*(wave + 4 i) + lr,
   // so (row & 15) == (4 * wave + lr) & 15 for all of them; the lane fetches source piece q ^ (row & 15)
@@ -436,13 +448,35 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
     const int h = pix_ok ? p / P.W : 0;
     const int w = pix_ok ? p - h * P.W : 0;
     __syncthreads();   // every wave has finished reading the previous stage's image
-    const float* abase = P.dy.p + (long long)n * P.dy.ns + (long long)(2 * h) * P.dy.W + 2 * w;
+    f32x2 a_fix[AX ? BMw / 16 : 1];
+    bool a_str = false;
+    if constexpr (AX) {
+      const int pa = (stage - n * P.tiles_flat) * 64 + 2 * a_sp;   // first pixel of this lane's pair
+      const bool pa_ok = pa < HW;
+      const int ha = pa_ok ? pa / P.W : 0, wa = pa_ok ? pa - ha * P.W : 0;
+      a_str = pa_ok && wa == P.W - 1;                              // the pair's second pixel starts the next image row
+      const bool pb_ok = pa + 1 < HW;
+      const float* abase = P.dy.p + (long long)n * P.dy.ns + (long long)(2 * ha) * P.dy.W + 2 * wa;
+#pragma unroll
+      for (int i = 0; i < BMw / 16; ++i) {
+        const int R = 2 * (wave + 4 * i) + a_lr;      // (co, kh) row of the block
+        const int m = m0 + 2 * R;
+        const float* src = abase + (long long)(m >> 2) * P.dy.cs + ((m >> 1) & 1) * P.dy.W;
+        const float* gsrc = (pa_ok && m < P.M) ? src : &gsd_zero16_wg[0];
+        float* dstp = Al + (wave + 4 * i) * 256;
+        __builtin_amdgcn_global_load_lds(gsrc, dstp, 16, 0, 0);
+        a_fix[i] = f32x2{0.f, 0.f};
+        if (a_str && pb_ok && m < P.M) a_fix[i] = *reinterpret_cast<const f32x2*>(src + 2 * P.dy.W - 2 * wa);   // row 2(ha+1)+kh, column 0
+      }
+    } else {
+      const float* abase = P.dy.p + (long long)n * P.dy.ns + (long long)(2 * h) * P.dy.W + 2 * w;
 #pragma unroll 4
-    for (int i = 0; i < BMw / 4; ++i) {
-      const int row = wave + 4 * i;           // m = (co, kh, kw)
-      const int m = m0 + row;
-      const float* gsrc = (pix_ok && m < P.M) ? abase + (long long)(m >> 2) * P.dy.cs + ((m >> 1) & 1) * P.dy.W + (m & 1) : &gsd_pad[0];
-      __builtin_amdgcn_global_load_lds(gsrc, Al + row * DS, 4, 0, 0);
+      for (int i = 0; i < BMw / 4; ++i) {
+        const int row = wave + 4 * i;           // m = (co, kh, kw)
+        const int m = m0 + row;
+        const float* gsrc = (pix_ok && m < P.M) ? abase + (long long)(m >> 2) * P.dy.cs + ((m >> 1) & 1) * P.dy.W + (m & 1) : &gsd_pad[0];
+        __builtin_amdgcn_global_load_lds(gsrc, Al + row * DS, 4, 0, 0);
+      }
     }
     if constexpr (BX) {
       const int p0 = (stage - n * P.tiles_flat) * 64 + 4 * b_piece;   // first pixel of this lane's piece (H * W % 4 == 0)
@@ -466,10 +500,20 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
         __builtin_amdgcn_global_load_lds(gsrc, Bl + ch * DS, 4, 0, 0);
       }
     }
-    gsd_dma_barrier();   // vmcnt(0) + barrier: the image is complete
+    if constexpr (AX) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills (and the plain loads behind them) have landed
+      if (a_str) {
+#pragma unroll
+        for (int i = 0; i < BMw / 16; ++i)
+          *reinterpret_cast<f32x2*>(&Al[(wave + 4 * i) * 256 + lane * 4 + 2]) = a_fix[i];
+      }
+      __syncthreads();
+    } else {
+      gsd_dma_barrier();   // vmcnt(0) + barrier: the image is complete
+    }
     float an[MT], bn[NTB];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS];
+    for (int m = 0; m < MT; ++m) an[m] = AX ? Al[a_off + m * 8 * 128 + 4 * ((j >> 1) ^ (l16 >> 1))] : Al[a_off + m * 16 * DS];
 #pragma unroll
     for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DSB + (BX ? 4 * l16 : 0)];   // BX: piece 0 sits in slot 0 ^ l16
     for (int s = 0; s < 16; ++s) {
@@ -480,7 +524,8 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_dma_kernel(const WgradPara
       for (int t = 0; t < NTB; ++t) b[t] = fmaxf(fmaf(bn[t], sc[t], sh[t]), lo[t]);
       const int sn = s + 1 < 16 ? s + 1 : s;   // next k-step's operands before this k-step's MFMAs
 #pragma unroll
-      for (int m = 0; m < MT; ++m) an[m] = Al[a_off + m * 16 * DS + 4 * sn];
+      for (int m = 0; m < MT; ++m)
+        an[m] = AX ? Al[a_off + m * 8 * 128 + 4 * ((2 * sn + (j >> 1)) ^ (l16 >> 1))] : Al[a_off + m * 16 * DS + 4 * sn];
 #pragma unroll
       for (int t = 0; t < NTB; ++t) bn[t] = Bl[b_off + t * 16 * DSB + 4 * (BX ? (sn ^ l16) : sn)];
 #pragma unroll
@@ -829,15 +874,19 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
     // activation rows as aligned 16-byte pieces when 64 consecutive pixels of a plane are 256 aligned bytes
     const bool bx = gsd_env_int("GSD_CONVT_WG_BX", 1) != 0 && (H * W) % 4 == 0 && ((uintptr_t)x->ptr & 15) == 0 &&
                     x->c_stride % 4 == 0 && x->n_stride % 4 == 0;
-    static gsd_attr_once big_lds_bx, big_lds;   // per-device caches of an idempotent launch attribute (gsd_common.h)
-    const void* fn = bx ? reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<true>)
-                        : reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<false>);
-    if (hipError_t e = gsd_allow_big_lds(bx ? big_lds_bx : big_lds, fn); e != hipSuccess) {
+    // ... and the gradient rows as 16-byte pieces of dy rows (8-byte aligned pixel pairs: dy is 8-byte aligned with even strides)
+    const bool ax = bx && gsd_env_int("GSD_CONVT_WG_AX", 1) != 0;
+    static gsd_attr_once big_lds_ax, big_lds_bx, big_lds;   // per-device caches of an idempotent launch attribute (gsd_common.h)
+    const void* fn = ax ? reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<2>)
+                        : (bx ? reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<1>)
+                              : reinterpret_cast<const void*>(&convT_wgrad_dma_kernel<0>));
+    if (hipError_t e = gsd_allow_big_lds(ax ? big_lds_ax : (bx ? big_lds_bx : big_lds), fn); e != hipSuccess) {
       gsd_set_error("gsd_convT2x2_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return GSD_ERR_HIP;
     }
-    if (bx) hipLaunchKernelGGL(convT_wgrad_dma_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(convT_wgrad_dma_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    if (ax) hipLaunchKernelGGL(convT_wgrad_dma_kernel<2>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    else if (bx) hipLaunchKernelGGL(convT_wgrad_dma_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(convT_wgrad_dma_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, P);
     GSD_LAUNCH_CHECK("gsd_convT2x2_wgrad");
     rc = GSD_OK;
   }
