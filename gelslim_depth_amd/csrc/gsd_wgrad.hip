@@ -614,15 +614,28 @@ __global__ void sum_planes_stage1(const float* __restrict__ x, int N, int K, lon
   const long long per = (total + G - 1) / G;
   const long long b = (long long)g * per, e = b + per < total ? b + per : total;
   double s = 0.0;
-  for (long long i = b + threadIdx.x; i < e; i += blockDim.x) {
-    const long long n = i / HW, p = i - n * HW;
+  // (image, pixel) carried along instead of a 64-bit division per element: the same elements in the same order
+  long long i = b + threadIdx.x;
+  long long n = i / HW, p = i - n * HW;
+  const long long step = blockDim.x, nstep = step / HW, pstep = step - nstep * HW;
+  for (; i < e; i += step) {
     s += (double)x[((size_t)n * K + k) * HW + p];
+    n += nstep;
+    p += pstep;
+    if (p >= HW) {
+      p -= HW;
+      ++n;
+    }
   }
-  __shared__ double red[4];
+  __shared__ double red[16];   // up to 1024 threads: with few planes (the output conv: K = 1) the 64 blocks are all there is
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) ws[(size_t)k * G + g] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    ws[(size_t)k * G + g] = (float)t;
+  }
 }
 __global__ void sum_planes_stage2(const float* __restrict__ ws, int K, int G, float* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -909,7 +922,7 @@ extern "C" int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, 
 
 extern "C" int gsd_sum_planes(const float* x, int N, int K, int64_t HW, float* out, float* workspace, void* stream) {
   GSD_REQUIRE(x && out && workspace && N > 0 && K > 0 && HW > 0, GSD_ERR_BAD_ARG, "gsd_sum_planes: bad argument");
-  hipLaunchKernelGGL(sum_planes_stage1, dim3(K, 64), dim3(256), 0, (hipStream_t)stream, x, N, K, (long long)HW, workspace);
+  hipLaunchKernelGGL(sum_planes_stage1, dim3(K, 64), dim3(K <= 8 ? 1024 : 256), 0, (hipStream_t)stream, x, N, K, (long long)HW, workspace);
   GSD_LAUNCH_CHECK("gsd_sum_planes stage1");
   hipLaunchKernelGGL(sum_planes_stage2, dim3(ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream, workspace, K, 64, out);
   GSD_LAUNCH_CHECK("gsd_sum_planes stage2");
