@@ -247,7 +247,7 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // own fills have landed (vmcnt(0)), in front of the chunk's barrier.  Ablation (fills removed, profiles/build_diag.sh
 // -DW43_ABL): the dword halo fills cost 9.5 % of the kernel's time, the weight fills 3 %, the barrier 2 %.
 template <int WM, int X4M, int NL, bool FAST, bool PLAIN>
-#ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk, 8 no wait for the fills (results are then garbage)
+#ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk, 8 no wait for the fills, 16 / 32 halo fills from hot addresses (results are then garbage)
 #define W43_ABL 0
 #endif
 #ifndef W43_MIN_WAVES   // diagnostic builds: waves per SIMD the register allocation must admit for the 4-wave form
@@ -494,7 +494,13 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
         }
       } else {
         if (p_on[pp] && f_xo[pp] >= 0) {
+#if (W43_ABL) & 16   // diagnostic: every halo lane reads chunk 0's address (same instructions, bytes from the L1 / L2 instead of HBM)
+          const float* gp = P.src0.p + f_xl[pp];
+#elif (W43_ABL) & 32   // diagnostic: every halo lane reads ONE address
+          const float* gp = P.src0.p;
+#else
           const float* gp = d_base + f_xl[pp];
+#endif
           float* dstp = Xb + ch * PS + (wave8 + NWAVE * pp) * 64;
           __builtin_amdgcn_global_load_lds(gp, dstp, 4, 0, 0);
         }
