@@ -482,10 +482,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         if (ks + 1 < 4) {   // the next k-step's dy tile and the one new window row fly during this k-step's MFMAs
 #pragma unroll
           for (int m = 0; m < MT; ++m) ya[nb2][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[ks + 1] + m * 16 * DS]);
-#ifndef WG43_RR_LATE_READ
           xa = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + (ks + 3) * P.WCp]);
           xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (ks + 3) * P.WCp + 4]);
-#endif
         }
         float U[MT][6];
 #pragma unroll
@@ -506,12 +504,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
           for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[(ks + r) % 3][f], acc[m][r * 6 + f]);
-#ifdef WG43_RR_LATE_READ
-        if (ks + 1 < 4) {
-          xa = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + (ks + 3) * P.WCp]);
-          xb = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (ks + 3) * P.WCp + 4]);
-        }
-#endif
 #if defined(WG43_ABL) && ((WG43_ABL) & 8)   // diagnostic: no row transform after the first three
         if (ks + 1 < 4) { V[ks % 3][0] = xa[0]; V[ks % 3][1] = xa[1]; V[ks % 3][2] = xa[2]; V[ks % 3][3] = xa[3]; V[ks % 3][4] = xb[0]; V[ks % 3][5] = xb[1]; }
 #else
