@@ -114,11 +114,13 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // -- as kernel rows 2, 1, 0 -- with the SAME six values for a lane, so its B^T relu(bn(.)) is computed once and kept across
 // the k-steps (a ring of three rows): 6 row transforms and window reads per stage instead of 12; same products in the same
 // order, bit-identical.
-template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4, bool RR>
+// RR == 2: the same for the 8 x 8 stage (TWq == 2: k-step ks holds tile rows 2ks and 2ks+1, lane groups j < 2 / j >= 2; a lane's
+// window rows are 2ks + (j>>1) + {0,1,2}, the last of which is the first of its next k-step): 9 instead of 12 row transforms.
+template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4, int RR>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
   static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
   static_assert(!BX4 || (AX4 && !R3), "16-byte window pieces come with 16-byte dy pieces and two LDS images");
-  static_assert(!RR || BX4, "row reuse is instantiated for the 16-byte-piece form only");
+  static_assert(RR == 0 || BX4, "row reuse is instantiated for the 16-byte-piece form only");
   constexpr int BM = 32 * NWM, BN = 16 * NWN, NW = NWM * NWN, DS = AX4 ? WG_DS_X4 : WG_DS, MT = 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XS = P.XS;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   };
   auto compute = [&](int cur, bool late, int next_stage, bool more) {
     const float* Sb = smem + cur * BUF;
-    if constexpr (RR) {
+    if constexpr (RR == 1) {
       // b_off[0] = this lane's channel plane + 4 j: window row w of tile column j is at + w * WCp
       f32x4 ya[2][MT];
       f32x4 xa;
@@ -509,6 +511,64 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
 #else
         if (ks + 1 < 4) row_transform(xa, xb, V[ks % 3]);   // window row ks + 3 takes the place of row ks
 #endif
+        if (ks == 0 && late && more) {
+          WG43_STAMP(2)
+          issue_dma(next_stage, cur ^ 1);
+          WG43_STAMP(1)
+        }
+      }
+      WG43_STAMP(2)
+      return;
+    }
+    if constexpr (RR == 2) {
+      // b_off[0] = plane + (j >> 1) * WCp + 4 * (j & 1): window row w (relative to the lane's first) is at + w * WCp
+      f32x4 ya[2][MT];
+      f32x4 xa[2];
+      f32x2w xb[2];
+      float V[3][6];   // V[w % 3]: relative window row w
+#pragma unroll
+      for (int m = 0; m < MT; ++m) ya[0][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[0] + m * 16 * DS]);
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        xa[0] = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + w * P.WCp]);
+        xb[0] = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + w * P.WCp + 4]);
+        row_transform(xa[0], xb[0], V[w]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cb = ks & 1, nb2 = cb ^ 1;
+        if (ks + 1 < 4) {   // the next k-step's dy tile and its two new window rows fly during this k-step's MFMAs
+#pragma unroll
+          for (int m = 0; m < MT; ++m) ya[nb2][m] = *reinterpret_cast<const f32x4*>(&Sb[a_off[ks + 1] + m * 16 * DS]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            xa[i] = *reinterpret_cast<const f32x4*>(&Sb[b_off[0] + (2 * ks + 3 + i) * P.WCp]);
+            xb[i] = *reinterpret_cast<const f32x2w*>(&Sb[b_off[0] + (2 * ks + 3 + i) * P.WCp + 4]);
+          }
+        }
+        float U[MT][6];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {   // U = A dy
+          const float y0 = ya[cb][m][0], y1 = ya[cb][m][1], y2 = ya[cb][m][2], y3 = ya[cb][m][3];
+          const float p = y0 + y2, q = y1 + y3;
+          const float a = fmaf(4.f, y2, y0), b = 2.f * fmaf(4.f, y3, y1);
+          U[m][0] = y0;
+          U[m][1] = p + q;
+          U[m][2] = p - q;
+          U[m][3] = a + b;
+          U[m][4] = a - b;
+          U[m][5] = y3;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[(2 * ks + r) % 3][f], acc[m][r * 6 + f]);
+        if (ks + 1 < 4) {   // relative rows 2ks+3, 2ks+4 take the places of rows 2ks, 2ks+1
+          row_transform(xa[0], xb[0], V[(2 * ks + 3) % 3]);
+          row_transform(xa[1], xb[1], V[(2 * ks + 4) % 3]);
+        }
         if (ks == 0 && late && more) {
           WG43_STAMP(2)
           issue_dma(next_stage, cur ^ 1);
@@ -825,7 +885,7 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
     else bx4 = false;
   }
   // row reuse: the 4 x 16 stage (k-step = tile row)
-  const bool rr = bx4 && gsd_env_int("GSD_WG43_RR", 1) != 0 && pl.TW == 16 && pl.TH == 4;
+  const int rr = (bx4 && gsd_env_int("GSD_WG43_RR", 1) != 0) ? (pl.TW == 16 && pl.TH == 4 ? 1 : (pl.TW == 8 && pl.TH == 8 ? 2 : 0)) : 0;
   const size_t img = (size_t)(pl.BM * (ax4 ? WG_DS_X4 : WG_DS) + (bx4 ? (pl.BN * (P.XS / 4) + 63) / 64 * 256 : pl.BN * P.XS)) * sizeof(float);
   const bool r3 = gsd_env_int("GSD_WG43_R3", 0) != 0 && eight && 3 * img <= 160 * 1024;
   const size_t lds = (r3 ? 3 : 2) * img;
@@ -845,33 +905,39 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
     hipLaunchKernelGGL((wgrad3x3_w43_kernel<NWM_, NWN_, AX4_, R3_, PL_, BX_, RR_>), g, dim3(64 * NWM_ * NWN_), lds, st, P);             \
   } while (0)
   if (pl.BM == 128) {
-    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false, false, false);
-    else if (bx4 && rr && plain) WG43_LAUNCH(4, 2, true, false, true, true, true);
-    else if (bx4 && rr) WG43_LAUNCH(4, 2, true, false, false, true, true);
-    else if (bx4 && plain) WG43_LAUNCH(4, 2, true, false, true, true, false);
-    else if (bx4) WG43_LAUNCH(4, 2, true, false, false, true, false);
-    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true, false, false);
-    else if (ax4) WG43_LAUNCH(4, 2, true, false, false, false, false);
-    else if (r3) WG43_LAUNCH(4, 2, false, true, false, false, false);
-    else WG43_LAUNCH(4, 2, false, false, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(4, 2, true, true, false, false, 0);
+    else if (bx4 && rr == 1 && plain) WG43_LAUNCH(4, 2, true, false, true, true, 1);
+    else if (bx4 && rr == 2 && plain) WG43_LAUNCH(4, 2, true, false, true, true, 2);
+    else if (bx4 && rr == 1) WG43_LAUNCH(4, 2, true, false, false, true, 1);
+    else if (bx4 && rr == 2) WG43_LAUNCH(4, 2, true, false, false, true, 2);
+    else if (bx4 && plain) WG43_LAUNCH(4, 2, true, false, true, true, 0);
+    else if (bx4) WG43_LAUNCH(4, 2, true, false, false, true, 0);
+    else if (ax4 && plain) WG43_LAUNCH(4, 2, true, false, true, false, 0);
+    else if (ax4) WG43_LAUNCH(4, 2, true, false, false, false, 0);
+    else if (r3) WG43_LAUNCH(4, 2, false, true, false, false, 0);
+    else WG43_LAUNCH(4, 2, false, false, false, false, 0);
   } else if (pl.BN == 64) {
-    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false, false, false);
-    else if (bx4 && rr && plain) WG43_LAUNCH(2, 4, true, false, true, true, true);
-    else if (bx4 && rr) WG43_LAUNCH(2, 4, true, false, false, true, true);
-    else if (bx4 && plain) WG43_LAUNCH(2, 4, true, false, true, true, false);
-    else if (bx4) WG43_LAUNCH(2, 4, true, false, false, true, false);
-    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true, false, false);
-    else if (ax4) WG43_LAUNCH(2, 4, true, false, false, false, false);
-    else if (r3) WG43_LAUNCH(2, 4, false, true, false, false, false);
-    else WG43_LAUNCH(2, 4, false, false, false, false, false);
+    if (ax4 && r3) WG43_LAUNCH(2, 4, true, true, false, false, 0);
+    else if (bx4 && rr == 1 && plain) WG43_LAUNCH(2, 4, true, false, true, true, 1);
+    else if (bx4 && rr == 2 && plain) WG43_LAUNCH(2, 4, true, false, true, true, 2);
+    else if (bx4 && rr == 1) WG43_LAUNCH(2, 4, true, false, false, true, 1);
+    else if (bx4 && rr == 2) WG43_LAUNCH(2, 4, true, false, false, true, 2);
+    else if (bx4 && plain) WG43_LAUNCH(2, 4, true, false, true, true, 0);
+    else if (bx4) WG43_LAUNCH(2, 4, true, false, false, true, 0);
+    else if (ax4 && plain) WG43_LAUNCH(2, 4, true, false, true, false, 0);
+    else if (ax4) WG43_LAUNCH(2, 4, true, false, false, false, 0);
+    else if (r3) WG43_LAUNCH(2, 4, false, true, false, false, 0);
+    else WG43_LAUNCH(2, 4, false, false, false, false, 0);
   } else {
-    if (bx4 && rr && plain) WG43_LAUNCH(2, 2, true, false, true, true, true);
-    else if (bx4 && rr) WG43_LAUNCH(2, 2, true, false, false, true, true);
-    else if (bx4 && plain) WG43_LAUNCH(2, 2, true, false, true, true, false);
-    else if (bx4) WG43_LAUNCH(2, 2, true, false, false, true, false);
-    else if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true, false, false);
-    else if (ax4) WG43_LAUNCH(2, 2, true, false, false, false, false);
-    else WG43_LAUNCH(2, 2, false, false, false, false, false);
+    if (bx4 && rr == 1 && plain) WG43_LAUNCH(2, 2, true, false, true, true, 1);
+    else if (bx4 && rr == 2 && plain) WG43_LAUNCH(2, 2, true, false, true, true, 2);
+    else if (bx4 && rr == 1) WG43_LAUNCH(2, 2, true, false, false, true, 1);
+    else if (bx4 && rr == 2) WG43_LAUNCH(2, 2, true, false, false, true, 2);
+    else if (bx4 && plain) WG43_LAUNCH(2, 2, true, false, true, true, 0);
+    else if (bx4) WG43_LAUNCH(2, 2, true, false, false, true, 0);
+    else if (ax4 && plain) WG43_LAUNCH(2, 2, true, false, true, false, 0);
+    else if (ax4) WG43_LAUNCH(2, 2, true, false, false, false, 0);
+    else WG43_LAUNCH(2, 2, false, false, false, false, 0);
   }
 #undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
