@@ -112,6 +112,7 @@ class UNetEngine:
         self.world = 1
         self._saved_train = False
         self.block_done_cb: Optional[Callable[[str], None]] = None   # data-parallel hook: a block's grads are final
+        self._nbt: list = []   # num_batches_tracked buffers of the current train-mode forward
         self.guard = None          # non-finite guard of the current step (_lib.make_guard), set by TrainStep per step
         self.generation = 0        # forwards so far: a backward belongs to exactly one (models/unet.py checks it)
         # bench hook: when a list, every conv3x3 launch appends (variant, flops, start_event, end_event)
@@ -224,7 +225,7 @@ class UNetEngine:
                                       u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(),
                                       self.guard, st),
                   "bn_finalize")
-            P[u.nbtname].add_(1)   # int64 counter buffer (BatchNorm2d.num_batches_tracked)
+            self._nbt.append(P[u.nbtname])   # int64 counter buffers (BatchNorm2d.num_batches_tracked): one add for all, below
         else:
             check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
                                          P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
@@ -264,6 +265,7 @@ class UNetEngine:
         """P: name -> tensor for every state_dict entry (reference names). Returns (N, n_classes, H, W)."""
         if x.dtype != torch.float32 or not x.is_cuda:
             raise L.GsdError("UNetEngine.forward needs a float32 tensor on the GPU (no CPU fallback)")
+        self._nbt = []
         x = x.contiguous()
         n, c, h, w = x.shape
         assert c == self.n_channels, f"expected {self.n_channels} input channels, got {c}"
@@ -303,6 +305,9 @@ class UNetEngine:
             self._run_unit(u0, [self._act_src(skip), L.make_src(up.out, off=self._pad_off(lvl), slack=L.SLACK)], P, train, st)
             self._run_unit(u1, [self._act_src(u0)], P, train, st)
             cur = u1
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)   # one launch instead of one per BatchNorm layer
+            self._nbt = []
         if out is None:
             out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
         s = self._act_src(cur)
