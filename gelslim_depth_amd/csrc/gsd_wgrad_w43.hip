@@ -116,6 +116,9 @@ __device__ __forceinline__ void wg43_wait_vmcnt(int n) {
 // order, bit-identical.
 // RR == 2: the same for the 8 x 8 stage (TWq == 2: k-step ks holds tile rows 2ks and 2ks+1, lane groups j < 2 / j >= 2; a lane's
 // window rows are 2ks + (j>>1) + {0,1,2}, the last of which is the first of its next k-step): 9 instead of 12 row transforms.
+#ifndef WG43_LATE_KS   // the k-step after which the late half of an 8-wave block issues its fills
+#define WG43_LATE_KS 0
+#endif
 template <int NWM, int NWN, bool AX4, bool R3, bool PLAIN, bool BX4, int RR>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3x3_w43_kernel(const WgW43Params P) {
   static_assert(!R3 || NWM * NWN == 8, "the three-image ring is the 8-wave form");
@@ -501,21 +504,27 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
           U[m][5] = y3;
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
           for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[(ks + r) % 3][f], acc[m][r * 6 + f]);
+#ifdef WG43_LATE_HALF   // diagnostic: the late half issues after the first 18 MFMAs of the stage
+          if (ks == 0 && m == 0 && late && more) issue_dma(next_stage, cur ^ 1);
+#endif
+        }
 #if defined(WG43_ABL) && ((WG43_ABL) & 8)   // diagnostic: no row transform after the first three
         if (ks + 1 < 4) { V[ks % 3][0] = xa[0]; V[ks % 3][1] = xa[1]; V[ks % 3][2] = xa[2]; V[ks % 3][3] = xa[3]; V[ks % 3][4] = xb[0]; V[ks % 3][5] = xb[1]; }
 #else
         if (ks + 1 < 4) row_transform(xa, xb, V[ks % 3]);   // window row ks + 3 takes the place of row ks
 #endif
-        if (ks == 0 && late && more) {
+#ifndef WG43_LATE_HALF
+        if (ks == WG43_LATE_KS && late && more) {
           WG43_STAMP(2)
           issue_dma(next_stage, cur ^ 1);
           WG43_STAMP(1)
         }
+#endif
       }
       WG43_STAMP(2)
       return;
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
           row_transform(xa[0], xb[0], V[(2 * ks + 3) % 3]);
           row_transform(xa[1], xb[1], V[(2 * ks + 4) % 3]);
         }
-        if (ks == 0 && late && more) {
+        if (ks == WG43_LATE_KS && late && more) {
           WG43_STAMP(2)
           issue_dma(next_stage, cur ^ 1);
           WG43_STAMP(1)
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int f = 0; f < 6; ++f) acc[m][r * 6 + f] = mfma16(U[m][f], V[r][f], acc[m][r * 6 + f]);
-      if (ks == 0 && late && more) {
+      if (ks == WG43_LATE_KS && late && more) {
         WG43_STAMP(2)
         issue_dma(next_stage, cur ^ 1);
         WG43_STAMP(1)
@@ -704,7 +713,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       // The barrier puts the two waves of a SIMD in phase, and a wave that issues its ~24 gathers (plus their address
       // work) keeps the matrix pipe idle: the SIMD's second wave (waves 4..7 of an 8-wave block) therefore multiplies its
       // first k-step BEFORE it issues its share of the next stage's DMA.
+#ifdef WG43_NO_LATE   // diagnostic: every wave issues its fills in front of the stage
+      const bool late = false;
+#else
       const bool late = NW == 8 && wave >= 4;
+#endif
       if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
       WG43_STAMP(1)   // this wave's share of the next stage's DMA
       compute(cur, late, s_begin + it + 1, it + 1 < nst);
