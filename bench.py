@@ -146,7 +146,7 @@ class Leg:
         model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
         self.model = model.to(dev).train()
         self.step = TrainStep(self.model, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse", process_group=pg,
-                              sync_bn=sync_bn)
+                              sync_bn=sync_bn, time_allreduce=pg is not None)
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
         self.x = torch.rand((batch, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
@@ -171,6 +171,8 @@ class Leg:
         for _ in range(warmup):
             self.one_step()
         barrier()
+        if getattr(self.step, "sync", None) is not None and self.step.sync.timing:
+            self.step.sync.pop_timing()          # the warm-up steps' collectives are not part of the timed region
         eng = self.model._engine
         eng.kernel_log, eng.region_log = [], []
         t0 = time.perf_counter()
@@ -181,6 +183,20 @@ class Leg:
         klog, rlog = eng.kernel_log, eng.region_log
         eng.kernel_log = eng.region_log = None
         return elapsed, klog, rlog
+
+    def comm(self, steps):
+        """Gradient all-reduce time of the timed region (HIP events on a side stream that waits for RCCL's stream around every
+        bucket, gelslim_depth_amd/distributed.py): per step, and the part the compute stream had to wait for."""
+        sync = getattr(self.step, "sync", None)
+        if sync is None or not sync.timing:
+            return None
+        t = sync.pop_timing()
+        n = max(1, t["steps"])
+        ms = t["allreduce_ms"] / n
+        return {"allreduce_ms_per_step": round(ms, 4), "exposed_ms_per_step": round(t["exposed_ms"] / n, 4),
+                "MB_per_step": round(t["bytes"] / n / 1e6, 3),
+                "bus_GBps": round(t["bytes"] / n / 1e9 / (ms * 1e-3), 2) if ms > 0 else None,
+                "buckets": t["buckets"], "steps_timed": n}
 
     def inc_hbm(self, rlog):
         """North-star second roofline: the `inc` double-conv forward against the HBM roof.  achieved = ALGORITHMIC bytes
@@ -305,13 +321,55 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def over_ranks(local_elapsed, comm):
+        """(max elapsed over ranks, [per-rank ms per step], rank-max of the collective times) -- rank 0 reports them."""
+        if pg is None:
+            return local_elapsed, [round(local_elapsed / args.steps * 1e3, 3)], comm
+        row = torch.tensor([local_elapsed, comm["allreduce_ms_per_step"] if comm else 0.0,
+                            comm["exposed_ms_per_step"] if comm else 0.0], device=dev, dtype=torch.float64)
+        rows = [torch.zeros_like(row) for _ in range(n_ranks_seen)]
+        torch.distributed.all_gather(rows, row)
+        tab = torch.stack(rows).cpu()
+        if comm:
+            comm = dict(comm, allreduce_ms_per_step=round(float(tab[:, 1].max()), 4),
+                        exposed_ms_per_step=round(float(tab[:, 2].max()), 4),
+                        per_rank_allreduce_ms=[round(float(v), 4) for v in tab[:, 1]])
+        return float(tab[:, 0].max()), [round(float(v), 3) for v in tab[:, 0] / args.steps * 1e3], comm
+
     leg = Leg(dev, rank, args.dtype, args.workload, B, pg=pg, sync_bn=args.sync_bn, graph=args.graph)
     elapsed, klog, rlog = leg.run(args.steps, args.warmup, barrier)
     loss = float(leg.step.last_loss.item())
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, per_rank_ms, comm = over_ranks(elapsed, leg.comm(args.steps))
+    hbm = leg.inc_hbm(rlog) if rank == 0 else None
+
+    # configs[3] names a batch-64 scaling sweep without saying whether 64 is global or per GPU (SURVEY.md 8(d): report both):
+    # the metric above is the weak-scaling line (fixed per-GPU batch); this short leg is the STRONG-scaling one -- the global
+    # batch of 64 split over the ranks -- run by every rank of the same invocation, after the metric's timed region
+    strong = None
+    if args.workload == "train" and args.dtype == "f32" and not args.no_extra and args.global_batch == 0 and 64 % world == 0:
+        del leg
+        torch.cuda.empty_cache()
+        sb, ssteps, swarm = 64 // world, 5, 2
+        lg = Leg(dev, rank, "f32", "train", sb, pg=pg, sync_bn=args.sync_bn)
+        el, _, _ = lg.run(ssteps, swarm, barrier)
+        sc = lg.comm(ssteps)
+        if pg is not None:
+            t2 = torch.tensor([el, sc["allreduce_ms_per_step"] if sc else 0.0, sc["exposed_ms_per_step"] if sc else 0.0],
+                              device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
+            el = float(t2[0])
+            if sc:
+                sc = dict(sc, allreduce_ms_per_step=round(float(t2[1]), 4), exposed_ms_per_step=round(float(t2[2]), 4))
+        strong = {"workload": "BASELINE.json configs[3]: batch-64 data-parallel train step fp32 (GLOBAL batch 64 = %d per GPU x %d), "
+                              "3x320x427, all HIP kernels, gradients summed over RCCL" % (sb, world),
+                  "value": round(64 * ssteps / el, 2), "unit": "frames/s", "scaling": "strong", "n_gpus": world,
+                  "per_gpu_batch": sb, "global_batch": 64, "ms_per_step": round(el / ssteps * 1e3, 3), "steps": ssteps,
+                  "warmup": swarm, "dtype": "f32", "final_loss": round(float(lg.step.last_loss.item()), 6)}
+        if sc is not None:
+            strong["allreduce"] = sc
+        del lg
+        torch.cuda.empty_cache()
+        leg = None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -326,7 +384,6 @@ def main():
                 roof["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes: %s)" % ", ".join(tj.get("sources", []))
         except (OSError, ValueError, KeyError):
             pass
-        hbm = leg.inc_hbm(rlog)
         if hbm is not None:
             roof["hbm"] = hbm
         out = {
@@ -336,6 +393,7 @@ def main():
             "unit": "frames/s",
             "n_gpus": world,
             "n_ranks_seen": n_ranks_seen,
+            "per_rank_ms_per_step": per_rank_ms,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -352,11 +410,17 @@ def main():
                                             os.environ.get("GSD_CONV_ALGO", ""), "winograd F(4,3) rows, fp32 (Cin>=16) / direct taps (first layer)"))},
             "roofline": roof,
         }
+        if comm is not None:
+            comm["share_of_step"] = round(comm["allreduce_ms_per_step"] / ms_per_step, 4) if ms_per_step > 0 else None
+            comm["exposed_share_of_step"] = round(comm["exposed_ms_per_step"] / ms_per_step, 4) if ms_per_step > 0 else None
+            out["allreduce"] = comm
+        extra = {}
+        if strong is not None:
+            extra["configs[3] strong scaling: global batch 64 fp32"] = strong
         if world == 1 and not args.no_extra and args.workload == "train" and args.dtype == "f32":
             # the other single-GPU configurations BASELINE.json names, a few steps each, AFTER the timed region of the metric
-            del leg
+            leg = None
             torch.cuda.empty_cache()
-            extra = {}
             for key, dt, wl, b in (("configs[1] batch-16 inference fp32", "f32", "infer", 16),
                                    ("configs[4] per-GPU share: batch-32 bf16 train step", "bf16", "train", 32)):
                 lg = Leg(dev, 0, dt, wl, b)
@@ -372,6 +436,7 @@ def main():
                 extra[key] = e
                 del lg
                 torch.cuda.empty_cache()
+        if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

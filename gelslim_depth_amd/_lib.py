@@ -86,6 +86,8 @@ SIGNATURES = {
     "gsd_convT2x2_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_convT2x2_wgrad": (_I, [_SRC, _SRC, _I, _I, _P, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_bn_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
+    "gsd_partials_channel_sums": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gsd_add_counters": (_I, [C.POINTER(C.c_void_p), _I, _L, _P]),
     "gsd_bn_finalize": (_I, [_P, _I, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _GUARD, _P]),
     "gsd_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "gsd_bn_bwd_partial_rows": (_I, [_I, _I, _I, _I]),
@@ -102,6 +104,7 @@ SIGNATURES = {
     "gsd_bn_bwd_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _P, _P, _P, _P]),
     "gsd_area_resize_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _F, _F, _P]),
     "gsd_ingest_images": (_I, [_P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _I, _F, _F, _P]),
+    "gsd_gaussian_blur": (_I, [_P, _L, _I, _I, _P, _I, _P, _P]),
     "gsd_channel_stats_workspace": (_L, [_I]),
     "gsd_channel_stats": (_I, [_P, _L, _I, _L, _P, _P, _P]),
     "gsd_gather_affine": (_I, [_P, _P, _L, _I, _I, _L, _P, _P, _I, _P, _P]),
@@ -168,11 +171,26 @@ def _chk_f32(t: torch.Tensor) -> None:
         raise GsdError(f"expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
 
 
-def _chk_nchw(t: torch.Tensor) -> None:
-    """(N,C,H,W) with unit column stride and non-overlapping rows / planes / images (contiguous, or a view of a pitched buffer)."""
-    if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) < t.shape[3] or t.stride(1) < t.shape[2] * t.stride(2) or \
-            (t.shape[0] > 1 and t.stride(0) < t.shape[1] * t.stride(1)):
+def _nchw_strides(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(n_stride, c_stride, w_stride) of an (N,C,H,W) tensor with unit column stride and non-overlapping rows / planes / images
+    (contiguous, or a view of a pitched buffer).  torch leaves the stride of a size-1 dimension arbitrary (a permuted,
+    channels_last or N == 1 tensor is still `is_contiguous()`): such a stride addresses nothing, so it is replaced by the
+    dense one before the checks and before it is handed to a kernel."""
+    if t.dim() != 4:
+        raise GsdError(f"expected an NCHW tensor, got shape {tuple(t.shape)}")
+    n, c, h, w = t.shape
+    if w > 1 and t.stride(3) != 1:
         raise GsdError(f"expected an NCHW tensor with unit column stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    ws = t.stride(2) if (h > 1 or t.stride(2) >= w) else w              # a usable pitch is kept even when H == 1
+    cs = t.stride(1) if (c > 1 or t.stride(1) >= h * ws) else h * ws
+    ns = t.stride(0) if (n > 1 or t.stride(0) >= c * cs) else c * cs
+    if ws < w or cs < h * ws or ns < c * cs:
+        raise GsdError(f"expected an NCHW tensor with unit column stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return ns, cs, ws
+
+
+def _chk_nchw(t: torch.Tensor) -> None:
+    _nchw_strides(t)
 
 
 def pitched_empty(shape, device, pitch_multiple: int = 4) -> torch.Tensor:
@@ -190,20 +208,20 @@ def make_src(t: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optio
     PITCHED buffer (rows padded to a multiple of 4 floats): any strides with stride(3) == 1 are accepted.
     slack: readable floats the caller vouches for before and after the tensor (slack_empty allocates such tensors)."""
     _chk_f32(t)
-    _chk_nchw(t)
+    ns, cs, ws = _nchw_strides(t)
     n, ct, h, w = t.shape
     cl = ct - c_off if c_len is None else c_len
     s = gsd_src()
-    s.ptr = t.data_ptr() + 4 * c_off * t.stride(1)
+    s.ptr = t.data_ptr() + 4 * c_off * cs
     s.scale = ptr(scale)
     s.shift = ptr(shift)
     s.C, s.H, s.W = cl, h, w
     s.off_h, s.off_w = off
     s.relu = 1 if relu else 0
-    s.w_stride = t.stride(2)
+    s.w_stride = ws
     s.slack = slack
-    s.n_stride = t.stride(0)
-    s.c_stride = t.stride(1)
+    s.n_stride = ns
+    s.c_stride = cs
     return s
 
 
@@ -224,16 +242,16 @@ def slack_empty(shape, device) -> torch.Tensor:
 
 def make_dst(t: torch.Tensor, c_off: int = 0, c_len: Optional[int] = None, off: Tuple[int, int] = (0, 0)) -> gsd_dst:
     _chk_f32(t)
-    _chk_nchw(t)
+    ns, cs, ws = _nchw_strides(t)
     n, ct, h, w = t.shape
     cl = ct - c_off if c_len is None else c_len
     d = gsd_dst()
-    d.ptr = t.data_ptr() + 4 * c_off * t.stride(1)
+    d.ptr = t.data_ptr() + 4 * c_off * cs
     d.C, d.H, d.W = cl, h, w
     d.off_h, d.off_w = off
-    d.w_stride = t.stride(2)
-    d.n_stride = t.stride(0)
-    d.c_stride = t.stride(1)
+    d.w_stride = ws
+    d.n_stride = ns
+    d.c_stride = cs
     return d
 
 
@@ -260,6 +278,17 @@ def make_guard(words: Optional[torch.Tensor], tick: int):
     g.words = words.data_ptr()
     g.tick = tick
     return C.pointer(g)
+
+
+def add_counters(tensors: Sequence[torch.Tensor], delta: int = 1) -> None:
+    """counter += delta for every int64 scalar tensor on the GPU (BatchNorm2d.num_batches_tracked), one libgsd launch."""
+    if not tensors:
+        return
+    for t in tensors:
+        if t.dtype != torch.int64 or not t.is_cuda or t.numel() != 1:
+            raise GsdError(f"add_counters: expected int64 scalars on the GPU, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    check(lib.gsd_add_counters(arr, len(tensors), delta, stream_ptr()), "add_counters")
 
 
 def int_array(vals: Sequence[int]):

@@ -8,7 +8,11 @@
 //   gsd_gather_affine    batch assembly: rows picked by a (shuffled) index vector, normalised on the way
 //                        general_dataset.py:222-236 (__getitem__ + normalize_sample), normalization_utils.py:4-35,67-99
 //
-// All three are one pass over their input at HBM rate: no LDS, coalesced along the pixel index.
+//   gsd_gaussian_blur    torchvision.transforms.functional.gaussian_blur on the resized depth planes (reflect padding,
+//                        depthwise 2-D correlation with the outer-product kernel): image_utils.py:17-19, called from
+//                        general_dataset.py:74-76,84-86 when depth_image_blur_kernel > 1
+//
+// All are one pass over their input at HBM rate: no LDS, coalesced along the pixel index.
 #include "gsd_common.h"
 
 namespace {
@@ -127,7 +131,44 @@ __global__ __launch_bounds__(256) void gather_affine_kernel(const float* __restr
   }
 }
 
+// out[p][h][w] = sum_{i,j} k2[i][j] * in[p][reflect(h+i-r)][reflect(w+j-r)],  r = K/2, reflect without repeating the edge
+// (torch's F.pad(mode="reflect")); taps accumulated in row-major (i, j) order like a direct depthwise conv2d
+__global__ __launch_bounds__(256) void gaussian_blur_kernel(const float* __restrict__ in, int H, int W, const float* __restrict__ k2,
+                                                            int K, float* __restrict__ out) {
+  const long long p = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= H * W) return;
+  const int h = e / W, w = e - h * W, r = K / 2;
+  const float* ip = in + (size_t)p * H * W;
+  float s = 0.f;
+  for (int i = 0; i < K; ++i) {
+    int hh = h + i - r;
+    hh = hh < 0 ? -hh : (hh >= H ? 2 * (H - 1) - hh : hh);
+    for (int j = 0; j < K; ++j) {
+      int ww = w + j - r;
+      ww = ww < 0 ? -ww : (ww >= W ? 2 * (W - 1) - ww : ww);
+      s = fmaf(k2[i * K + j], ip[(size_t)hh * W + ww], s);
+    }
+  }
+  out[(size_t)p * H * W + e] = s;
+}
+
 }  // namespace
+
+extern "C" int gsd_gaussian_blur(const float* in, int64_t planes, int H, int W, const float* kernel2d, int K, float* out,
+                                 void* stream) {
+  GSD_REQUIRE(in && out && kernel2d && in != out && planes > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG, "gsd_gaussian_blur: bad argument");
+  GSD_REQUIRE(K >= 1 && (K & 1) == 1, GSD_ERR_BAD_ARG, "gsd_gaussian_blur: the kernel size must be odd and positive");
+  GSD_REQUIRE(K / 2 < H && K / 2 < W, GSD_ERR_UNSUPPORTED,
+              "gsd_gaussian_blur: reflect padding needs kernel_size/2 < H and W (as torch's F.pad does)");
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)(planes - p0 < 65535 ? planes - p0 : 65535);
+    hipLaunchKernelGGL(gaussian_blur_kernel, dim3(ceil_div(H * W, 256), np), dim3(256), 0, (hipStream_t)stream,
+                       in + (size_t)p0 * H * W, H, W, kernel2d, K, out + (size_t)p0 * H * W);
+    GSD_LAUNCH_CHECK("gsd_gaussian_blur");
+  }
+  return GSD_OK;
+}
 
 extern "C" int gsd_ingest_images(const void* in, const void* base, int dtype, int N, int C, int H, int W, int64_t in_n_stride,
                                  int64_t in_c_stride, int64_t base_n_stride, int64_t base_c_stride, float* out, int OH,

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(64 * CS_LANES) void colsum_stage1(const float* __re
     tmp[(size_t)g * ncols + col] = t;
   }
 }
-__global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double* __restrict__ sums) {
+// out32 (optional): columns [c_begin, c_begin + c_count) of the FIRST half (blockIdx.y == 0) also leave as fp32
+__global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double* __restrict__ sums, float* __restrict__ out32 = nullptr,
+                              int c_begin = 0, int c_count = 0) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   tmp += (size_t)blockIdx.y * RG * ncols;
   sums += (size_t)blockIdx.y * ncols;
@@ -226,6 +228,7 @@ __global__ void colsum_stage2(const double* __restrict__ tmp, int ncols, double*
     double s = 0.0;
     for (int g = 0; g < RG; ++g) s += tmp[(size_t)g * ncols + col];
     sums[col] = s;
+    if (out32 != nullptr && blockIdx.y == 0 && col >= c_begin && col < c_begin + c_count) out32[col - c_begin] = (float)s;
   }
 }
 
@@ -240,6 +243,42 @@ extern "C" int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad,
   GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage1");
   hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(C, 256), 2), dim3(256), 0, (hipStream_t)stream, tmp, C, sums);
   GSD_LAUNCH_CHECK("gsd_bn_reduce_partials stage2");
+  return GSD_OK;
+}
+
+// Per-channel sums of what a conv launch stored (the first halves of its partial rows), channels [c_begin, c_begin + c_count),
+// as fp32 -- the ConvT bias gradient from the statistics epilogue of the dX launch that writes the up-sampled tensor's gradient.
+extern "C" int gsd_partials_channel_sums(const float* partials, int rows, int Mpad, int C, int c_begin, int c_count, float* out,
+                                         double* sums, void* stream) {
+  GSD_REQUIRE(partials && sums && out && rows > 0 && C > 0 && Mpad >= C && c_begin >= 0 && c_count > 0 && c_begin + c_count <= C,
+              GSD_ERR_BAD_ARG, "gsd_partials_channel_sums: bad argument");
+  double* tmp = sums + 2 * C;
+  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(C, 64), RG, 1), dim3(64 * CS_LANES), 0, (hipStream_t)stream, partials, rows,
+                     2 * Mpad, C, Mpad, tmp);
+  GSD_LAUNCH_CHECK("gsd_partials_channel_sums stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(C, 256), 1), dim3(256), 0, (hipStream_t)stream, tmp, C, sums, out, c_begin, c_count);
+  GSD_LAUNCH_CHECK("gsd_partials_channel_sums stage2");
+  return GSD_OK;
+}
+
+// BatchNorm2d.num_batches_tracked += 1 for every layer of a train-mode forward: one launch for up to 64 int64 counters
+struct counter_ptrs { long long* p[64]; };
+__global__ void add_counters_kernel(counter_ptrs c, int n, long long delta) {
+  const int i = threadIdx.x;
+  if (i < n) *c.p[i] += delta;
+}
+extern "C" int gsd_add_counters(int64_t* const* counters, int n, int64_t delta, void* stream) {
+  GSD_REQUIRE(counters && n > 0, GSD_ERR_BAD_ARG, "gsd_add_counters: bad argument");
+  for (int base = 0; base < n; base += 64) {
+    counter_ptrs c;
+    const int m = n - base < 64 ? n - base : 64;
+    for (int i = 0; i < m; ++i) {
+      GSD_REQUIRE(counters[base + i] != nullptr, GSD_ERR_BAD_ARG, "gsd_add_counters: null counter");
+      c.p[i] = (long long*)counters[base + i];
+    }
+    hipLaunchKernelGGL(add_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c, m, (long long)delta);
+    GSD_LAUNCH_CHECK("gsd_add_counters");
+  }
   return GSD_OK;
 }
 

@@ -75,6 +75,36 @@ def ingest_images(raw: torch.Tensor, base: Optional[torch.Tensor], c0: int, c1: 
                                     out[s:e].data_ptr(), size[0], size[1], 255.0, 0.5, L.stream_ptr()), "ingest_images")
 
 
+def gaussian_kernel2d(kernel_size: int, sigma: Optional[float] = None) -> torch.Tensor:
+    """The K x K kernel torchvision.transforms.functional.gaussian_blur(img, kernel_size) convolves with (fp32, CPU):
+    sigma = 0.3 * ((K - 1) * 0.5 - 1) + 0.8 unless given; k1[i] = exp(-0.5 (x_i / sigma)^2) on K points of
+    linspace(-(K-1)/2, (K-1)/2), normalised to sum 1; k2 = k1 (column) x k1 (row).  torchvision is absent from this image and
+    unpinned by the reference: restated from its published source, parity unpinned."""
+    k = int(kernel_size)
+    if k < 1 or k % 2 == 0:
+        raise ValueError(f"Kernel size value should be an odd and positive number, got {kernel_size}")
+    if sigma is None:
+        sigma = k * 0.15 + 0.35            # == 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    half = (k - 1) * 0.5
+    x = torch.linspace(-half, half, steps=k, dtype=torch.float32)
+    pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+    k1 = pdf / pdf.sum()
+    return torch.mm(k1[:, None], k1[None, :])
+
+
+def gaussian_blur(x: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    """blur_depth_images (image_utils.py:17-19) on a contiguous (N, C, H, W) fp32 device tensor: one libgsd kernel."""
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise L.GsdError("gaussian_blur: expected a contiguous (N,C,H,W) float32 tensor on the GPU")
+    k2 = gaussian_kernel2d(kernel_size).to(x.device)
+    out = torch.empty_like(x)
+    n, c, h, w = x.shape
+    if n * c:
+        check(lib.gsd_gaussian_blur(x.data_ptr(), n * c, h, w, k2.data_ptr(), int(kernel_size), out.data_ptr(), L.stream_ptr()),
+              "gaussian_blur")
+    return out
+
+
 def channel_stats(x: torch.Tensor) -> torch.Tensor:
     """(C, 4) float64 {min, max, mean, unbiased std} per channel of x (N, C, H, W)."""
     n, c, h, w = x.shape
@@ -111,8 +141,7 @@ class DeviceDataset:
         if interp_method not in (None, "area"):
             raise NotImplementedError("only interp_method='area' (what the reference's configs use) is implemented")
         if depth_image_blur_kernel > 1:
-            raise NotImplementedError("depth_image_blur_kernel > 1 (torchvision gaussian_blur) is not built; "
-                                      "the reference's configs use 1")
+            gaussian_kernel2d(depth_image_blur_kernel)      # an even size raises here, as torchvision does
         self.use_difference_image = use_difference_image
         self.downsample_factor = downsample_factor
         self.depth_image_blur_kernel = depth_image_blur_kernel
@@ -179,6 +208,8 @@ class DeviceDataset:
             d_out = torch.empty((k, dep.shape[1], *size), device=dev, dtype=torch.float32)
             ingest_images(tac_d, base_d, 0, tac.shape[1], size, t_out)
             ingest_images(dep_d, None, 0, dep.shape[1], size, d_out)
+        if self.depth_image_blur_kernel > 1:        # general_dataset.py:74-76,84-86: blur AFTER the area resize
+            d_out = gaussian_blur(d_out, self.depth_image_blur_kernel)
         obj = torch.full((rows,), object_index, dtype=torch.int64, device=dev)
         if keep is not None:
             kd = keep.to(dev)
@@ -253,6 +284,15 @@ class DeviceLoader:
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
         self.rank, self.world_size = rank, world_size
 
+    def unsharded(self) -> "DeviceLoader":
+        """The same loader as ONE process sees it: the global batches (batch_size * world_size samples each, ragged tail as
+        DataLoader(drop_last=False) leaves it), no wrap-around padding.  harness.fit evaluates validation / test passes
+        through it on every rank: an evaluation issues no collective, and a padded shard would count the wrapped samples
+        twice in the loss that early stopping reads."""
+        if self.world_size == 1:
+            return self
+        return DeviceLoader(self.dataset, self.batch_size * self.world_size, self.shuffle, self.drop_last, rank=0, world_size=1)
+
     def order(self) -> torch.Tensor:
         n = len(self.dataset)
         if not self.shuffle:
@@ -297,7 +337,12 @@ def train_epoch(step, loader: DeviceLoader) -> Tuple[float, int]:
         losses.append(step(data["tactile_image"], data["depth_image"]).detach().clone())   # the step reuses its loss buffer
     if not losses:
         return 0.0, 0
-    total = float(torch.stack(losses).sum().item())
+    stack = torch.stack(losses)
+    if getattr(step, "nan_policy", None) is not None:
+        # a skipped step's loss is NaN: the reference counts a NaN loss as 0.0 (train_unet.py:371-372), and so does
+        # evaluate_loader -- one bad batch must not turn the epoch's (and, through the rank mean, every rank's) loss into NaN
+        stack = torch.nan_to_num(stack, nan=0.0)
+    total = float(stack.sum().item())
     if hasattr(step, "check_finite"):
         step.check_finite()          # nan_policy="raise": the epoch's one host sync has just happened
     return total, len(losses)

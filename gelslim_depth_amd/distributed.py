@@ -35,10 +35,16 @@ def make_buckets(names: Sequence[str], offsets: Dict[str, Tuple[int, int]], n_le
 
 
 class GradSync:
-    """Sum a flat gradient arena across ranks, bucket by bucket."""
+    """Sum a flat gradient arena across ranks, bucket by bucket.
+
+    timing=True (bench.py --gpus N): every bucket's all-reduce is issued from a side stream of this class between two HIP
+    events -- the side stream first waits for the compute stream (the bucket's gradients are final), and `work.wait()` makes
+    it wait for RCCL's own stream, so the events bracket exactly the collective (plus its queueing behind earlier buckets).
+    `pop_timing()` then says how long the collectives ran per step and how much of that the compute stream had to wait for
+    at the end of backward (the part that was NOT overlapped)."""
 
     def __init__(self, g_flat: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None, overlap: bool = True,
-                 force: bool = False):
+                 force: bool = False, timing: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.g = g_flat
@@ -49,12 +55,30 @@ class GradSync:
         self.force = force or bool(os.environ.get("GSD_FORCE_SYNC"))   # exercise the collectives with one rank
         self._works: List = []
         self._done: List[str] = []
+        self.timing = bool(timing) and g_flat.is_cuda
+        self._side = torch.cuda.Stream(device=g_flat.device) if self.timing else None
+        self._ev: List[Tuple[str, int, torch.cuda.Event, torch.cuda.Event]] = []     # (tag, bytes, start, end) on the side stream
+        self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []          # compute stream: around the final wait
+
+    def _reduce(self, tag: str, lo: int, hi: int) -> None:
+        if not self.timing:
+            self._works.append(self.dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True))
+            return
+        cur = torch.cuda.current_stream(self.g.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            w = self.dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True)
+            w.wait()                      # stream-level for RCCL: the side stream waits for the collective's stream
+            e1.record()
+        self._ev.append((tag, 4 * (hi - lo), e0, e1))
 
     def on_block_done(self, tag: str) -> None:
         self._done.append(tag)
         if (self.world > 1 or self.force) and self.overlap and tag in self.buckets:
             lo, hi = self.buckets[tag]
-            self._works.append(self.dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True))
+            self._reduce(tag, lo, hi)
 
     def finish(self) -> None:
         """After backward: every bucket has been summed when this returns (stream-ordered for NCCL)."""
@@ -63,13 +87,40 @@ class GradSync:
                 missing = [t for t in self.buckets if t not in self._done]
                 for t in missing:          # a block the schedule did not announce: reduce it now
                     lo, hi = self.buckets[t]
-                    self._works.append(self.dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True))
+                    self._reduce(t, lo, hi)
                 for w in self._works:
                     w.wait()
+            elif self.timing:
+                self._reduce("all", 0, self.g.numel())
             else:
                 self.dist.all_reduce(self.g, group=self.group)
+            if self.timing:
+                cur = torch.cuda.current_stream(self.g.device)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self._side)
+                b.record(cur)
+                self._exposed.append((a, b))
         self._works = []
         self._done = []
+
+    def pop_timing(self) -> Dict[str, object]:
+        """Collective time since the last call (synchronise first): total ms on the side stream, ms the compute stream waited
+        for it after backward, bytes, and the per-bucket totals in backward order."""
+        per: Dict[str, List[float]] = {}
+        total_ms, total_bytes = 0.0, 0
+        for tag, nbytes, e0, e1 in self._ev:
+            ms = e0.elapsed_time(e1)
+            d = per.setdefault(tag, [0.0, 0])
+            d[0] += ms
+            d[1] += nbytes
+            total_ms += ms
+            total_bytes += nbytes
+        exposed = sum(a.elapsed_time(b) for a, b in self._exposed)
+        steps = max(1, len(self._exposed))
+        self._ev, self._exposed = [], []
+        return {"steps": steps, "allreduce_ms": total_ms, "exposed_ms": exposed, "bytes": total_bytes,
+                "buckets": {k: {"ms": round(v[0] / steps, 4), "MB": round(v[1] / steps / 1e6, 3)} for k, v in per.items()}}
 
 
 def broadcast_state(p_flat: torch.Tensor, buffers: Sequence[torch.Tensor], group=None, src: int = 0) -> None:

@@ -4,7 +4,7 @@ Mirrors the control flow of the reference model
 (/root/reference/gelslim_depth/models/unet.py:79-88 forward; autograd's reverse sweep for backward)
 but every arithmetic step is a libgsd kernel launch on torch's current HIP stream.  torch is used
 for device memory (buffers) and, in data-parallel runs, for the RCCL collectives; no torch op
-computes any part of the path.
+computes any part of the path (tests/test_gpu_robust.py checks that a fused train step dispatches no ATen compute op).
 
 Data layout in HBM (all fp32 NCHW):
   raw[u]    raw conv3x3 output of every conv unit (pre-BN); the normalised/activated tensor is
@@ -306,7 +306,7 @@ class UNetEngine:
             self._run_unit(u1, [self._act_src(u0)], P, train, st)
             cur = u1
         if self._nbt:
-            torch._foreach_add_(self._nbt, 1)   # one launch instead of one per BatchNorm layer
+            L.add_counters(self._nbt, 1)        # one libgsd launch for every BatchNorm layer's counter
             self._nbt = []
         if out is None:
             out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
@@ -423,9 +423,8 @@ class UNetEngine:
             db_fused = u0.form_d.algo == 1
             rows = self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st, stats=db_fused)
             if db_fused:
-                check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u0.cin), u0.cin, self.db_sums.data_ptr(),
-                                                 st), "bn_reduce_partials")
-                G[up.bname].copy_(self.db_sums[skip.cout:skip.cout + up.cout])
+                check(lib.gsd_partials_channel_sums(self.partials.data_ptr(), rows, _r64(u0.cin), u0.cin, skip.cout, up.cout,
+                                                    G[up.bname].data_ptr(), self.db_sums.data_ptr(), st), "partials_channel_sums")
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
             xs = self._act_src(prev)

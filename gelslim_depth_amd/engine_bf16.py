@@ -260,7 +260,7 @@ class UNetEngineBF16:
                                       u.mean.data_ptr(), u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(),
                                       self.guard, st),
                   "bn_finalize")
-        P[u.nbtname].add_(1)
+        self._nbt.append(P[u.nbtname])   # int64 counters: one libgsd launch for all of them at the end of the forward
         check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
 
     # ------------------------------------------------------------------ forward
@@ -274,6 +274,7 @@ class UNetEngineBF16:
         self._ensure(n, h, w, x.device, train)
         st = L.stream_ptr()
         self._saved_train = train
+        self._nbt = []
         self.generation += 1       # every forward overwrites the saved activations
         dcol = L.make_nhwc(self.col0)
         region = self._region_begin()         # bench hook: the `inc` double-conv forward (im2col, 2 convs, BN statistics + apply)
@@ -310,6 +311,9 @@ class UNetEngineBF16:
             self._run_unit(u0, (self.cat[lvl], 0, u0.cin), P, train, st)
             self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st)
             cur = u1
+        if self._nbt:
+            L.add_counters(self._nbt, 1)
+            self._nbt = []
         if out is None:
             out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
         check(lib.gsd_bf16_conv1x1_out(C.byref(cur.a), P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(),

@@ -92,7 +92,9 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
 
     Data parallel (a build-side addition, the reference is single-process): every rank runs the same epochs on its shard
     of each batch; the epoch losses are averaged over the ranks (`step.mean_across_ranks`) so that all ranks take the
-    same stopping and checkpoint decisions, and only rank 0 writes checkpoints, the log file and the echo."""
+    same stopping and checkpoint decisions, and only rank 0 writes checkpoints, the log file and the echo.  Validation and
+    test passes run UNSHARDED on every rank (`DeviceLoader.unsharded()`): they issue no collective, every rank gets the
+    single-process value, and the wrap-around padding of a sharded loader cannot bias the loss early stopping reads."""
     if train_pass is None:
         from .dataset import train_epoch as train_pass
     if eval_pass is None:
@@ -100,6 +102,8 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
     if save is None:
         def save(st, path):
             st.save_checkpoint(path, use_ema=True)
+    val_loader = val_loader.unsharded() if hasattr(val_loader, "unsharded") else val_loader
+    test_loader = test_loader.unsharded() if hasattr(test_loader, "unsharded") else test_loader
     H: Dict[str, List[float]] = {"train_loss": [], "validation_loss": [], "test_loss": []}
     stopper = EarlyStopping(val_loss_SMA_window, validation_loss_count_threshold, train_indefinitely)
     is_main = getattr(step, "rank", 0) == 0

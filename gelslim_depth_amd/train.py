@@ -15,7 +15,10 @@ The reference's NaN guard (train_unet.py:371-372) replaces a NaN loss by a const
 loss.backward() raises; it costs a host sync per step.  Here it is a device-side flag (`nan_policy`, gsd_guard in
 include/gsd.h): a step whose loss or BatchNorm batch statistics are non-finite leaves parameters, Adam moments and the
 EMA shadow untouched and is counted on the device (non-finite batch statistics never reach the running statistics, with
-or without a policy) -- "skip" carries on, "raise" raises GsdError at
+or without a policy).  A skipped step still consumes a tick of the two host-side schedules -- Adam's bias-correction step
+count and torch_ema's warm-up count ((1+n)/(10+n)) advance as if the step had been applied, where torch / torch_ema would
+not have counted it; either factor changes by less than 1/t from tick t to t+1, so the effect of a skipped step fades with
+the step count -- "skip" carries on, "raise" raises GsdError at
 the next `check_finite()` (train_epoch calls it once per epoch: one host sync per epoch instead of two per step),
 None (default) runs the reference's arithmetic unguarded.
 """
@@ -85,7 +88,7 @@ class TrainStep:
     def __init__(self, model: UNet, lr: float = 1e-3, weight_decay: float = 1e-6, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, ema_decay: Optional[float] = 0.995, loss: str = "mse",
                  process_group=None, sync_bn: bool = False, overlap_allreduce: bool = True,
-                 nan_policy: Optional[str] = None, force_sync: bool = False):
+                 nan_policy: Optional[str] = None, force_sync: bool = False, time_allreduce: bool = False):
         if nan_policy not in (None, "skip", "raise"):
             raise ValueError(f"nan_policy must be None, 'skip' or 'raise', got {nan_policy!r}")
         self.model = model
@@ -143,7 +146,7 @@ class TrainStep:
             if self.ema_flat is not None:
                 self.ema_flat.copy_(self.p_flat)
             self.sync = GradSync(self.g_flat, make_buckets(names, self.offsets, eng.L), group=self.pg,
-                                 overlap=overlap_allreduce, force=force_sync)
+                                 overlap=overlap_allreduce, force=force_sync, timing=time_allreduce)
 
     def __call__(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         model = self.model

@@ -192,6 +192,15 @@ int gsd_convT2x2_wgrad(const gsd_src* x, const gsd_src* dy, int Cin, int Cout,
  * finalize so a data-parallel run can all-reduce sums[0..2C) (SyncBN) in between.
  * `sums` must hold 65*2*C doubles: the result followed by 64*2*C doubles of stage-1 scratch. */
 int gsd_bn_reduce_partials(const float* partials, int rows, int Mpad, int C, double* sums, void* stream);
+/* Per-channel sums (fp32) of what a conv launch STORED, channels [c_begin, c_begin+c_count): the first halves of its partial
+ * rows summed in fp64 in the same two ordered stages.  The ConvT bias gradient (aten::convolution_backward of unet.py:36,41)
+ * comes out of the statistics epilogue of the dX launch that writes the up-sampled tensor's gradient this way, without a
+ * second pass over it.  `sums`: 65*2*C doubles of scratch (sums[0..C) receives all C channel sums). */
+int gsd_partials_channel_sums(const float* partials, int rows, int Mpad, int C, int c_begin, int c_count, float* out,
+                              double* sums, void* stream);
+/* *counters[i] += delta for n int64 device counters (host array of device pointers): BatchNorm2d.num_batches_tracked of
+ * every layer of a train-mode forward (aten::native_batch_norm's `num_batches_tracked += 1`, unet.py:12,15), one launch. */
+int gsd_add_counters(int64_t* const* counters, int n, int64_t delta, void* stream);
 /* sums -> mean, invstd, (scale, shift) = (gamma*invstd, beta - mean*scale); updates running stats
  * (momentum 0.1, unbiased variance) when running_mean != NULL and the batch statistics are finite.
  * count = N*H*W (global if synced). guard may be NULL. */
@@ -283,6 +292,12 @@ int gsd_area_resize_affine(const float* in, const float* base, int N, int C, int
 int gsd_ingest_images(const void* in, const void* base, int dtype, int N, int C, int H, int W, int64_t in_n_stride,
                       int64_t in_c_stride, int64_t base_n_stride, int64_t base_c_stride, float* out, int OH, int OW,
                       float pre_add, float pre_mul, void* stream);
+/* torchvision.transforms.functional.gaussian_blur of `planes` contiguous HxW planes (blur_depth_images, image_utils.py:17-19;
+ * general_dataset.py:74-76,84-86 when depth_image_blur_kernel > 1): reflect padding of K/2, then the depthwise correlation
+ * with the K x K kernel (device pointer, row-major; the caller builds it as torchvision does -- gelslim_depth_amd/dataset.py).
+ * Out of place (in != out).  torchvision is a third-party dependency the reference does not pin and this image lacks:
+ * its published algorithm is restated, parity unpinned for this one function. */
+int gsd_gaussian_blur(const float* in, int64_t planes, int H, int W, const float* kernel2d, int K, float* out, void* stream);
 /* Per-channel {min, max, mean, unbiased std} over x (N,C,HW) -> out[4*C] doubles
  * (calculate_image_normalization_params / calculate_depth_normalization_params, general_dataset.py:199-220).
  * workspace: gsd_channel_stats_workspace(C) doubles. Deterministic (fixed reduction order). */

@@ -54,6 +54,25 @@ def resize(x, size):                                                 # image_uti
     return F.interpolate(x, size=size, mode="area")
 
 
+def gaussian_blur(x, kernel_size):                                   # image_utils.py:17-19 -> torchvision TF.gaussian_blur
+    """torchvision.transforms.functional.gaussian_blur(x, kernel_size) restated with torch CPU operators.  torchvision is a
+    third-party dependency that the reference does not pin (setup.py / requirements.txt do not list it) and that is absent
+    from this image, so this follows its published algorithm (functional.gaussian_blur -> _functional_tensor.gaussian_blur):
+    sigma = 0.15 k + 0.35; 1-D kernel exp(-0.5 (x/sigma)^2) on linspace(-(k-1)/2, (k-1)/2, k), normalised; 2-D kernel =
+    outer product; reflect padding of k//2 on every side; depthwise conv2d.  PARITY UNPINNED for this one function."""
+    k = int(kernel_size)
+    sigma = k * 0.15 + 0.35
+    half = (k - 1) * 0.5
+    pts = torch.linspace(-half, half, steps=k, dtype=x.dtype)
+    pdf = torch.exp(-0.5 * (pts / sigma).pow(2))
+    k1 = pdf / pdf.sum()
+    k2 = torch.mm(k1[:, None], k1[None, :])
+    c = x.shape[-3]
+    w = k2.expand(c, 1, k, k)
+    xp = F.pad(x, [k // 2, k // 2, k // 2, k // 2], mode="reflect")
+    return F.conv2d(xp, w, groups=c)
+
+
 class DatasetOracle:
     """GeneralDataset on in-memory dicts (general_dataset.py:12-245), sequential loading branch."""
 
@@ -61,7 +80,8 @@ class DatasetOracle:
                  depth_normalization_method="min_max_to_0_-1", image_normalization_method="mean_std",
                  separate_fingers=True, downsample_factor=0.5, depth_normalization_parameters=None,
                  image_normalization_parameters=None, norm_scale=None, max_datapoints_per_object=None,
-                 normalizers=None):
+                 normalizers=None, depth_image_blur_kernel=1):
+        self.depth_image_blur_kernel = depth_image_blur_kernel
         self.use_difference_image = use_difference_image
         self.downsample_factor = downsample_factor
         self.max_datapoints_per_object = max_datapoints_per_object
@@ -107,6 +127,8 @@ class DatasetOracle:
             tac = torch.cat((tac[:, 0:tc], tac[:, tc:2 * tc]), dim=0)
             dep = torch.cat((dep[:, 0:dc], dep[:, dc:2 * dc]), dim=0)
         data = {"tactile_image": resize(tac, size), "depth_image": resize(dep, size)}
+        if self.depth_image_blur_kernel > 1:                         # :74-76, 84-86
+            data["depth_image"] = gaussian_blur(data["depth_image"], self.depth_image_blur_kernel)
         rows = data["tactile_image"].shape[0]
         data["object_index"] = torch.tensor([object_index] * rows)   # :87
         if self.max_datapoints_per_object is not None and rows > self.max_datapoints_per_object:     # :90-96

@@ -21,10 +21,11 @@ def main():
     from gelslim_depth_amd import synth
     from gelslim_depth_amd.models.unet import UNet
     from gelslim_depth_amd.train import TrainStep
-    dims = [16, 32, 64] if precision == "fp32" else [32, 64, 128]
+    full = len(sys.argv) > 4 and sys.argv[4] == "full"     # BASELINE's network and resolution: the REAL bucket sizes (0.15-57 MB)
+    dims = [64, 128, 256, 512, 1024] if full else ([16, 32, 64] if precision == "fp32" else [32, 64, 128])
     # every rank starts from DIFFERENT weights: the rank-0 broadcast must fix that
     st = synth.make_state(3, 1, dims, 5 + 100 * rank, "conditioned")
-    x, t = synth.make_batch(4, 37, 53, 6)            # global batch 4 -> 2 per rank
+    x, t = synth.make_batch(4, 320, 427, 6) if full else synth.make_batch(4, 37, 53, 6)            # global batch 4 -> 2 per rank
     per = 4 // world
     xs, ts = x[rank * per:(rank + 1) * per], t[rank * per:(rank + 1) * per]
     m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)

@@ -145,3 +145,18 @@ def test_device_loader_gives_every_rank_the_same_number_of_equal_batches(n, bs, 
     for r in range(world):
         ld = DeviceLoader(_StubDataset(n), batch_size=bs, shuffle=False, drop_last=True, rank=r, world_size=world)
         assert [int(b["tactile_image"].numel()) for b in ld] == [bs] * (n // (bs * world))
+
+
+@pytest.mark.parametrize("n,bs,world", [(65, 32, 2), (7, 2, 2), (9, 2, 4)])
+def test_unsharded_loader_is_the_single_process_loader(n, bs, world):
+    """Validation / test passes (harness.fit) read the sharded loader's UNSHARDED form: the global batches one process would
+    see, every sample exactly once -- no wrap-around padding in the loss that early stopping reads."""
+    from gelslim_depth_amd.dataset import DeviceLoader
+    ref = [b["tactile_image"] for b in DeviceLoader(_StubDataset(n), batch_size=bs * world, shuffle=False)]
+    for r in range(world):
+        ld = DeviceLoader(_StubDataset(n), batch_size=bs, shuffle=False, rank=r, world_size=world).unsharded()
+        got = [b["tactile_image"] for b in ld]
+        assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+        assert torch.equal(torch.cat(got), torch.arange(n))
+    one = DeviceLoader(_StubDataset(n), batch_size=bs)
+    assert one.unsharded() is one

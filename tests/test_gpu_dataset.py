@@ -165,3 +165,53 @@ def test_fit_two_epochs_end_to_end(tmp_path):
         out = ot.forward({k: v.clone() for k, v in sd.items()}, xs, train=False)
     best = int(np.argmin(H["validation_loss"]))
     assert abs(float(((out - ts) ** 2).mean()) - H["validation_loss"][best]) <= 1e-4 * H["validation_loss"][best]
+
+
+@pytest.mark.parametrize("n,c,h,w,k", [(2, 1, 10, 13, 3), (3, 2, 17, 9, 5), (1, 1, 160, 213, 9), (2, 1, 6, 7, 11), (1, 1, 4, 4, 1)])
+def test_gaussian_blur_vs_oracle(n, c, h, w, k):
+    """gsd_gaussian_blur == oracle/dataset_ref.gaussian_blur (torchvision's published algorithm on torch CPU operators:
+    reflect padding + depthwise conv2d with the outer-product kernel), the padding as wide as reflect allows (k//2 = H - 1)."""
+    from gelslim_depth_amd.dataset import gaussian_blur, gaussian_kernel2d
+    from gelslim_depth_amd import _lib as gsd
+    from oracle import dataset_ref as dr
+    rng = np.random.default_rng(h * w + k)
+    x = torch.from_numpy((-2 * rng.random((n, c, h, w))).astype(np.float32))
+    ref = dr.gaussian_blur(x, k).numpy()
+    xd = x.cuda()
+    got = gaussian_blur(xd, k).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    k2 = gaussian_kernel2d(k)
+    assert abs(float(k2.sum()) - 1.0) < 1e-6 and torch.equal(k2, k2.t())
+    # refused, not mis-read: even sizes, in-place, a pad that reflect cannot serve
+    k2d, out = k2.cuda(), torch.empty_like(xd)
+    assert gsd.lib.gsd_gaussian_blur(xd.data_ptr(), n * c, h, w, k2d.data_ptr(), 4, out.data_ptr(), gsd.stream_ptr()) == -1
+    assert gsd.lib.gsd_gaussian_blur(xd.data_ptr(), n * c, h, w, k2d.data_ptr(), k, xd.data_ptr(), gsd.stream_ptr()) == -1
+    big = 2 * min(h, w) + 1
+    assert gsd.lib.gsd_gaussian_blur(xd.data_ptr(), n * c, h, w, k2d.data_ptr(), big, out.data_ptr(), gsd.stream_ptr()) == -2
+
+
+@pytest.mark.parametrize("separate", [True, False])
+def test_device_dataset_with_depth_blur(separate):
+    """depth_image_blur_kernel > 1 (general_dataset.py:74-76,84-86): the depth targets are blurred after the area resize,
+    before the per-object subsample and the normalisation statistics; the tactile images are not."""
+    from gelslim_depth_amd.dataset import DeviceDataset
+    from oracle import dataset_ref as dr
+    kw = dict(use_difference_image=True, image_normalization_method="0_255_to_0_1", depth_normalization_method="min_max_to_0_-1",
+              norm_scale=0.9, max_datapoints_per_object=5, separate_fingers=separate)
+    torch.manual_seed(7)
+    ds = DeviceDataset(objects=dr.synthetic_objects(11, [3, 4]), extra_objects=dr.synthetic_objects(12, [2]), device="cuda",
+                       depth_image_blur_kernel=5, **kw)
+    torch.manual_seed(7)
+    ref = dr.DatasetOracle(dr.synthetic_objects(11, [3, 4]), dr.synthetic_objects(12, [2]), depth_image_blur_kernel=5, **kw)
+    torch.manual_seed(7)
+    plain = dr.DatasetOracle(dr.synthetic_objects(11, [3, 4]), dr.synthetic_objects(12, [2]), **kw)
+    d, dref = ds.entire_dataset["depth_image"].cpu().numpy(), ref.entire_dataset["depth_image"].numpy()
+    assert d.shape == dref.shape and np.abs(d - dref).max() <= 2e-6 * np.abs(dref).max()
+    assert np.abs(dref - plain.entire_dataset["depth_image"].numpy()).max() > 1e-3          # the blur did something
+    assert np.abs(ds.entire_dataset["tactile_image"].cpu().numpy() - ref.entire_dataset["tactile_image"].numpy()).max() <= 2e-5
+    assert np.allclose(np.array(ds.depth_normalization_parameters), np.array(ref.depth_normalization_parameters), rtol=2e-6, atol=1e-6)
+    for i in (0, len(ds) - 1):
+        assert np.abs(ds[i]["depth_image"].cpu().numpy() - ref[i]["depth_image"].numpy()).max() <= 3e-6
+    with pytest.raises(ValueError):
+        DeviceDataset(objects=dr.synthetic_objects(11, [1]), device="cuda", depth_image_blur_kernel=4)

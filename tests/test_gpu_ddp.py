@@ -17,10 +17,10 @@ from gelslim_depth_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_two_ranks(tmp_path, mode, precision="fp32"):
+def run_two_ranks(tmp_path, mode, precision="fp32", size="small"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode, precision]
+           "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode, precision, size]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
@@ -149,3 +149,33 @@ def test_one_rank_rccl_step_is_bit_equal(tmp_path, precision):
     for k, v in m.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert np.array_equal(v.cpu().numpy(), res["buf/" + k]), k
+
+
+def test_two_rank_full_size_step_is_the_sum_of_its_shards(tmp_path):
+    """The data-parallel step on BASELINE's network at 3x320x427 (2 + 2 images, local BatchNorm statistics): the nine gradient
+    buckets are the real ones (0.15 - 57 MB, 124 MB in all).  Every rank's kernels are deterministic, so the all-reduced
+    arena must equal, bit for bit, the fp32 sum of two single-process steps on the two shards; both ranks start from rank 0's
+    weights and end with identical parameters, equal to a single-process Adam step on the averaged gradient."""
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    res = run_two_ranks(tmp_path, "local_bn", "fp32", "full")
+    dims = [64, 128, 256, 512, 1024]
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, t = synth.make_batch(4, 320, 427, 6)
+    assert np.array_equal(res[0]["g_sum"], res[1]["g_sum"]) and np.array_equal(res[0]["p1"], res[1]["p1"])
+    names = synth.param_names(list(st0.keys()))
+    assert np.array_equal(res[1]["p0"], oracle_flat(st0, names)), "rank-0 broadcast"
+    shards = []
+    for r in range(2):
+        m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st0.items()}, strict=True)
+        m = m.to("cuda").train()
+        step = TrainStep(m)
+        loss = float(step(torch.from_numpy(x[2 * r:2 * r + 2]).cuda(), torch.from_numpy(t[2 * r:2 * r + 2]).cuda()))
+        assert loss == float(res[r]["loss"])
+        shards.append(step.g_flat.cpu().numpy())
+        del m, step
+        torch.cuda.empty_cache()
+    assert np.array_equal(res[0]["g_sum"], shards[0] + shards[1])
+    assert res[0]["g_sum"].size == 31037633

@@ -125,6 +125,22 @@ def test_mid_net_vs_golden_and_oracle():
         assert rel_l1(grads[k], first["grads"][k]) < 2e-2, k
 
 
+def _check_stage_statistics(m, want, rtol):
+    """Per-stage activation checksums of the HIP path against the reference's forward hooks (tests/golden/make_golden.py:
+    mean, mean |.|, L2 norm of the output of inc, down[0..3], up[0..3]).  The engine never stores a normalised activation:
+    a stage's output is relu(raw * scale + shift) of its second conv unit, rebuilt here from the engine's buffers."""
+    eng = m._engine
+    stages = {"inc": eng.enc[0][1]}
+    for i in range(eng.L):
+        stages[f"down{i}"] = eng.enc[i + 1][1]
+        stages[f"up{i}"] = eng.dec[i][1]
+    assert set(want) == set(stages)
+    for k, u in stages.items():
+        a = torch.relu(u.raw.double() * u.scale.double()[None, :, None, None] + u.shift.double()[None, :, None, None])
+        got = np.array([a.mean().item(), a.abs().mean().item(), a.pow(2).sum().sqrt().item()])
+        np.testing.assert_allclose(got, want[k], rtol=rtol, err_msg=k)
+
+
 def test_full_size_config1_forward_and_train_step():
     """BASELINE.json configs[0]: one 3x320x427 image through the full-size net, vs the reference's own
     output; then one full train step, gradient checksums vs the reference."""
@@ -140,9 +156,11 @@ def test_full_size_config1_forward_and_train_step():
     assert y.shape == (1, 1, 320, 427)
     err = rel_l1(y.cpu().numpy(), g["y_eval"])
     assert err < 1e-4, err
+    _check_stage_statistics(m, sub(g, "act_eval"), 1e-4)
     m.train()
     from gelslim_depth_amd.train import mse_loss
     out = m(x=xd)
+    _check_stage_statistics(m, sub(g, "act_train"), 2e-4)
     o64 = out.detach().double()
     np.testing.assert_allclose([o64.sum().item(), o64.abs().sum().item()], g["y_train_sum"], rtol=2e-4)
     assert rel_l1(out.detach().cpu().numpy(), g["y_train"].astype(np.float32)) < 1e-3   # fp16-stored fixture

@@ -178,3 +178,62 @@ def test_ema_kernel_properties():
         ref = d * prev.double() + (1 - d) * p.double()
         assert float((s1.double() - ref).abs().max()) <= 4e-7 * float(ref.abs().max() + 1)          # convex combination
         prev = s1
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_train_step_dispatches_no_aten_compute_op(precision):
+    """"No torch op computes any part of the path" (engine.py): every ATen operator that reaches the dispatcher during a
+    fused train step (forward + loss + backward + Adam + EMA, after the buffers exist) must be an allocation or a view --
+    the arithmetic, the BatchNorm counters and the ConvT bias gradients included, is libgsd launches."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    dims = [32, 64, 128]
+    st = synth.make_state(3, 1, dims, 5, "conditioned")
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m)
+    x, t = synth.make_batch(2, 37, 53, 6)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    step(xd, td)                                   # first call allocates the activation buffers (zero fills allowed there)
+    nbt0 = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+    seen = []
+
+    class Recorder(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    with Recorder():
+        step(xd, td)
+    torch.cuda.synchronize()
+    harmless = ("aten.empty", "aten.view", "aten._unsafe_view", "aten.slice", "aten.select", "aten.as_strided", "aten.detach",
+                "aten.alias", "aten.reshape", "aten.expand", "aten.unsqueeze", "aten.squeeze", "aten.t.", "aten.permute",
+                "aten.narrow", "aten.lift_fresh", "aten.new_empty", "aten.empty_like", "aten.empty_strided")
+    computing = sorted({f for f in seen if not f.startswith(harmless)})
+    assert computing == [], computing
+    assert all(int(v) == nbt0[k] + 1 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
+
+
+def test_partials_channel_sums_and_add_counters():
+    """gsd_partials_channel_sums == the fp64 column sums of gsd_bn_reduce_partials' first half, rounded to fp32, for a channel
+    range; gsd_add_counters bumps every int64 counter it is given (more than one launch's worth of them)."""
+    from gelslim_depth_amd import _lib as gsd
+    rng = np.random.default_rng(3)
+    rows, mpad, c = 517, 128, 100
+    part = torch.from_numpy(rng.standard_normal((rows, 2 * mpad)).astype(np.float32)).cuda()
+    sums = torch.zeros(65 * 2 * c, dtype=torch.float64, device="cuda")
+    out = torch.full((40,), float("nan"), device="cuda")
+    gsd.check(gsd.lib.gsd_partials_channel_sums(part.data_ptr(), rows, mpad, c, 37, 40, out.data_ptr(), sums.data_ptr(),
+                                                gsd.stream_ptr()))
+    ref = part.double().sum(0)[:c]
+    np.testing.assert_allclose(sums[:c].cpu().numpy(), ref.cpu().numpy(), rtol=1e-13, atol=1e-10)
+    assert torch.equal(out, ref[37:77].float())
+    assert gsd.lib.gsd_partials_channel_sums(part.data_ptr(), rows, mpad, c, 90, 40, out.data_ptr(), sums.data_ptr(),
+                                             gsd.stream_ptr()) == -1
+    counters = [torch.tensor(i, dtype=torch.int64, device="cuda") for i in range(70)]
+    gsd.add_counters(counters, 3)
+    assert [int(v) for v in counters] == [i + 3 for i in range(70)]
+    with pytest.raises(gsd.GsdError):
+        gsd.add_counters([torch.zeros((), dtype=torch.int32, device="cuda")])

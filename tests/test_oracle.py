@@ -249,3 +249,32 @@ def test_device_loader_order_equals_torch_dataloader():
     assert np.array_equal(DeviceLoader(Stub(), 4, shuffle=False).order().numpy(), np.arange(14))
     assert len(DeviceLoader(Stub(), 4)) == 4 and len(DeviceLoader(Stub(), 4, drop_last=True)) == 3
     assert len(DeviceLoader(Stub(), 4, world_size=2)) == 2
+
+
+@pytest.mark.parametrize("k", [3, 5, 9])
+def test_gaussian_blur_restatement(k):
+    """oracle/dataset_ref.gaussian_blur (torchvision's algorithm restated on torch operators; torchvision is absent and
+    unpinned: parity unpinned) against a plain numpy loop of the same published definition, and the product's host-side
+    kernel builder against the same numbers."""
+    from oracle import dataset_ref as dr
+    from gelslim_depth_amd.dataset import gaussian_kernel2d
+    rng = np.random.default_rng(k)
+    x = rng.standard_normal((2, 1, 9, 11)).astype(np.float32)
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    pts = np.linspace(-(k - 1) / 2, (k - 1) / 2, k)
+    k1 = np.exp(-0.5 * (pts / sigma) ** 2)
+    k1 /= k1.sum()
+    k2 = np.outer(k1, k1)
+    assert np.abs(gaussian_kernel2d(k).numpy() - k2).max() < 1e-7
+    r = k // 2
+
+    def refl(i, n):
+        return -i if i < 0 else (2 * (n - 1) - i if i >= n else i)
+    want = np.zeros_like(x, dtype=np.float64)
+    for h in range(9):
+        for w in range(11):
+            for i in range(k):
+                for j in range(k):
+                    want[:, :, h, w] += k2[i, j] * x[:, :, refl(h + i - r, 9), refl(w + j - r, 11)]
+    got = dr.gaussian_blur(torch.from_numpy(x), k).numpy()
+    assert np.abs(got - want).max() < 1e-6
