@@ -14,6 +14,10 @@
 //   activations [pixel][96 B] (64 B of data + 32 B never written): with 6 pieces per pixel the ds_read_b128 of the B
 //               operand (16 consecutive pixels x 4 pieces) is bank-conflict free for EVERY tap shift; 64-byte pixels
 //               are 2-way conflicted whenever the shift is not a multiple of 4 pixels.
+// Output-channel order inside a wave's 64: LDS weight row m*16 + i of MFMA tile m holds channel (i>>2)*16 + m*4 + (i&3) (a
+// permutation of the DMA's SOURCE rows only), so lane group g ends up with the 16 CONSECUTIVE channels g*16 .. g*16+15 of
+// its pixel across its four m-tiles: the epilogue stores (and the fused BatchNorm-backward loads) are 16-byte accesses, two
+// per pixel and lane instead of four 8-byte ones -- the epilogue is bound by the store ISSUE rate, not by bandwidth.
 // Block = 4 waves; wave tile 64 (m) x 128 (pixels) = 4 x 8 MFMA tiles = 128 accumulator registers; block tile
 // 128 x 256 (WM=2, WN=2) or 64 x 512 (WM=1, WN=4): L2->LDS traffic per FLOP falls with the PIXEL extent of the tile
 // (weights are re-read per pixel tile), which is why the tile is wide in pixels.
@@ -117,7 +121,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     const int tapk = idx / (BM * 4);
     const int row = (idx >> 2) % BM;
     const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
-    woff[k] = MODE == 0 ? (tapk * P.Mpad + m0 + row) * P.K + gg * 8 : (m0 + row) * P.K + tapk * 32 + gg * 8;
+    // LDS row `row` = (64-block, m-tile mm, tile row ii) receives the weights of channel (ii>>2)*16 + mm*4 + (ii&3) of the block
+    const int srow = (row & ~63) | (((row & 15) >> 2) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+    woff[k] = MODE == 0 ? (tapk * P.Mpad + m0 + srow) * P.K + gg * 8 : (m0 + srow) * P.K + tapk * 32 + gg * 8;
   }
   // activations, tile-invariant part: (y << 16 | x << 4 | slot) of this lane's 16-byte piece -- halo position (MODE 0) or
   // tile pixel (MODE 1) -- or -2: a pad / slack piece.  Those are filled from the zero line like out-of-image pixels:
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   for (int m = 0; m < MT; ++m) {
     f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
     if (MODE == 1 && P.bias != nullptr) {
-      const int mrow = m0 + wm * 64 + m * 16 + g * 4;
+      const int mrow = m0 + wm * 64 + g * 16 + m * 4;
       if (mrow < P.M) {
         const int co = P.Cs > 0 ? mrow % P.Cs : mrow;
         init = f32x4{P.bias[co], P.bias[co + 1], P.bias[co + 2], P.bias[co + 3]};
