@@ -308,25 +308,23 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
 
-  // per-lane output rows are the same for every pixel tile: resolve channel / scatter quadrant once
-  long long ooff_m[MT];   // element offset of the m-tile's 4 channels relative to the (scaled) pixel: channel + scatter shift
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int mrow = m0 + wm * 64 + m * 16 + g * 4;
-    int co = mrow, q = 0;
-    if (P.Cs > 0) {
-      q = mrow / P.Cs;
-      co = mrow - q * P.Cs;
+  // A lane's 16 output channels (4 per m-tile) are CONSECUTIVE (see the file header): resolve them / the scatter quadrant once
+  const int ch0 = m0 + wm * 64 + g * 16;   // first of the lane's 16 channels
+  long long ooff;                           // element offset of those channels relative to the (scaled) pixel: channel + scatter shift
+  {
+    int co = ch0, q = 0;
+    if (P.Cs > 0) {                         // Cs % 16 == 0: the 16 channels share their quadrant
+      q = ch0 / P.Cs;
+      co = ch0 - q * P.Cs;
     }
-    ooff_m[m] = ((long long)((q >> 1) + P.oy) * P.Wob + (q & 1) + P.ox) * P.out_pitch + co;
+    ooff = ((long long)((q >> 1) + P.oy) * P.Wob + (q & 1) + P.ox) * P.out_pitch + co;
   }
   const int sm = P.Cs > 0 ? 2 : 1;
-  // Interior tiles (all 256 / 512 pixels inside the image) and full m-tiles take a store path WITHOUT per-store branches:
-  // `guard` is a compile-time constant in each instantiation of the lambda, the m-tile test is wave-uniform.
-  bool mt_ok[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) mt_ok[m] = m0 + wm * 64 + m * 16 < P.M;
+  // Interior tiles (all 256 / 512 pixels inside the image) take a store path WITHOUT per-store branches: `guard` is a
+  // compile-time constant in each instantiation of the lambda.  M % 16 == 0: a lane's 16 channels exist together.
+  const bool ch_ok = ch0 < P.M;
   const bool interior = h0 + P.TH <= P.H && w0 + P.TW <= P.W;
+  typedef unsigned u32x4s __attribute__((ext_vector_type(4), aligned(8)));   // pitches are multiples of 4 elements: 8-byte aligned
   auto epilogue = [&](auto guard_c) {
     constexpr bool GUARD = decltype(guard_c)::value;
     if (P.bw_y != nullptr) {
@@ -334,15 +332,15 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       // half's stores (loads and stores share vmcnt: a load between two stores serialises them); coefficients from LDS.
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        uint2 yr[NT / 2][MT];
+        u32x4 yr[NT / 2][2];
 #pragma unroll
         for (int tt = 0; tt < NT / 2; ++tt) {
           const int t = half * (NT / 2) + tt, nt = wn * NT + t;
           const int r = nt / cbs, cb = nt - r * cbs;
           const int h = GUARD ? min(h0 + r, P.H - 1) : h0 + r, w = GUARD ? min(w0 + cb * 16 + j, P.W - 1) : w0 + cb * 16 + j;
-          const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch + m0 + wm * 64 + g * 4;
-#pragma unroll
-          for (int m = 0; m < MT; ++m) yr[tt][m] = *reinterpret_cast<const uint2*>(yp + (mt_ok[m] ? m * 16 : 0));
+          const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch + (ch_ok ? ch0 : 0);
+          yr[tt][0] = *reinterpret_cast<const u32x4s*>(yp);
+          yr[tt][1] = *reinterpret_cast<const u32x4s*>(yp + 8);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -351,20 +349,23 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           const int r = nt / cbs, cb = nt - r * cbs;
           const int h = h0 + r, w = w0 + cb * 16 + j;
           const bool pix_ok = !GUARD || (h < P.H && w < P.W);
-          u16* ot = P.out + ((long long)(n * P.Hob + h) * P.Wob + w) * P.out_pitch + m0 + wm * 64 + g * 4;
+          u16* ot = P.out + ((long long)(n * P.Hob + h) * P.Wob + w) * P.out_pitch + ch0;
+          unsigned pk[2 * MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const int cl = wm * 64 + m * 16 + g * 4;
+            const int cl = wm * 64 + g * 16 + m * 4;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
             const f32x4 mu = *reinterpret_cast<const f32x4*>(sBw + 2 * BM + cl), is = *reinterpret_cast<const f32x4*>(sBw + 3 * BM + cl);
-            float yv[4] = {__uint_as_float(yr[tt][m].x << 16), __uint_as_float(yr[tt][m].x & 0xffff0000u),
-                           __uint_as_float(yr[tt][m].y << 16), __uint_as_float(yr[tt][m].y & 0xffff0000u)};
+            const unsigned y01 = yr[tt][m >> 1][(m & 1) * 2], y23 = yr[tt][m >> 1][(m & 1) * 2 + 1];
+            float yv[4] = {__uint_as_float(y01 << 16), __uint_as_float(y01 & 0xffff0000u), __uint_as_float(y23 << 16),
+                           __uint_as_float(y23 & 0xffff0000u)};
             float dz[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) dz[e] = fmaf(yv[e], sc[e], sh[e]) > 0.f ? acc[m][t][e] : 0.f;
             const unsigned lo = pack_bf16(dz[0], dz[1]), hi = pack_bf16(dz[2], dz[3]);
-            if (mt_ok[m] && pix_ok) {
-              *reinterpret_cast<uint2*>(ot + m * 16) = make_uint2(lo, hi);
+            pk[2 * m] = lo;
+            pk[2 * m + 1] = hi;
+            if (ch_ok && pix_ok) {
               const float q[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
                                   __uint_as_float(hi & 0xffff0000u)};   // sums of the values as stored
 #pragma unroll
@@ -373,6 +374,10 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
                 s2[m][e] = fmaf(q[e], (yv[e] - mu[e]) * is[e], s2[m][e]);
               }
             }
+          }
+          if (ch_ok && pix_ok) {
+            *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4s*>(ot + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -384,29 +389,33 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         const int r = nt / cbs, cb = nt - r * cbs;
         const int h = h0 + r, w = w0 + cb * 16 + j;
         const bool pix_ok = !GUARD || (h < P.H && w < P.W);
-        u16* ot = P.out + ((long long)(n * P.Hob + sm * h) * P.Wob + sm * w) * P.out_pitch;
+        u16* ot = P.out + ((long long)(n * P.Hob + sm * h) * P.Wob + sm * w) * P.out_pitch + ooff;
+        unsigned pk[2 * MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           f32x4 v = acc[m][t];
           if (P.ep_scale != nullptr) {
-            const int cl = wm * 64 + m * 16 + g * 4;
+            const int cl = wm * 64 + g * 16 + m * 4;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
           }
           const unsigned lo = pack_bf16(v[0], v[1]);
           const unsigned hi = pack_bf16(v[2], v[3]);
-          if (mt_ok[m] && pix_ok) {
-            *reinterpret_cast<uint2*>(ot + ooff_m[m]) = make_uint2(lo, hi);
-            if (P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
-              const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
-              const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
-              s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
-              s1[m][1] += q1; s2[m][1] = fmaf(q1, q1, s2[m][1]);
-              s1[m][2] += q2; s2[m][2] = fmaf(q2, q2, s2[m][2]);
-              s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
-            }
+          pk[2 * m] = lo;
+          pk[2 * m + 1] = hi;
+          if (ch_ok && pix_ok && P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
+            const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
+            const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
+            s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
+            s1[m][1] += q1; s2[m][1] = fmaf(q1, q1, s2[m][1]);
+            s1[m][2] += q2; s2[m][2] = fmaf(q2, q2, s2[m][2]);
+            s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
           }
+        }
+        if (ch_ok && pix_ok) {
+          *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          *reinterpret_cast<u32x4s*>(ot + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         }
       }
     }
@@ -417,15 +426,15 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     // The block is persistent, so its statistics are too: per item the 16-lane rows are summed with DPP and the totals
     // added into the block's LDS cells; ONE partial row per (block, wave) leaves for HBM at the very end (a few hundred
     // rows per launch instead of one per pixel tile, so the column reduction behind it is nearly free).
-    float* cell = sSt + wave * 128 + g * 4;
+    float* cell = sSt + wave * 128 + g * 16;   // cell index = channel offset inside the wave's 64: g*16 + m*4 + r
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
         if (j == 15) {
-          cell[m * 16 + r] += a1;
-          cell[64 + m * 16 + r] += a2;
+          cell[m * 4 + r] += a1;
+          cell[64 + m * 4 + r] += a2;
         }
       }
   }
