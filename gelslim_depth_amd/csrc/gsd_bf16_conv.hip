@@ -14,10 +14,12 @@
 //   activations [pixel][96 B] (64 B of data + 32 B never written): with 6 pieces per pixel the ds_read_b128 of the B
 //               operand (16 consecutive pixels x 4 pieces) is bank-conflict free for EVERY tap shift; 64-byte pixels
 //               are 2-way conflicted whenever the shift is not a multiple of 4 pixels.
-// Output-channel order inside a wave's 64: LDS weight row m*16 + i of MFMA tile m holds channel (i>>2)*16 + m*4 + (i&3) (a
-// permutation of the DMA's SOURCE rows only), so lane group g ends up with the 16 CONSECUTIVE channels g*16 .. g*16+15 of
-// its pixel across its four m-tiles: the epilogue stores (and the fused BatchNorm-backward loads) are 16-byte accesses, two
-// per pixel and lane instead of four 8-byte ones -- the epilogue is bound by the store ISSUE rate, not by bandwidth.
+// Output-channel order inside a wave's 64: LDS weight row m*16 + i of MFMA tile m holds channel
+// (m>>1)*32 + (i>>2)*8 + (m&1)*4 + (i&3) (a permutation of the DMA's SOURCE rows only), so lane group g ends up with channels
+// g*8 .. g*8+7 (m-tiles 0, 1) and 32 + g*8 .. (m-tiles 2, 3) of its pixel: the epilogue stores (and the fused
+// BatchNorm-backward loads) are 16-byte accesses, two per pixel and lane instead of four 8-byte ones, and the four lane
+// groups of a pixel write 64 contiguous bytes per instruction -- the epilogue is bound by the store ISSUE rate, not by
+// bandwidth.
 // Block = 4 waves; wave tile 64 (m) x 128 (pixels) = 4 x 8 MFMA tiles = 128 accumulator registers; block tile
 // 128 x 256 (WM=2, WN=2) or 64 x 512 (WM=1, WN=4): L2->LDS traffic per FLOP falls with the PIXEL extent of the tile
 // (weights are re-read per pixel tile), which is why the tile is wide in pixels.
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     const int tapk = idx / (BM * 4);
     const int row = (idx >> 2) % BM;
     const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
-    // LDS row `row` = (64-block, m-tile mm, tile row ii) receives the weights of channel (ii>>2)*16 + mm*4 + (ii&3) of the block
-    const int srow = (row & ~63) | (((row & 15) >> 2) << 4) | (((row >> 4) & 3) << 2) | (row & 3);
+    // LDS row `row` = (64-block, m-tile mm, tile row ii) receives the weights of channel (mm>>1)*32 + (ii>>2)*8 + (mm&1)*4 + (ii&3)
+    const int srow = (row & ~63) | (((row >> 5) & 1) << 5) | (((row & 15) >> 2) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
     woff[k] = MODE == 0 ? (tapk * P.Mpad + m0 + srow) * P.K + gg * 8 : (m0 + srow) * P.K + tapk * 32 + gg * 8;
   }
   // activations, tile-invariant part: (y << 16 | x << 4 | slot) of this lane's 16-byte piece -- halo position (MODE 0) or
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   for (int m = 0; m < MT; ++m) {
     f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
     if (MODE == 1 && P.bias != nullptr) {
-      const int mrow = m0 + wm * 64 + g * 16 + m * 4;
+      const int mrow = m0 + wm * 64 + (m >> 1) * 32 + g * 8 + (m & 1) * 4;
       if (mrow < P.M) {
         const int co = P.Cs > 0 ? mrow % P.Cs : mrow;
         init = f32x4{P.bias[co], P.bias[co + 1], P.bias[co + 2], P.bias[co + 3]};
@@ -308,21 +310,22 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
 
-  // A lane's 16 output channels (4 per m-tile) are CONSECUTIVE (see the file header): resolve them / the scatter quadrant once
-  const int ch0 = m0 + wm * 64 + g * 16;   // first of the lane's 16 channels
-  long long ooff;                           // element offset of those channels relative to the (scaled) pixel: channel + scatter shift
-  {
-    int co = ch0, q = 0;
-    if (P.Cs > 0) {                         // Cs % 16 == 0: the 16 channels share their quadrant
-      q = ch0 / P.Cs;
-      co = ch0 - q * P.Cs;
+  // A lane's 16 output channels are two runs of 8 (see the file header): resolve them / their scatter quadrants once
+  const int ch0 = m0 + wm * 64 + g * 8;    // first channel of the lane's run A (m-tiles 0, 1); run B (m-tiles 2, 3) starts 32 later
+  long long ooff[2];                        // element offset of a run relative to the (scaled) pixel: channel + scatter shift
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int co = ch0 + 32 * k, q = 0;
+    if (P.Cs > 0) {                         // Cs % 16 == 0: the 8 channels of a run share their quadrant
+      q = co / P.Cs;
+      co -= q * P.Cs;
     }
-    ooff = ((long long)((q >> 1) + P.oy) * P.Wob + (q & 1) + P.ox) * P.out_pitch + co;
+    ooff[k] = ((long long)((q >> 1) + P.oy) * P.Wob + (q & 1) + P.ox) * P.out_pitch + co;
   }
   const int sm = P.Cs > 0 ? 2 : 1;
   // Interior tiles (all 256 / 512 pixels inside the image) take a store path WITHOUT per-store branches: `guard` is a
-  // compile-time constant in each instantiation of the lambda.  M % 16 == 0: a lane's 16 channels exist together.
-  const bool ch_ok = ch0 < P.M;
+  // compile-time constant in each instantiation of the lambda.  M % 16 == 0: the 8 channels of a run exist together.
+  const bool ch_ok[2] = {ch0 < P.M, ch0 + 32 < P.M};
   const bool interior = h0 + P.TH <= P.H && w0 + P.TW <= P.W;
   typedef unsigned u32x4s __attribute__((ext_vector_type(4), aligned(8)));   // pitches are multiples of 4 elements: 8-byte aligned
   auto epilogue = [&](auto guard_c) {
@@ -338,9 +341,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           const int t = half * (NT / 2) + tt, nt = wn * NT + t;
           const int r = nt / cbs, cb = nt - r * cbs;
           const int h = GUARD ? min(h0 + r, P.H - 1) : h0 + r, w = GUARD ? min(w0 + cb * 16 + j, P.W - 1) : w0 + cb * 16 + j;
-          const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch + (ch_ok ? ch0 : 0);
-          yr[tt][0] = *reinterpret_cast<const u32x4s*>(yp);
-          yr[tt][1] = *reinterpret_cast<const u32x4s*>(yp + 8);
+          const u16* yp = P.bw_y + ((long long)(n * P.H + h) * P.W + w) * P.bw_pitch;
+          yr[tt][0] = *reinterpret_cast<const u32x4s*>(yp + (ch_ok[0] ? ch0 : 0));
+          yr[tt][1] = *reinterpret_cast<const u32x4s*>(yp + (ch_ok[1] ? ch0 + 32 : 0));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           unsigned pk[2 * MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const int cl = wm * 64 + g * 16 + m * 4;
+            const int cl = wm * 64 + (m >> 1) * 32 + g * 8 + (m & 1) * 4;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
             const f32x4 mu = *reinterpret_cast<const f32x4*>(sBw + 2 * BM + cl), is = *reinterpret_cast<const f32x4*>(sBw + 3 * BM + cl);
             const unsigned y01 = yr[tt][m >> 1][(m & 1) * 2], y23 = yr[tt][m >> 1][(m & 1) * 2 + 1];
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
             const unsigned lo = pack_bf16(dz[0], dz[1]), hi = pack_bf16(dz[2], dz[3]);
             pk[2 * m] = lo;
             pk[2 * m + 1] = hi;
-            if (ch_ok && pix_ok) {
+            if (ch_ok[m >> 1] && pix_ok) {
               const float q[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
                                   __uint_as_float(hi & 0xffff0000u)};   // sums of the values as stored
 #pragma unroll
@@ -375,10 +378,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
               }
             }
           }
-          if (ch_ok && pix_ok) {
-            *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *reinterpret_cast<u32x4s*>(ot + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-          }
+          if (ch_ok[0] && pix_ok) *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          if (ch_ok[1] && pix_ok) *reinterpret_cast<u32x4s*>(ot + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -389,13 +390,13 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         const int r = nt / cbs, cb = nt - r * cbs;
         const int h = h0 + r, w = w0 + cb * 16 + j;
         const bool pix_ok = !GUARD || (h < P.H && w < P.W);
-        u16* ot = P.out + ((long long)(n * P.Hob + sm * h) * P.Wob + sm * w) * P.out_pitch + ooff;
+        u16* ot = P.out + ((long long)(n * P.Hob + sm * h) * P.Wob + sm * w) * P.out_pitch;
         unsigned pk[2 * MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           f32x4 v = acc[m][t];
           if (P.ep_scale != nullptr) {
-            const int cl = wm * 64 + g * 16 + m * 4;
+            const int cl = wm * 64 + (m >> 1) * 32 + g * 8 + (m & 1) * 4;
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sBw + cl), sh = *reinterpret_cast<const f32x4*>(sBw + BM + cl);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           const unsigned hi = pack_bf16(v[2], v[3]);
           pk[2 * m] = lo;
           pk[2 * m + 1] = hi;
-          if (ch_ok && pix_ok && P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
+          if (ch_ok[m >> 1] && pix_ok && P.partials != nullptr) {   // statistics of the values as stored (what the BatchNorm kernel will read back)
             const float q0 = __uint_as_float(lo << 16), q1 = __uint_as_float(lo & 0xffff0000u);
             const float q2 = __uint_as_float(hi << 16), q3 = __uint_as_float(hi & 0xffff0000u);
             s1[m][0] += q0; s2[m][0] = fmaf(q0, q0, s2[m][0]);
@@ -413,10 +414,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
             s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
           }
         }
-        if (ch_ok && pix_ok) {
-          *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          *reinterpret_cast<u32x4s*>(ot + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-        }
+        if (ch_ok[0] && pix_ok) *reinterpret_cast<u32x4s*>(ot + ooff[0]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        if (ch_ok[1] && pix_ok) *reinterpret_cast<u32x4s*>(ot + ooff[1]) = u32x4{pk[4], pk[5], pk[6], pk[7]};
       }
     }
   };
@@ -426,15 +425,15 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     // The block is persistent, so its statistics are too: per item the 16-lane rows are summed with DPP and the totals
     // added into the block's LDS cells; ONE partial row per (block, wave) leaves for HBM at the very end (a few hundred
     // rows per launch instead of one per pixel tile, so the column reduction behind it is nearly free).
-    float* cell = sSt + wave * 128 + g * 16;   // cell index = channel offset inside the wave's 64: g*16 + m*4 + r
+    float* cell = sSt + wave * 128 + g * 8;    // cell index = channel offset inside the wave's 64: (m>>1)*32 + g*8 + (m&1)*4 + r
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
         if (j == 15) {
-          cell[m * 4 + r] += a1;
-          cell[64 + m * 4 + r] += a2;
+          cell[(m >> 1) * 32 + (m & 1) * 4 + r] += a1;
+          cell[64 + (m >> 1) * 32 + (m & 1) * 4 + r] += a2;
         }
       }
   }
