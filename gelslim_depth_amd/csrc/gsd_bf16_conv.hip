@@ -226,6 +226,11 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   decode(item, n, h0, w0);
   prep(h0, w0);
   issue(0, 0, n, h0, w0);
+  float s1[MT][4], s2[MT][4];   // this lane's running BatchNorm sums over all the block's items
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
   while (true) {
   // The accumulators start at the bias (MODE 1 only): no load is then left for the epilogue, where it would sit between
   // the stores -- loads and stores share vmcnt on gfx950, and hipcc answers a load of unknown age inside divergent
@@ -303,12 +308,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
   }
 
-  // ---- epilogue: bf16 store (4 consecutive channels per lane), optional bias / scatter / BatchNorm partial sums ----
-  float s1[MT][4], s2[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+  // ---- epilogue: bf16 store (16 channels per lane and pixel), optional bias / scatter / BatchNorm partial sums -----------
 
   // A lane's 16 output channels are two runs of 8 (see the file header): resolve them / their scatter quadrants once
   const int ch0 = m0 + wm * 64 + g * 8;    // first channel of the lane's run A (m-tiles 0, 1); run B (m-tiles 2, 3) starts 32 later
@@ -421,22 +421,6 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   };
   if (interior) epilogue(std::integral_constant<bool, false>{});
   else epilogue(std::integral_constant<bool, true>{});
-  if (P.partials != nullptr) {
-    // The block is persistent, so its statistics are too: per item the 16-lane rows are summed with DPP and the totals
-    // added into the block's LDS cells; ONE partial row per (block, wave) leaves for HBM at the very end (a few hundred
-    // rows per launch instead of one per pixel tile, so the column reduction behind it is nearly free).
-    float* cell = sSt + wave * 128 + g * 8;    // cell index = channel offset inside the wave's 64: (m>>1)*32 + g*8 + (m&1)*4 + r
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
-        if (j == 15) {
-          cell[(m >> 1) * 32 + (m & 1) * 4 + r] += a1;
-          cell[64 + (m >> 1) * 32 + (m & 1) * 4 + r] += a2;
-        }
-      }
-  }
   if (next >= P.nitems) break;
   item = next;
   n = nn;
@@ -444,6 +428,23 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   w0 = nw0;
   }
   gsd_dma_barrier();   // vmcnt(0): the last (unread) fill must have landed before the block gives its LDS back
+  if (P.partials != nullptr) {
+    // The block is persistent, so its statistics are too: every lane has summed its pixels of ALL the block's items in
+    // registers; the 16-lane rows are summed with DPP once, here, and ONE partial row per (block, wave) leaves for HBM (a few
+    // hundred rows per launch instead of one per pixel tile, so the column reduction behind it is nearly free).
+    float* cell = sSt + wave * 128 + g * 8;    // cell index = channel offset inside the wave's 64: (m>>1)*32 + g*8 + (m&1)*4 + r
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a1 = reduce16_to_lane15(s1[m][r]), a2 = reduce16_to_lane15(s2[m][r]);
+        if (j == 15) {
+          cell[(m >> 1) * 32 + (m & 1) * 4 + r] = a1;
+          cell[64 + (m >> 1) * 32 + (m & 1) * 4 + r] = a2;
+        }
+      }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's cells are written (the row below is read by the same wave)
+  }
   if (P.partials != nullptr && lane < 64) {
     float* row = P.partials + (size_t)((blockIdx.x / P.mblocks) * WN + wn) * (2 * P.Mpad);
     const int mrow = m0 + wm * 64 + lane;
