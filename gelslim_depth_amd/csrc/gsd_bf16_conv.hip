@@ -271,26 +271,34 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
     const unsigned char* Wc = Wl + (git & 1) * WBUF + aoff;
     const unsigned char* Xc = MODE == 0 ? Xl + ((git / 3) & 1) * XBUF + KH * P.HC * 96 : Xl + (git & 1) * XBUF;
-    u32x4 a[2][MT], b[2][NT];
+    u32x4 a[2][MT], b[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(Wc + m * 1024);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b[0][t] = *reinterpret_cast<const u32x4*>(Xc + boff[t]);
+    for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const u32x4*>(Xc + boff[t]);
     __builtin_amdgcn_sched_barrier(0);
+    constexpr int BSTEP = MODE == 0 ? 96 : NPX * 96;   // B operand of the next tap: one pixel on (MODE 0), the next plane (MODE 1)
 #pragma unroll
     for (int kw = 0; kw < NTAPI; ++kw) {
-      // 16 micro-steps of {two MFMAs, one operand read for the next tap, one DMA slot}, pinned in this order: the
+      // 16 micro-steps of {two MFMAs, one or two operand reads for the next tap, one DMA slot}, pinned in this order: the
       // LDS-touching instructions (ds_read, global_load_lds) keep their program order anyway, so the interleaving has to
       // be written out -- a sched_group_barrier pattern over the whole tap leaves the reads bunched in front.
+      // Order: pixel-tile PAIR major (micro-step i: tiles 2(i/4), 2(i/4)+1 x m-tile i%4): a pair's B operands are dead after
+      // four micro-steps and are re-read IN PLACE for the next tap (one set of B registers instead of two); the last pair's
+      // at the start of the next tap.  The A operands (all four live through the tap) stay double-buffered.
 #pragma unroll
       for (int i = 0; i < MT * NT / 2; ++i) {
-        const int m = i / (NT / 2), t = 2 * (i % (NT / 2));
-        acc[m][t] = mfma_bf16(a[kw & 1][m], b[kw & 1][t], acc[m][t]);
-        acc[m][t + 1] = mfma_bf16(a[kw & 1][m], b[kw & 1][t + 1], acc[m][t + 1]);
+        const int m = i % MT, t = 2 * (i / MT);
+        acc[m][t] = mfma_bf16(a[kw & 1][m], b[t], acc[m][t]);
+        acc[m][t + 1] = mfma_bf16(a[kw & 1][m], b[t + 1], acc[m][t + 1]);
         if (kw + 1 < NTAPI) {
           if (i < MT) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + i * 1024);
-          else if (i < MT + NT) b[(kw + 1) & 1][i - MT] = *reinterpret_cast<const u32x4*>(Xc + boff[i - MT] + (kw + 1) * (MODE == 0 ? 96 : NPX * 96));
+          if (i >= MT && (i % MT) < 2) {   // i = 4, 5 -> b[0], b[1]; 8, 9 -> b[2], b[3]; 12, 13 -> b[4], b[5]
+            const int bt = 2 * (i / MT - 1) + (i % MT);
+            b[bt] = *reinterpret_cast<const u32x4*>(Xc + boff[bt] + (kw + 1) * BSTEP);
+          }
         }
+        if (kw > 0 && i < 2) b[NT - 2 + i] = *reinterpret_cast<const u32x4*>(Xc + boff[NT - 2 + i] + kw * BSTEP);   // the last pair
         if (i < SPT && kw * SPT + i < NS) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
         __builtin_amdgcn_sched_barrier(0);
       }
