@@ -403,6 +403,156 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_dma_kernel(const ConvTFwdPar
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// DGRAD on the same LDS-DMA template:  dx[ci][q] = sum_{co,kh,kw} W[ci][co][kh][kw] * dy[co][2h+kh][2w+kw]  (q = low-res pixel).
+// Block tile 128 (m = ci) x 128 pixels, K walked in chunks of 32 k-rows = 8 output channels x (kh, kw); weights as 16 one-KiB
+// pieces of a [chunk][32][128] image with permuted columns (gsd_weight_layout mode 7: a lane's four A operands are one
+// ds_read_b128).  The B operand is dy read with stride 2 in both directions -- as dword gathers that would be 64 DMA
+// instructions per wave and chunk.  Instead an LDS row holds, for one (co, kh), the dy values of the tile's 128 low-res
+// pixels with kw = 0 / 1 INTERLEAVED: 256 floats = 64 sixteen-byte pieces, a piece = two low-res pixels = four consecutive
+// dy floats of row 2h+kh, one DMA instruction per row (16 per chunk, 4 per wave).  A lane reads the 8 floats of its four
+// pixels (two ds_read_b128) once per PAIR of k-steps and feeds the even floats to the kw = 0 step, the odd ones to kw = 1.
+// Piece p of a row is stored at slot p ^ ((p >> 4) & 1): lanes l and l + 8 of a read then hit different bank groups.
+// Pixels are tiled over the flattened VIRTUAL grid q' = (n*H + h)*W' + w with W' = W rounded up to even, so a pair never
+// straddles a row; the virtual last column of an odd-width plane (53, 213) is computed and not stored -- its piece reads two
+// floats past the end of a dy row, i.e. the next row's, and past the tensor for the very last row: the caller vouches for
+// 2 readable floats behind the tensor (gsd_src.slack) or gets the register-staged kernel above.
+struct ConvTDgParams {
+  SrcD src;           // dy (Cout, 2H, 2W), plain
+  DstD dst;           // dx (Cin, H, W)
+  const float* wt;    // mode 7: [mblock][Kpad][128], k = co*4 + kh*2 + kw
+  int K, Kpad, M, nchunks, mblocks;
+  int N, H, W, Wv, tiles_flat;
+};
+
+__global__ __launch_bounds__(256, 2) void convT_dgrad_dma_kernel(const ConvTDgParams P) {
+  constexpr int BM = 128, BN = 128, KC = 32, MT = 4, NT = 4;
+  constexpr int WIMG = KC * BM, XIMG = (KC / 2) * (2 * BN), BUF = WIMG + XIMG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);   // the m-blocks of a pixel tile share the dy tile: one XCD's L2
+  const int mb = lid % P.mblocks;
+  const int pt = lid / P.mblocks;
+  const int m0 = mb * BM;
+  const long long q0 = (long long)pt * BN;              // first virtual pixel of the tile
+  const int HWv = P.H * P.Wv;
+  const long long QT = (long long)P.N * HWv;
+
+  // ---- DMA lane geometry ---------------------------------------------------------------------------------------------------
+  const float* const wsrc = P.wt + (size_t)mb * P.Kpad * BM + lane * 4;
+  // dy: lane = physical slot of the row; it holds piece pi = slot ^ ((slot >> 4) & 1) = virtual pixels q0 + 2 pi, + 1
+  const int pi = lane ^ ((lane >> 4) & 1);
+  long long xo = 0;        // float offset of dy[n][.][2h][2w] inside a channel-0 plane set, for kh = 0
+  bool xok;
+  {
+    const long long q = q0 + 2 * pi;
+    xok = q < QT;
+    const int nn = xok ? (int)(q / HWv) : 0;
+    const int rem = xok ? (int)(q - (long long)nn * HWv) : 0;
+    const int h = rem / P.Wv, w = rem - h * P.Wv;       // w even, w < W (w + 1 may be the virtual column)
+    xo = (long long)nn * P.src.ns + (long long)(2 * h) * P.src.ws + 2 * w;
+  }
+  auto fill = [&](int chunk, int buf) {
+    float* Wb = smem + buf * BUF;
+    float* Xb = Wb + WIMG;
+    const float* wc = wsrc + (size_t)chunk * WIMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(wc + (wave + 4 * i) * 256, Wb + (wave + 4 * i) * 256, 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave + 4 * i;                        // LDS row = (co_local = r >> 1, kh = r & 1)
+      const int co = chunk * 8 + (r >> 1);
+      const float* g = (xok && co < P.src.C) ? P.src.p + xo + (long long)co * P.src.cs + (long long)(r & 1) * P.src.ws
+                                              : &gsd_zero16_ct[0];
+      __builtin_amdgcn_global_load_lds(g, Xb + r * 256, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A: k-row 8 p + 2 j + kw of the chunk image (pair p, sub-step kw); B: row 4 p + j = (co_local 2p + (j >> 1), kh = j & 1),
+  // logical pieces 2 (wn*16 + l16) and + 1 of it (pixels wn*64 + 4 l16 .. + 3), stored swizzled
+  const int a_off = (2 * j) * BM + wm * 64 + l16 * 4;
+  const int lp = 2 * (wn * 16 + l16);
+  const int b_off0 = WIMG + j * 256 + 4 * (lp ^ ((lp >> 4) & 1));
+  const int b_off1 = WIMG + j * 256 + 4 * ((lp + 1) ^ (((lp + 1) >> 4) & 1));
+  fill(0, 0);
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    gsd_dma_barrier();   // this chunk has landed; everyone has left the other image
+    if (chunk + 1 < P.nchunks) fill(chunk + 1, cur ^ 1);
+    const float* Sb = smem + cur * BUF;
+    f32x4 av[2], x0[2], x1[2];
+    av[0] = *reinterpret_cast<const f32x4*>(&Sb[a_off]);
+    x0[0] = *reinterpret_cast<const f32x4*>(&Sb[b_off0]);
+    x1[0] = *reinterpret_cast<const f32x4*>(&Sb[b_off1]);
+#pragma unroll
+    for (int s = 0; s < KC / 4; ++s) {          // s = 2 p + kw
+      const int p = s >> 1, kw = s & 1, c = s & 1, pc = p & 1;
+      if (s + 1 < KC / 4) {   // the next k-step's operands fly during this one's MFMAs
+        av[c ^ 1] = *reinterpret_cast<const f32x4*>(&Sb[a_off + ((s + 1) >> 1) * 8 * BM + ((s + 1) & 1) * BM]);
+        if (kw == 1) {
+          x0[pc ^ 1] = *reinterpret_cast<const f32x4*>(&Sb[b_off0 + (p + 1) * 4 * 256]);
+          x1[pc ^ 1] = *reinterpret_cast<const f32x4*>(&Sb[b_off1 + (p + 1) * 4 * 256]);
+        }
+      }
+      const float b[NT] = {x0[pc][kw], x0[pc][2 + kw], x1[pc][kw], x1[pc][2 + kw]};
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = mfma16(av[c][m], b[t], acc[m][t]);
+    }
+  }
+
+  // ---- epilogue: acc[m][t][reg] = dx[ci = m0 + wm*64 + m*16 + 4j + reg][virtual pixel qa + t]; a lane owns 4 consecutive
+  // virtual pixels: one 16-byte store per (m, reg) when they are 4 real pixels of one image row
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  const DstD& D = P.dst;
+  const long long qa = q0 + wn * 64 + l16 * 4;
+  if (qa < QT) {
+    const int na = (int)(qa / HWv);
+    const int ra = (int)(qa - (long long)na * HWv);
+    const int ha = ra / P.Wv, wa = ra - ha * P.Wv;
+    if (wa + 3 < P.W) {
+      float* const o = D.p + (long long)na * D.ns + (long long)ha * D.ws + wa;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ci = m0 + wm * 64 + m * 16 + j * 4 + reg;
+          if (ci < D.C)
+            *reinterpret_cast<f32x4u*>(o + (long long)ci * D.cs) = f32x4{acc[m][0][reg], acc[m][1][reg], acc[m][2][reg], acc[m][3][reg]};
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const long long q = qa + t;
+        if (q >= QT) continue;
+        const int nn = (int)(q / HWv);
+        const int r = (int)(q - (long long)nn * HWv);
+        const int h = r / P.Wv, w = r - h * P.Wv;
+        if (w >= P.W) continue;                       // the virtual column
+        float* const o = D.p + (long long)nn * D.ns + (long long)h * D.ws + w;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int ci = m0 + wm * 64 + m * 16 + j * 4 + reg;
+            if (ci < D.C) o[(long long)ci * D.cs] = acc[m][t][reg];
+          }
+      }
+    }
+  }
+}
+
 template <int MODE, int WM, int WN>
 int launch(const ConvTParams& P, int grid, size_t lds, hipStream_t st, const char* what) {
   hipLaunchKernelGGL((convT_kernel<MODE, WM, WN>), dim3(grid), dim3(256), lds, st, P);
@@ -473,6 +623,17 @@ extern "C" int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bi
   return GSD_OK;
 }
 
+// Which gsd_weight_layout mode gsd_convT2x2_dgrad expects for these arguments: 7 (the LDS-DMA kernel) unless an odd-width
+// plane comes without the two readable floats behind the tensor that its virtual last column reads (gsd_src.slack), or the
+// tuning switch GSD_CONVT_DG_DMA=0 asks for the register-staged kernel: then 3.
+extern "C" int gsd_convT2x2_dgrad_layout(const gsd_src* src, int Cin, int Cout, int N, int H, int W) {
+  if (src == nullptr || Cin <= 0 || Cout <= 0 || N <= 0 || H <= 0 || W <= 0) return 3;
+  if (gsd_env_int("GSD_CONVT_DG_DMA", 1) == 0) return 3;
+  if ((W & 1) && src->slack < 2) return 3;
+  if ((int64_t)N * src->n_stride >= (1LL << 40)) return 3;
+  return 7;
+}
+
 extern "C" int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, int N,
                                   int H, int W, void* stream) {
   GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: null argument");
@@ -486,6 +647,32 @@ extern "C" int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, 
               GSD_ERR_UNSUPPORTED, "gsd_convT2x2_dgrad: src must be 8-byte aligned with even strides");
   GSD_REQUIRE(dst->C == Cin && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
               "gsd_convT2x2_dgrad: dst must be (Cin,H,W)");
+  if (gsd_convT2x2_dgrad_layout(src, Cin, Cout, N, H, W) == 7) {
+    GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: the weight image must be 16-byte aligned");
+    ConvTDgParams Q;
+    Q.src = to_srcd(*src);
+    Q.dst = to_dstd(*dst);
+    Q.wt = wt;
+    Q.K = Cout * 4;
+    Q.Kpad = round_up(Cout, 8) * 4;
+    Q.M = Cin;
+    Q.nchunks = Q.Kpad / 32;
+    Q.mblocks = ceil_div(Cin, 128);
+    Q.N = N; Q.H = H; Q.W = W;
+    Q.Wv = round_up(W, 2);
+    Q.tiles_flat = (int)ceil_div64((int64_t)N * H * Q.Wv, 128);   // pixel tiles over the whole batch's virtual grid
+    const long grid = (long)Q.tiles_flat * Q.mblocks;
+    GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_convT2x2_dgrad: grid too large");
+    const size_t lds = (size_t)(2 * (32 * 128 + 16 * 256)) * sizeof(float);   // 64 KiB: two blocks per CU
+    static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+    if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_dgrad_dma_kernel)); e != hipSuccess) {
+      gsd_set_error("gsd_convT2x2_dgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return GSD_ERR_HIP;
+    }
+    hipLaunchKernelGGL(convT_dgrad_dma_kernel, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, Q);
+    GSD_LAUNCH_CHECK("gsd_convT2x2_dgrad");
+    return GSD_OK;
+  }
   ConvTParams P;
   P.src = to_srcd(*src);
   P.dst = to_dstd(*dst);

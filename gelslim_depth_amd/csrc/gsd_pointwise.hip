@@ -49,6 +49,7 @@ extern "C" int gsd_selftest_mfma(const float* a, const float* b, float* out, voi
 // modes 2/3 (convT): plain [k row][Mpad].
 // mode 6 (convT forward, LDS-DMA kernel): like modes 0/1 with BM = 128 and k rows padded to 32: [mblock][k row][128],
 //   one K-chunk of 32 input channels of one m-block is one contiguous 16 KiB LDS image, columns permuted as above.
+// mode 7 (convT dgrad, LDS-DMA kernel): the same image shape with k = co*4+kh*2+kw (8 output channels per chunk), m = ci.
 static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, int* pitch, int* mblocks) {
   switch (mode) {
     case 0: *rows = round_up(Ci, 4) * 9; *M = Co; break;        // k = ci*9+t        m = co
@@ -57,9 +58,10 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
     case 3: *rows = round_up(Co, 4) * 4; *M = Ci; break;        // k = co*4+khkw     m = ci
     case 4: *rows = round_up(Ci, 4) * 18; *M = Co; break;       // k = ci*18+r*6+f   m = co   (Winograd F(4,3) rows)
     case 5: *rows = round_up(Co, 4) * 18; *M = Ci; break;       // k = co*18+r*6+f (flip) m = ci
+    case 7: *rows = round_up(Co, 8) * 4; *M = Ci; break;        // k = co*4+khkw     m = ci   (convT dgrad, LDS-DMA kernel)
     default: *rows = round_up(Ci, 32); *M = Co * 4; break;      // k = ci            m = co*4+khkw  (mode 6)
   }
-  if (mode == 6) {
+  if (mode == 6 || mode == 7) {
     *BM = 128;
     *pitch = 128;
     *mblocks = ceil_div(*M, 128);
@@ -78,7 +80,7 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
   }
 }
 extern "C" int64_t gsd_weight_layout_size(int mode, int Co, int Ci) {
-  if (mode < 0 || mode > 6 || Co <= 0 || Ci <= 0) return 0;
+  if (mode < 0 || mode > 7 || Co <= 0 || Ci <= 0) return 0;
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
   return (int64_t)mblocks * rows * pitch;
@@ -106,6 +108,8 @@ __global__ void weight_layout_kernel(int mode, const float* __restrict__ w, int 
         if (co < Co) v = w[((size_t)co * Ci + m) * 9 + (8 - tp)];
       } else if (mode == 6) {
         if (k < Ci) v = w[(size_t)k * M + m];  // (Ci, Co*4) is already [k][m]
+      } else if (mode == 7) {
+        if ((k >> 2) < Co) v = w[(size_t)m * (Co * 4) + k];   // W[ci][co][kh][kw] -> [k = co*4+kh*2+kw][m = ci]
       } else if (mode >= 4) {
         // U = G g for the 3 taps g of kernel row r (dX: the flipped kernel, channels swapped), G of F(4,3):
         // rows (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void weight_layout_w43_kernel(int mode, const 
   }
 }
 extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
-  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 6 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
+  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 7 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
   if (mode == 4 || mode == 5) {

@@ -78,6 +78,7 @@ class _Up:
         self.j, self.cin, self.cout, self.level_in = j, cin, cin // 2, level_in
         self.wname, self.bname = f"up.{j}.up.weight", f"up.{j}.up.bias"
         self.wt_f = self.wt_d = None
+        self.mode_d = 3            # gsd_weight_layout mode of wt_d (gsd_convT2x2_dgrad_layout)
         self.out = self.dout = None
 
 
@@ -181,10 +182,14 @@ class UNetEngine:
             if up.out is None:
                 up.out = L.slack_empty((n, up.cout, 2 * hs[li], 2 * ws[li]), dev)
             if train and up.dout is None:
-                up.dout = torch.empty((n, up.cout, 2 * hs[li], 2 * ws[li]), **f32)
+                up.dout = L.slack_empty((n, up.cout, 2 * hs[li], 2 * ws[li]), dev)   # ConvT dX reads pixel PAIRS: 2 floats past odd rows
             if up.wt_f is None or up.wt_f.device != dev:
                 up.wt_f = torch.empty((lib.gsd_weight_layout_size(6, up.cout, up.cin),), **f32)
-                up.wt_d = torch.empty((lib.gsd_weight_layout_size(3, up.cout, up.cin),), **f32)
+            if train:
+                up.mode_d = lib.gsd_convT2x2_dgrad_layout(C.byref(L.make_src(up.dout, slack=L.SLACK)), up.cin, up.cout, n, hs[li], ws[li])
+                need = lib.gsd_weight_layout_size(up.mode_d, up.cout, up.cin)
+                if up.wt_d is None or up.wt_d.numel() != need or up.wt_d.device != dev:
+                    up.wt_d = torch.empty((need,), **f32)
             if train:
                 max_ws = max(max_ws, lib.gsd_convT2x2_wgrad_workspace(n, hs[li], ws[li], up.cin, up.cout))
         self.pooled = [None] + [L.slack_empty((n, self.dims[l - 1], hs[l], ws[l]), dev) for l in range(1, self.L + 1)]
@@ -428,11 +433,11 @@ class UNetEngine:
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
             xs = self._act_src(prev)
-            dys = L.make_src(up.dout)
+            dys = L.make_src(up.dout, slack=L.SLACK)
             check(lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
                                          None if db_fused else G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(),
                                          self.wgrad_ws.numel(), n, hi, wi, st), "convT2x2_wgrad")
-            check(lib.gsd_weight_layout(3, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
+            check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
             check(lib.gsd_convT2x2_dgrad(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
                   "convT2x2_dgrad")

@@ -105,6 +105,7 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * mode 4: conv3x3 forward, Winograd F(4,3) rows: k = ci*18+r*6+f, m = co   (see gsd_conv3x3_w43)
  * mode 5: conv3x3 dgrad,   Winograd F(4,3) rows: k = co*18+r*6+f (flipped kernel), m = ci
  * mode 6: convT   forward, LDS-DMA kernel: k = ci (rows padded to 32), m = co*4+kh*2+kw in 128-column blocks
+ * mode 7: convT   dgrad,   LDS-DMA kernel: k = co*4+kh*2+kw (rows padded to 32), m = ci in 128-column blocks
  * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM] with BM = 64 (M <= 64) or 128, columns
  * permuted inside each 64-group (slot l*4+t = column t*16+l), so one K-chunk of one m-block is a contiguous LDS
  * image whose A operands are aligned float4s; modes 2/3 are [k row][M rounded up to 64].
@@ -150,7 +151,10 @@ int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, i
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 6. */
 int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin, int Cout,
                  const gsd_dst* dst, int N, int H, int W, void* stream);
-/* dX of the above: src = gradient w.r.t. the (2h,2w) output (plain), dst (h,w). weights: mode 3. */
+/* dX of the above: src = gradient w.r.t. the (2h,2w) output (plain), dst (h,w).  weights: the gsd_weight_layout mode that
+ * gsd_convT2x2_dgrad_layout returns for the same arguments -- 7 (LDS-DMA kernel; an odd-width plane needs src->slack >= 2:
+ * its last pixel pair reads two floats past the end of a row) or 3 (register-staged kernel). */
+int gsd_convT2x2_dgrad_layout(const gsd_src* src, int Cin, int Cout, int N, int H, int W);
 int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout,
                        const gsd_dst* dst, int N, int H, int W, void* stream);
 

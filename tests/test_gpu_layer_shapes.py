@@ -277,11 +277,14 @@ def test_convT_at_network_shape(gsd, case, n):
         dwr = np.zeros((ci, co, 2, 2), np.float64)
         for i in range(0, n, 4):
             dwr += on.convT_bwd(x[i:i + 4], wt_, dy[i:i + 4])[1]
-    dyd = dev(dy)
+    dyd = slack_dev(gsd, dy)           # as the engine allocates up.dout
     dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
-    sdy, ddx = gsd.make_src(dyd), gsd.make_dst(dx)
-    gsd.check(L.gsd_convT2x2_dgrad(C.byref(sdy), layout(gsd, 3, wd, co, ci).data_ptr(), ci, co, C.byref(ddx), n, h, w,
+    sdy, ddx = gsd.make_src(dyd, slack=gsd.SLACK), gsd.make_dst(dx)
+    mode = L.gsd_convT2x2_dgrad_layout(C.byref(sdy), ci, co, n, h, w)
+    assert mode == 7, "the LDS-DMA dX kernel runs at every level of the network"
+    gsd.check(L.gsd_convT2x2_dgrad(C.byref(sdy), layout(gsd, mode, wd, co, ci).data_ptr(), ci, co, C.byref(ddx), n, h, w,
                                    gsd.stream_ptr()))
+    assert bool(torch.isfinite(dx).all())
     assert rel_l1(dx.cpu().numpy(), dxr) < 2e-5
     need = L.gsd_convT2x2_wgrad_workspace(n, h, w, ci, co)
     ws = torch.zeros(need, device="cuda")

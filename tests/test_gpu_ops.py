@@ -187,8 +187,8 @@ def test_conv3x3_wgrad_two_segments(gsd, n, c0, c1, co, h, w, uh, uw):
     assert rel_l1(got[:, c0:], dwr[:, c0:]) < 5e-5      # the offset segment on its own
 
 
-@pytest.mark.parametrize("n,ci,h,w", [(2, 8, 4, 5), (1, 128, 20, 26), (2, 36, 7, 9)])
-def test_convT_fwd_bwd(gsd, n, ci, h, w):
+@pytest.mark.parametrize("n,ci,h,w", [(2, 8, 4, 5), (1, 128, 20, 26), (2, 36, 7, 9), (3, 24, 5, 53), (1, 264, 3, 2), (2, 16, 1, 1)])
+def test_convT_fwd_bwd(gsd, monkeypatch, n, ci, h, w):
     from oracle import unet_numpy as on
     rng = np.random.default_rng(ci)
     co = ci // 2
@@ -207,12 +207,25 @@ def test_convT_fwd_bwd(gsd, n, ci, h, w):
     dy = rnd(rng, n, co, 2 * h, 2 * w)
     dxr, dwr, dbr = on.convT_bwd(x, wt_, dy)
     dyd = dev(dy)
-    dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
     sdy = gsd.make_src(dyd)
-    ddx = gsd.make_dst(dx)
-    gsd.check(gsd.lib.gsd_convT2x2_dgrad(C.byref(sdy), layout(gsd, 3, wd, co, ci).data_ptr(), ci, co, C.byref(ddx), n, h, w,
-                                         gsd.stream_ptr()))
-    assert rel_l1(dx.cpu().numpy(), dxr) < TOL
+    # dX: the LDS-DMA kernel (weight layout 7; an odd-width plane needs 2 readable floats behind dy: gsd_src.slack) and the
+    # register-staged kernel (layout 3) -- gsd_convT2x2_dgrad_layout says which one a call will run
+    dys = gsd.slack_empty(dyd.shape, "cuda")
+    dys.copy_(dyd)
+    for src_, env in ((gsd.make_src(dys, slack=gsd.SLACK), None), (sdy, "0")):
+        if env is not None:
+            monkeypatch.setenv("GSD_CONVT_DG_DMA", env)
+        mode = gsd.lib.gsd_convT2x2_dgrad_layout(C.byref(src_), ci, co, n, h, w)
+        assert mode == (7 if env is None else 3)
+        dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        ddx = gsd.make_dst(dx)
+        gsd.check(gsd.lib.gsd_convT2x2_dgrad(C.byref(src_), layout(gsd, mode, wd, co, ci).data_ptr(), ci, co, C.byref(ddx), n, h, w,
+                                             gsd.stream_ptr()))
+        assert bool(torch.isfinite(dx).all())
+        assert rel_l1(dx.cpu().numpy(), dxr) < TOL, mode
+    monkeypatch.delenv("GSD_CONVT_DG_DMA")
+    if w % 2:      # an odd width without slack falls back to the register-staged kernel instead of reading past the tensor
+        assert gsd.lib.gsd_convT2x2_dgrad_layout(C.byref(sdy), ci, co, n, h, w) == 3
     need = gsd.lib.gsd_convT2x2_wgrad_workspace(n, h, w, ci, co)
     ws = torch.zeros(need, device="cuda")
     dw = torch.full((ci, co, 2, 2), float("nan"), device="cuda")
