@@ -296,6 +296,10 @@ class UNetEngine:
                 srcs = [L.make_src(self.pooled[lvl], slack=L.SLACK)]
             self._run_unit(u0, srcs, P, train, st)
             self._run_unit(u1, [self._act_src(u0)], P, train, st)
+        if self.L == 0 and region is not None:          # a one-level network (profiles/inc_block.py): the block ends here
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.region_log.append(("inc_forward", region, e))
         cur = self.enc[self.L][1]
         for j in range(self.L):
             up = self.ups[j]

@@ -1,7 +1,7 @@
 """Build profiles/traffic.json from three rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 0` (FETCH_SIZE; WRITE_SIZE;
 SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), as written by profiles/run_pmc.sh.  All template variants of the dominant
 kernel are pooled.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM).
-usage: python profiles/make_traffic.py <tag>     (reads gpurun_out/<tag>_{fetch,write,sq}_pmc.txt, profiles named r02_*)"""
+usage: python profiles/make_traffic.py <tag>     (reads gpurun_out/<tag>_{fetch,write,sq}_pmc.txt, profiles named per round)"""
 import json
 import re
 import sys
