@@ -207,7 +207,20 @@ class Leg:
         avg = sum(ms) / len(ms)
         by = INC_ALGO_BYTES_PER_IMAGE_FP32 * self.B * (0.5 if self.dtype == "bf16" else 1.0)
         tbs = by / (avg * 1e-3) / 1e12
-        return {"bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
+        # the bytes the block REALLY moves: not observed by this run -- the committed rocprofv3 --pmc passes over the block on
+        # its own (profiles/inc_block.py, batch 32; FETCH_SIZE x 2 + WRITE_SIZE, summed over its kernels)
+        traffic = traffic_src = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "inc_traffic.json")))["bf16" if self.dtype == "bf16" else "fp32"]
+            traffic = round(float(tj["hbm_bytes_per_run"]) * self.B / 32.0)
+            traffic_src = "profiles/inc_traffic.json (committed rocprofv3 --pmc passes: %s), scaled by batch / 32" % ", ".join(tj["sources"])
+        except (OSError, ValueError, KeyError):
+            pass
+        extra = {}
+        if traffic:
+            extra = {"traffic": traffic, "traffic_source": traffic_src, "traffic_vs_algorithmic": round(traffic / by, 3),
+                     "traffic_TBps": round(traffic / (avg * 1e-3) / 1e12, 3)}
+        return {**extra, "bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
                 + ("im2col + 2 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
                    else "direct conv + Winograd conv + BN statistics launches"),
                 "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),

@@ -100,6 +100,8 @@ SIGNATURES = {
     "gsd_maxpool2": (_I, [_SRC, _P, _I, _I, _I, _I, _P]),
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
     "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _GUARD, _P]),
+    "gsd_guard_snapshot": (_I, [_P, _P, _L, _P]),
+    "gsd_guard_restore": (_I, [_GUARD, _P, _P, _L, _P]),
     "gsd_adam_ema": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _GUARD, _P]),
     "gsd_bn_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _GUARD, _P]),
     "gsd_bn_bwd_reduce_finalize": (_I, [_P, _I, _I, _I, _P, _D, _P, _P, _P, _P, _P, _P]),

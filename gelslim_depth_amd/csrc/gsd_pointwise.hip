@@ -1049,6 +1049,30 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
     }
   }
 }
+// A skipped step leaves no trace in the BatchNorm running statistics: snapshot before the step, conditional restore behind it
+__global__ void guard_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, const int* guard_words,
+                                  int tick) {
+  if (guard_words != nullptr && guard_words[0] != tick) return;   // restore form: only when this step was marked bad
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int gsd_guard_snapshot(const float* live, float* snapshot, int64_t n, void* stream) {
+  GSD_REQUIRE(live && snapshot && n > 0, GSD_ERR_BAD_ARG, "gsd_guard_snapshot: bad argument");
+  const int blocks = (int)(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
+  hipLaunchKernelGGL(guard_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, live, snapshot, (long long)n,
+                     (const int*)nullptr, 0);
+  GSD_LAUNCH_CHECK("gsd_guard_snapshot");
+  return GSD_OK;
+}
+extern "C" int gsd_guard_restore(const gsd_guard* guard, float* live, const float* snapshot, int64_t n, void* stream) {
+  GSD_REQUIRE(guard && guard->words && guard->tick != 0 && live && snapshot && n > 0, GSD_ERR_BAD_ARG,
+              "gsd_guard_restore: bad argument");
+  const int blocks = (int)(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
+  hipLaunchKernelGGL(guard_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, snapshot, live, (long long)n,
+                     (const int*)guard->words, guard->tick);
+  GSD_LAUNCH_CHECK("gsd_guard_restore");
+  return GSD_OK;
+}
+
 extern "C" int gsd_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, int step, float lr,
                             float beta1, float beta2, float eps, float weight_decay, float ema_decay, float grad_scale,
                             const gsd_guard* guard, void* stream) {

@@ -132,6 +132,21 @@ class TrainStep:
         self.loss_ws = torch.empty((2048,), device=dev, dtype=torch.float64)
         # non-finite guard: words[0] = tick of the last bad step, words[1] = steps skipped (include/gsd.h: gsd_guard)
         self.guard_words = torch.zeros((2,), device=dev, dtype=torch.int32) if nan_policy is not None else None
+        # With a nan_policy a skipped step must leave no trace in the BatchNorm running statistics either (layers in front of
+        # the first bad one have updated theirs by the time the step is found bad, and every data-parallel rank must end with
+        # the same buffers): the float buffers become views of one arena that is snapshotted before the step and put back
+        # by a device-side conditional copy behind it.  (num_batches_tracked keeps counting, as it would in the reference,
+        # whose forward has run by the time its NaN test fires.)
+        self.bn_flat = self.bn_snap = None
+        if nan_policy is not None:
+            bufs = [b for _, b in model.named_buffers() if b.dtype == torch.float32]
+            self.bn_flat = torch.empty((sum(b.numel() for b in bufs),), device=dev, dtype=torch.float32)
+            o = 0
+            for b in bufs:
+                self.bn_flat[o:o + b.numel()].copy_(b.reshape(-1))
+                b.data = self.bn_flat[o:o + b.numel()].view(b.shape)
+                o += b.numel()
+            self.bn_snap = torch.empty_like(self.bn_flat)
         self._dout = None
         self._out = None
         eng = model._engine
@@ -162,6 +177,9 @@ class TrainStep:
             self._out = torch.empty((x.shape[0], model.n_classes, x.shape[2], x.shape[3]), device=x.device,
                                     dtype=torch.float32)
             self._dout = torch.empty_like(self._out)
+        if self.bn_flat is not None:
+            check(lib.gsd_guard_snapshot(self.bn_flat.data_ptr(), self.bn_snap.data_ptr(), self.bn_flat.numel(), L.stream_ptr()),
+                  "guard_snapshot")
         try:
             out = eng.forward(x, P, train=True, out=self._out)
             loss_fwd_bwd(self.loss_kind, out, target, self._dout, self.loss_buf, self.loss_ws, guard=guard)
@@ -184,6 +202,9 @@ class TrainStep:
                                self.v_flat.data_ptr(), L.ptr(self.ema_flat), self.numel, self.step_count, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.wd, d, 1.0 / self.world, guard, L.stream_ptr()),
               "adam_ema")
+        if self.bn_flat is not None:
+            check(lib.gsd_guard_restore(guard, self.bn_flat.data_ptr(), self.bn_snap.data_ptr(), self.bn_flat.numel(), L.stream_ptr()),
+                  "guard_restore")
         return self.loss_buf
 
     def skipped_steps(self) -> int:

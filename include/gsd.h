@@ -48,11 +48,17 @@ typedef enum {
  * batch statistic (gsd_bn_finalize) or loss (gsd_loss_fwd_bwd) stores `tick` (the caller's step number,
  * never 0) into words[0]; gsd_adam_ema called with the same tick then leaves parameters, moments and EMA
  * untouched and adds 1 to words[1].  No host synchronisation; the caller reads words[1] when it likes.
- * Independently of the guard, non-finite batch statistics never reach running_mean/running_var. */
+ * Independently of the guard, non-finite batch statistics never reach running_mean/running_var.
+ * Running statistics of a SKIPPED step: layers in front of the first bad one (and, racily, its finite channels) have
+ * already been updated when the step is found bad.  A caller that wants a skipped step to leave no trace -- and every
+ * data-parallel rank with the same buffers -- brackets the step with gsd_guard_snapshot / gsd_guard_restore over its
+ * BatchNorm buffer arena: the restore puts the snapshot back iff words[0] == tick. */
 typedef struct {
   int32_t* words;
   int32_t tick;
 } gsd_guard;
+int gsd_guard_snapshot(const float* live, float* snapshot, int64_t n, void* stream);
+int gsd_guard_restore(const gsd_guard* guard, float* live, const float* snapshot, int64_t n, void* stream);
 
 /* One channel segment of an input operand as a consumer sees it. */
 typedef struct {

@@ -237,3 +237,38 @@ def test_partials_channel_sums_and_add_counters():
     assert [int(v) for v in counters] == [i + 3 for i in range(70)]
     with pytest.raises(gsd.GsdError):
         gsd.add_counters([torch.zeros((), dtype=torch.int32, device="cuda")])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_skipped_step_leaves_no_trace_in_any_running_statistic(precision):
+    """One output channel of a MIDDLE layer goes NaN: the layers in front of it have finite batch statistics and have
+    already updated their running statistics when the step is found bad, and so may the finite channels beside it.  With a
+    nan_policy the step is bracketed by gsd_guard_snapshot / gsd_guard_restore: after the skipped step every running
+    statistic, parameter, moment and EMA value is bit-identical to before -- on every rank alike."""
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    dims = [32, 64, 128] if precision == "bf16" else DIMS
+    st = synth.make_state(3, 1, dims, 5, "conditioned")
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m, nan_policy="skip")
+    x, t = synth.make_batch(2, 21, 27, 6)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    step(xd, td)
+    w = dict(m.named_parameters())["down.0.maxpool_conv.1.double_conv.0.weight"]
+    saved = w.data[3].clone()
+    w.data[3] = float("nan")
+    before = snapshot(m, step)
+    nbt = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+    step(xd, td)
+    assert step.skipped_steps() == 1
+    after = snapshot(m, step)
+    for k in before:
+        assert torch.equal(before[k].view(torch.int32), after[k].view(torch.int32)), k     # bitwise, NaN row included
+    assert all(int(v) == nbt[k] + 1 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
+    w.data[3] = saved
+    step(xd, td)
+    assert step.skipped_steps() == 1 and bool(torch.isfinite(step.p_flat).all())
+    rm = m.state_dict()["inc.double_conv.1.running_mean"]
+    assert not torch.equal(rm, before["inc.double_conv.1.running_mean"])          # a healthy step moves them again
