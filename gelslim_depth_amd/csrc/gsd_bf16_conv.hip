@@ -38,7 +38,7 @@ struct GConvP {
   long long out_pitch;
   int Hob, Wob;   // output BUFFER extent
   int N, H, W;    // GEMM pixel grid
-  int K, M, Mpad, mblocks, nitems;
+  int K, M, Mpad, mblocks, nitems, xcd;
   int ntaps, stride;
   int ty[9], tx[9];
   int TH, TW, tiles_y, tiles_x, HC, HP;
@@ -81,14 +81,31 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, j = lane & 15;
 
-  // Persistent block: it walks work items (pixel tile, m-block) item = blockIdx.x, + gridDim.x, ...; gridDim.x is a
-  // multiple of mblocks, so the m-block (and with it every weight address and coefficient) is fixed per block.
-  const int mb = blockIdx.x % P.mblocks;
+  // Persistent block: it walks pixel tiles pt, pt + pt_step, ... < pt_end for ONE m-block (gridDim.x is a multiple of mblocks),
+  // so every weight address and coefficient is fixed per block.
+  // XCD-aware order (P.xcd): the hardware deals blocks round-robin over the 8 XCDs, each with its own L2.  XCD x takes the
+  // contiguous pixel-tile range [ntile x/8, ntile (x+1)/8) and its gridDim/8 blocks sweep it together -- the m-blocks of a pixel
+  // tile (same activation tile) and the neighbouring tiles (shared halo rows) then sit behind ONE L2 at about the same time,
+  // instead of the activation tile being fetched once per XCD that hosts one of its m-blocks.
+  const int ntile = P.nitems / P.mblocks;
+  int mb, pt, pt_step, pt_end;
+  if (P.xcd) {
+    const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nq = (int)(gridDim.x >> 3) / P.mblocks;
+    mb = l % P.mblocks;
+    pt = (int)((long long)ntile * x / 8) + l / P.mblocks;
+    pt_step = nq;
+    pt_end = (int)((long long)ntile * (x + 1) / 8);
+  } else {
+    mb = blockIdx.x % P.mblocks;
+    pt = blockIdx.x / P.mblocks;
+    pt_step = gridDim.x / P.mblocks;
+    pt_end = ntile;
+  }
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
   const int cbs = P.TW >> 4;  // 16-pixel column blocks per tile row
-  auto decode = [&](int item, int& n, int& h0, int& w0) {
-    const int pt = item / P.mblocks;
+  auto decode = [&](int pt_, int& n, int& h0, int& w0) {
+    const int pt = pt_;
     n = pt / tpi;
     const int trem = pt - n * tpi;
     const int tyi = trem / P.tiles_x;
@@ -220,10 +237,16 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   }
 
   const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * ((P.K >> 5) / NSUB);
-  int item = blockIdx.x;
-  if (item >= P.nitems) return;
+  if (pt >= pt_end) {   // (an XCD's range can be shorter than its blocks): this block's partial rows are zeros
+    if (P.partials != nullptr && lane < 64) {
+      float* row = P.partials + (size_t)((blockIdx.x / P.mblocks) * WN + wn) * (2 * P.Mpad);
+      const int mrow = m0 + wm * 64 + lane;
+      if (mrow < P.Mpad) row[mrow] = row[P.Mpad + mrow] = 0.f;
+    }
+    return;
+  }
   int n, h0, w0, git = 0;
-  decode(item, n, h0, w0);
+  decode(pt, n, h0, w0);
   prep(h0, w0);
   issue(0, 0, n, h0, w0);
   float s1[MT][4], s2[MT][4];   // this lane's running BatchNorm sums over all the block's items
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     for (int t = 0; t < NT; ++t) acc[m][t] = init;
   }
 
-  const int next = item + gridDim.x;
+  const int next = pt + pt_step;
   int nn = n, nh0 = h0, nw0 = w0;
   int it = 0;
   // One iteration = one barrier = NTAPI taps.  KH (MODE 0: the kernel row, = it % 3) is a compile-time constant so that the
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     int f_it = it + 1, f_n = n, f_h0 = h0, f_w0 = w0;
     if (it + 1 == iters) {   // the fill belongs to the next item: it flies during this item's last iteration and epilogue
       f_it = 0;              // (after the last item it repeats this item's first fill, which nobody reads: no branch)
-      if (next < P.nitems) decode(next, nn, nh0, nw0);
+      if (next < pt_end) decode(next, nn, nh0, nw0);
       prep(nh0, nw0);
       f_n = nn; f_h0 = nh0; f_w0 = nw0;
     }
@@ -429,8 +452,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   };
   if (interior) epilogue(std::integral_constant<bool, false>{});
   else epilogue(std::integral_constant<bool, true>{});
-  if (next >= P.nitems) break;
-  item = next;
+  if (next >= pt_end) break;
+  pt = next;
   n = nn;
   h0 = nh0;
   w0 = nw0;
@@ -518,6 +541,7 @@ int launch(GConvP& P, long items, size_t lds, hipStream_t st, const char* what) 
   GSD_REQUIRE(items > 0 && items < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: %ld work items out of range", what, items);
   P.nitems = (int)items;
   const long grid = launch_grid(items, P.mblocks);
+  P.xcd = (gsd_env_int("GSD_BF16_XCD", 1) != 0 && grid % 8 == 0 && (grid / 8) % P.mblocks == 0) ? 1 : 0;
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
   if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>)); e != hipSuccess) {
     gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
