@@ -36,7 +36,7 @@ struct GWgradP {
   int T, stride;
   int ty[9], tx[9];
   int TH, TW, tiles_y, tiles_x, HC, HP, KS, NPIX;
-  int stages_total, splits, mblocks, nblocks;
+  int stages_total, splits, mblocks, nblocks, xcd;
 };
 
 __device__ __forceinline__ u32x2 tr_read_b64(const unsigned char* p) {
@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
 
   const int per_split = P.mblocks * P.nblocks;
-  const int split = blockIdx.x / per_split;
-  const int rem = blockIdx.x - split * per_split;
+  // XCD-aware order: the (m-block, n-block) pairs of one split read the same dy / activation pixel range -- logical ids are
+  // contiguous per XCD (the hardware deals blocks round-robin over the 8 XCDs, each with its own L2), so one L2 serves them
+  const int lid = P.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
   const int mb = rem % P.mblocks, nb = rem / P.mblocks;
   const int m0 = mb * BM, n0 = nb * BNC;
   const int s_begin = (int)((long long)split * P.stages_total / P.splits);
@@ -339,6 +342,7 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
   P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HC = pl.HC; P.HP = pl.HP;
   P.NPIX = pl.NPIX; P.KS = pl.NPIX / 32;
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
+  P.xcd = gsd_env_int("GSD_BF16_XCD", 1) != 0 ? 1 : 0;
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   int rc;
   hipStream_t st = (hipStream_t)stream;
