@@ -55,6 +55,9 @@ struct GConvP {
   const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_invstd;
 };
 
+#ifndef GCONV_ABL   // diagnostic builds (profiles/build_diag_one.sh; results are then garbage): 1 the iteration barrier does not wait
+#define GCONV_ABL 0 // for the fills, 2 no fills after an item's first, 4 no epilogue stores, 8 no barrier (wait only)
+#endif
 template <int MODE, int WM, int WN>
 __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   constexpr int BM = WM * 64, NPX = WN * 128;
@@ -284,7 +287,13 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     constexpr int KH = decltype(khc)::value;
     constexpr int NS = (MODE == 1 || KH == 2) ? NWI + MAXX : NWI;     // DMA slots of this iteration
     constexpr int SPT = (NS + NTAPI - 1) / NTAPI;                       // per tap
+#if (GCONV_ABL) & 1
+    __syncthreads();
+#elif (GCONV_ABL) & 8
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
     gsd_dma_barrier();   // iteration git's DMA has landed (vmcnt(0) + barrier) and every wave has left the other buffers
+#endif
     int f_it = it + 1, f_n = n, f_h0 = h0, f_w0 = w0;
     if (it + 1 == iters) {   // the fill belongs to the next item: it flies during this item's last iteration and epilogue
       f_it = 0;              // (after the last item it repeats this item's first fill, which nobody reads: no branch)
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           }
         }
         if (kw > 0 && i < 2) b[NT - 2 + i] = *reinterpret_cast<const u32x4*>(Xc + boff[NT - 2 + i] + kw * BSTEP);   // the last pair
-        if (i < SPT && kw * SPT + i < NS) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
+        if (i < SPT && kw * SPT + i < NS && !(((GCONV_ABL) & 2) && git > 0)) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -409,8 +418,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
               }
             }
           }
-          if (ch_ok[0] && pix_ok) *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          if (ch_ok[1] && pix_ok) *reinterpret_cast<u32x4s*>(ot + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+          if (ch_ok[0] && pix_ok && !((GCONV_ABL) & 4)) *reinterpret_cast<u32x4s*>(ot) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          if (ch_ok[1] && pix_ok && !((GCONV_ABL) & 4)) *reinterpret_cast<u32x4s*>(ot + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -445,8 +454,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
             s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
           }
         }
-        if (ch_ok[0] && pix_ok) *reinterpret_cast<u32x4s*>(ot + ooff[0]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-        if (ch_ok[1] && pix_ok) *reinterpret_cast<u32x4s*>(ot + ooff[1]) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        if (ch_ok[0] && pix_ok && !((GCONV_ABL) & 4)) *reinterpret_cast<u32x4s*>(ot + ooff[0]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        if (ch_ok[1] && pix_ok && !((GCONV_ABL) & 4)) *reinterpret_cast<u32x4s*>(ot + ooff[1]) = u32x4{pk[4], pk[5], pk[6], pk[7]};
       }
     }
   };
