@@ -122,7 +122,12 @@ class UNetEngineBF16:
         self.hs, self.ws = hs, ws
         bf = dict(device=dev, dtype=torch.bfloat16)
         f32 = dict(device=dev, dtype=torch.float32)
-        self.col0 = torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
+        # first layer: straight from x (gsd_bf16_conv3x3_first / gsd_bf16_wgrad_first) where the shape is served, else through the
+        # im2col'd input (col0) and the dense-tap kernels; GSD_BF16_FIRST=0 forces the im2col path
+        import os
+        self.first_direct = bool(lib.gsd_bf16_conv3x3_first_supported(self.n_channels, self.dims[0])) and \
+            os.environ.get("GSD_BF16_FIRST", "1") != "0"
+        self.col0 = None if self.first_direct else torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
         # concat buffers (zeroed once: the F.pad border of the `up` slice is never written again)
         self.cat = [torch.zeros((n, hs[l], ws[l], self.dims[l] + self.dims[l + 1] // 2), **bf) for l in range(self.L)]
         self.gcat = [torch.empty_like(c) for c in self.cat] if train else [None] * self.L
@@ -141,11 +146,16 @@ class UNetEngineBF16:
             lh, lw = hs[u.level], ws[u.level]
             u.a = L.make_nhwc(u.a_t, u.a_off, u.cout)
             mp = lib.gsd_bf16_conv_mpad(u.cout)
-            max_part = max(max_part, lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout) * 2 * mp)
+            direct = u.first and self.first_direct
+            rows = lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout) if direct else lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
+            max_part = max(max_part, rows * 2 * mp)
             if train:
                 max_part = max(max_part, lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw) * 3 * u.cout)
-                kcols = _r32(9 * u.cin) if u.first else u.cin
-                max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(1 if u.first else 9, n, lh, lw, u.cout, kcols))
+                if direct:
+                    max_ws = max(max_ws, lib.gsd_bf16_wgrad_first_workspace(n, lh, lw, u.cout))
+                else:
+                    kcols = _r32(9 * u.cin) if u.first else u.cin
+                    max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(1 if u.first else 9, n, lh, lw, u.cout, kcols))
         for up in self.ups:
             li = up.level_in
             if up.wt_f is None or up.wt_f.device != dev:
@@ -211,7 +221,7 @@ class UNetEngineBF16:
     def _run_unit(self, u: _Unit, src: Tuple[torch.Tensor, int, int], P, train: bool, st: int) -> None:
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         u.src = src
-        din = L.make_nhwc(*src)
+        din = L.make_nhwc(*src) if src[0] is not None else None     # the first layer's direct kernels read x itself
         dy = L.make_nhwc(u.y)
         part = self.partials.data_ptr()
         if not train:
@@ -220,7 +230,11 @@ class UNetEngineBF16:
             check(lib.gsd_bn_eval_coeffs(P[u.gname].data_ptr(), P[u.bname].data_ptr(), P[u.rmname].data_ptr(),
                                          P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
                   "bn_eval_coeffs")
-            if u.first:
+            if u.first and self.first_direct:
+                check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                check(lib.gsd_bf16_conv3x3_first(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(u.a), u.cout, None,
+                                                 u.scale.data_ptr(), u.shift.data_ptr(), st), "conv3x3_first")
+            elif u.first:
                 check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
                 check(lib.gsd_bf16_conv1x1_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), src[2], u.cout, u.scale.data_ptr(),
                                                   u.shift.data_ptr(), st), "conv1x1_bnrelu")
@@ -231,7 +245,13 @@ class UNetEngineBF16:
                                                   u.shift.data_ptr(), st), "conv3x3_bnrelu")
                 done()
             return
-        if u.first:
+        if u.first and self.first_direct:
+            check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            done = self._log("bf16_conv_first", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
+            check(lib.gsd_bf16_conv3x3_first(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(dy), u.cout, part, None,
+                                             None, st), "conv3x3_first")
+            done()
+        elif u.first:
             check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
             z = L.int_array([0])
             done = self._log("bf16_conv_dense", 2.0 * u.cout * src[2] * n * lh * lw)
@@ -243,7 +263,8 @@ class UNetEngineBF16:
             done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
             check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
-        rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
+        rows = (lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout) if (u.first and self.first_direct)
+                else lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout))
         count = float(n * lh * lw)
         if self.sync_fn is None:     # a few hundred partial rows: column sums and finalize in ONE launch
             check(lib.gsd_bn_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout, u.sums.data_ptr(),
@@ -276,15 +297,17 @@ class UNetEngineBF16:
         self._saved_train = train
         self._nbt = []
         self.generation += 1       # every forward overwrites the saved activations
-        dcol = L.make_nhwc(self.col0)
-        region = self._region_begin()         # bench hook: the `inc` double-conv forward (im2col, 2 convs, BN statistics + apply)
-        check(lib.gsd_bf16_im2col3x3(x.data_ptr(), n, c, h, w, C.byref(dcol), st), "im2col3x3")
+        self._x = x
+        region = self._region_begin()         # bench hook: the `inc` double-conv forward (2 convs, BN statistics + apply)
+        if not self.first_direct:
+            dcol = L.make_nhwc(self.col0)
+            check(lib.gsd_bf16_im2col3x3(x.data_ptr(), n, c, h, w, C.byref(dcol), st), "im2col3x3")
         for lvl in range(self.L + 1):
             u0, u1 = self.enc[lvl]
             if lvl == 1:
                 self._region_end("inc_forward", region)
             if lvl == 0:
-                src = (self.col0, 0, self.col0.shape[3])
+                src = (None, 0, 0) if self.first_direct else (self.col0, 0, self.col0.shape[3])
             else:
                 prev = self.enc[lvl - 1][1]
                 dp = L.make_nhwc(self.pooled[lvl])
@@ -355,6 +378,14 @@ class UNetEngineBF16:
             check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), gsum.data_ptr(), u.cout, count, G[u.gname].data_ptr(),
                                           G[u.bname].data_ptr(), dw_ptr, u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_finalize")
         dz, dy = L.make_nhwc(u.g), L.make_nhwc(u.y)
+        if u.first and self.first_direct:
+            # no dX for the first layer, so dW is d_raw's only reader: it forms d_raw from (dz, y) itself -- no apply pass, no im2col
+            done = self._log("bf16_wgrad", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
+            check(lib.gsd_bf16_wgrad_first(self._x.data_ptr(), n, u.cin, lh, lw, C.byref(dz), C.byref(dy), u.scale.data_ptr(),
+                                           u.mean.data_ptr(), u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(),
+                                           G[u.wname].data_ptr(), self.wspace.data_ptr(), self.wspace.numel(), st), "wgrad_first")
+            done()
+            return
         check(lib.gsd_bf16_bn_bwd_apply(C.byref(dz), C.byref(dy), u.scale.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
                                         u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_apply")
         db = L.make_nhwc(*u.src)

@@ -77,6 +77,26 @@ int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out,
 int64_t gsd_bf16_weight_image_size(int mode, int Cout, int Cin);
 int gsd_bf16_weight_image(int mode, const float* w, int Cout, int Cin, void* out, void* stream);
 
+/* First layer WITHOUT the im2col tensor (unet.py:11 for `inc`, 9*C <= 32 and M in {32, 64}: gsd_bf16_conv3x3_first_supported):
+ *   out[n,h,w,m] = sum_{c,t} bf16(x[n,c,h+t/3-1,w+t%3-1]) * wt[m][c*9+t]       x (N,C,H,W) fp32, wt: weight image mode 2
+ * straight from x -- the layer is bound by the HBM write of its output (K = 27 is one MFMA k-step), and the im2col tensor
+ * costs more traffic than the input.  Bit-identical to gsd_bf16_im2col3x3 + gsd_bf16_conv_dense.  partials (train): BatchNorm
+ * partial sums, gsd_bf16_conv3x3_first_partial_rows rows of 2*gsd_bf16_conv_mpad(M) floats; ep_scale/ep_shift (eval): out =
+ * relu(acc*scale+shift) instead of the raw output.
+ * gsd_bf16_wgrad_first: dW (M,C,3,3) fp32 of the same layer from x and the gradient of its output.  With y != NULL the
+ * BatchNorm backward of the layer's output is applied on the fly -- d_raw = scale*(dz - c1 - (y-mean)*invstd*c2), rounded to
+ * bf16 exactly as gsd_bf16_bn_bwd_apply stores it: the first layer has no dX, so dW is d_raw's only reader and the apply
+ * pass (and the im2col tensor) disappear.  y == NULL: dz already is d_raw.  workspace: gsd_bf16_wgrad_first_workspace floats
+ * (one slab per block, summed in a fixed order: bitwise reproducible). */
+int gsd_bf16_conv3x3_first_supported(int C, int M);
+int gsd_bf16_conv3x3_first_partial_rows(int N, int H, int W, int M);
+int gsd_bf16_conv3x3_first(const float* x, int N, int C, int H, int W, const void* wt, const gsd_nhwc* out, int M,
+                           float* partials, const float* ep_scale, const float* ep_shift, void* stream);
+int64_t gsd_bf16_wgrad_first_workspace(int N, int H, int W, int M);
+int gsd_bf16_wgrad_first(const float* x, int N, int C, int H, int W, const gsd_nhwc* dz, const gsd_nhwc* y,
+                         const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
+                         float* dw, float* workspace, int64_t workspace_elems, void* stream);
+
 /* First layer: x (N,C,H,W) fp32 NCHW -> col (N,H,W,round_up(9C,32)) bf16 with col[..,c*9+t] = x[n,c,h+t/3-1,w+t%3-1]
  * (zero padded), so that conv3x3(x) is a 1x1 convolution of col (gsd_bf16_conv_dense). unet.py:11 for `inc`. */
 int gsd_bf16_im2col3x3(const float* x, int N, int C, int H, int W, const gsd_nhwc* col, void* stream);

@@ -405,3 +405,91 @@ def test_conv3x3_bnrelu_fused_eval_bf16():
     L.check(L.lib.gsd_bf16_conv3x3_bnrelu(C.byref(L.make_nhwc(xin)), img.data_ptr(), C.byref(L.make_nhwc(out)), k, m, sc_d.data_ptr(),
                                           sh_d.data_ptr(), L.stream_ptr()), "conv_bnrelu")
     assert_close_bf16(from_nhwc(out, 0, m), ref, "conv3x3+bn+relu")
+
+
+@pytest.mark.parametrize("n,c,h,w,m", [(2, 3, 21, 27, 32), (1, 3, 37, 130, 64), (2, 1, 9, 70, 32), (1, 2, 5, 64, 64), (3, 3, 4, 3, 64)])
+def test_first_layer_direct_kernels_bf16(n, c, h, w, m):
+    """gsd_bf16_conv3x3_first / gsd_bf16_wgrad_first (the first layer straight from x) against the im2col path they replace:
+    the forward multiplies the same bf16 operands in the same k order through the same MFMA -- bit-identical raw output, equal
+    BatchNorm sums, bit-identical fused eval output; dW (with the BatchNorm backward applied on the fly) against
+    gsd_bf16_bn_bwd_apply + im2col + gsd_bf16_wgrad and against fp64, twice the same bits."""
+    L = _lib()
+    g = torch.Generator().manual_seed(n * 100 + w + m)
+    assert L.lib.gsd_bf16_conv3x3_first_supported(c, m) == 1 and L.lib.gsd_bf16_conv3x3_first_supported(4, m) == 0
+    assert L.lib.gsd_bf16_conv3x3_first_supported(c, 48) == 0
+    x = torch.rand((n, c, h, w), generator=g)
+    wt = torch.randn((m, c, 3, 3), generator=g) * 0.3
+    x_d, w_d = x.cuda(), wt.cuda()
+    img = torch.zeros(L.lib.gsd_bf16_weight_image_size(2, m, c), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.gsd_bf16_weight_image(2, w_d.data_ptr(), m, c, img.data_ptr(), L.stream_ptr()), "wimg")
+    mp = L.lib.gsd_bf16_conv_mpad(m)
+    # ---- forward: the im2col path
+    col = torch.zeros((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
+    dcol = L.make_nhwc(col)
+    L.check(L.lib.gsd_bf16_im2col3x3(x_d.data_ptr(), n, c, h, w, C.byref(dcol), L.stream_ptr()), "im2col")
+    y0 = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    rows0 = L.lib.gsd_bf16_conv_partial_rows(n, h, w, m)
+    part0 = torch.zeros((rows0, 2 * mp), device="cuda")
+    z = L.int_array([0])
+    d0 = L.make_nhwc(y0)
+    L.check(L.lib.gsd_bf16_conv_dense(C.byref(dcol), img.data_ptr(), C.byref(d0), 32, m, 1, 1, z, z, h, w, 0, 0, 0, None,
+                                      part0.data_ptr(), None, L.stream_ptr()), "dense")
+    # ---- forward: straight from x
+    y1 = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rows1 = L.lib.gsd_bf16_conv3x3_first_partial_rows(n, h, w, m)
+    part1 = torch.full((rows1, 2 * mp), float("nan"), device="cuda")
+    d1 = L.make_nhwc(y1)
+    L.check(L.lib.gsd_bf16_conv3x3_first(x_d.data_ptr(), n, c, h, w, img.data_ptr(), C.byref(d1), m, part1.data_ptr(), None, None,
+                                         L.stream_ptr()), "first")
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    ref = F.conv2d(bf16r(x).double(), bf16r(wt).double(), padding=1)
+    assert_close_bf16(from_nhwc(y1, 0, m), ref, "first layer")
+    s0, s1 = part0.double().sum(0), part1.double().sum(0)
+    yv = y1.double()
+    np.testing.assert_allclose(s1[:m].cpu().numpy(), yv.sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s1[mp:mp + m].cpu().numpy(), (yv * yv).sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s1[:m].cpu().numpy(), s0[:m].cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # eval mode: BatchNorm (running statistics) + ReLU in the epilogue
+    sc, sh = (torch.rand(m, generator=g) + 0.5).cuda(), (torch.randn(m, generator=g) * 0.2).cuda()
+    a0 = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    a1 = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+    da0, da1 = L.make_nhwc(a0), L.make_nhwc(a1)
+    L.check(L.lib.gsd_bf16_conv1x1_bnrelu(C.byref(dcol), img.data_ptr(), C.byref(da0), 32, m, sc.data_ptr(), sh.data_ptr(),
+                                          L.stream_ptr()), "1x1 bnrelu")
+    L.check(L.lib.gsd_bf16_conv3x3_first(x_d.data_ptr(), n, c, h, w, img.data_ptr(), C.byref(da1), m, None, sc.data_ptr(),
+                                         sh.data_ptr(), L.stream_ptr()), "first bnrelu")
+    assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
+    # ---- dW with the BatchNorm backward on the fly
+    dz = bf16r(torch.randn((n, m, h, w), generator=g))
+    vec = [(torch.rand(m, generator=g) + 0.5), torch.randn(m, generator=g) * 0.3, (torch.rand(m, generator=g) + 0.5),
+           torch.randn(m, generator=g) * 0.1, torch.randn(m, generator=g) * 0.1]        # scale mean invstd c1 c2
+    vd = [v.cuda() for v in vec]
+    dz_d = to_nhwc(dz)
+    need = L.lib.gsd_bf16_wgrad_first_workspace(n, h, w, m)
+    ws = torch.zeros(need, device="cuda")
+    outs = []
+    ddz = L.make_nhwc(dz_d)
+    for _ in range(2):
+        dw = torch.full((m, c, 3, 3), float("nan"), device="cuda")
+        L.check(L.lib.gsd_bf16_wgrad_first(x_d.data_ptr(), n, c, h, w, C.byref(ddz), C.byref(d1), *[v.data_ptr() for v in vd],
+                                           dw.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "wgrad_first")
+        outs.append(dw.cpu())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    # the path it replaces: apply pass (in place on a copy), then dW of the im2col'd input
+    dr = dz_d.clone()
+    ddr = L.make_nhwc(dr)
+    L.check(L.lib.gsd_bf16_bn_bwd_apply(C.byref(ddr), C.byref(d1), vd[0].data_ptr(), vd[1].data_ptr(), vd[2].data_ptr(),
+                                        vd[3].data_ptr(), vd[4].data_ptr(), L.stream_ptr()), "apply")
+    old = _wgrad(L, dr, 0, m, col, 0, 32, 1, 1, [0], [0], 9 * c).reshape(m, c, 3, 3)
+    scale_ref = float(old.abs().max())
+    assert float((outs[0] - old).abs().max()) <= 2e-5 * scale_ref
+    wz = torch.zeros((m, c, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(bf16r(x).double(), wz, padding=1).backward(from_nhwc(dr, 0, m).double())
+    assert float((outs[0].double() - wz.grad).abs().max()) <= 2e-5 * float(wz.grad.abs().max())
+    # unfused form (y == NULL: the gradient already is d_raw) and the workspace check
+    dw2 = torch.full((m, c, 3, 3), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_wgrad_first(x_d.data_ptr(), n, c, h, w, C.byref(ddr), None, None, None, None, None, None,
+                                       dw2.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "wgrad_first plain")
+    assert float((dw2.cpu() - old).abs().max()) <= 2e-5 * scale_ref
+    assert L.lib.gsd_bf16_wgrad_first(x_d.data_ptr(), n, c, h, w, C.byref(ddz), C.byref(d1), *[v.data_ptr() for v in vd],
+                                      dw.data_ptr(), ws.data_ptr(), need - 1, L.stream_ptr()) == -4

@@ -78,6 +78,9 @@ def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
 
     def unit_input(u):
         tsr, off, c = u.src
+        if tsr is None:       # the first layer reads x itself (gsd_bf16_conv3x3_first): its operand is im2col(bf16(x)), k = c*9 + t
+            n_, c_, h_, w_ = xt.shape
+            return F.unfold(_q(xt), 3, padding=1).reshape(n_, 9 * c_, h_, w_)
         return _nchw(tsr, off, c)
 
     for u in eng.units:
@@ -98,6 +101,11 @@ def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
         _ulp_close(_nchw(u.a_t, u.a_off, u.cout), a_ref, f"{u.gname} apply")
         # backward: u.g holds dy (gradient w.r.t. the raw conv output) after the step
         dy = _nchw(u.g)
+        if u.first and u.src[0] is None:
+            # gsd_bf16_wgrad_first applies the BatchNorm backward itself: u.g still holds dz, and d_raw -- rounded to bf16 as the
+            # apply pass would have stored it -- exists only inside that kernel
+            b_ = lambda v: v.cpu()[None, :, None, None]      # noqa: E731
+            dy = _q(b_(u.scale) * (dy - b_(u.c1) - (y - b_(u.mean)) * b_(u.invstd) * b_(u.c2)))
         if u.first:
             dw_ref = torch.einsum("nmhw,nkhw->mk", dy.double(), a_in.double())[:, :9 * u.cin].reshape(got[u.wname].shape)
         else:
