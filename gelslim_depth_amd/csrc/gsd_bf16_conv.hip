@@ -92,17 +92,20 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   // instead of the activation tile being fetched once per XCD that hosts one of its m-blocks.
   const int ntile = P.nitems / P.mblocks;
   int mb, pt, pt_step, pt_end;
+  int prow;   // this block's row group of the BatchNorm partials: unique per (pixel-tile lane of the grid), shared by its m-blocks
   if (P.xcd) {
     const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nq = (int)(gridDim.x >> 3) / P.mblocks;
     mb = l % P.mblocks;
     pt = (int)((long long)ntile * x / 8) + l / P.mblocks;
     pt_step = nq;
     pt_end = (int)((long long)ntile * (x + 1) / 8);
+    prow = x * nq + l / P.mblocks;
   } else {
     mb = blockIdx.x % P.mblocks;
     pt = blockIdx.x / P.mblocks;
     pt_step = gridDim.x / P.mblocks;
     pt_end = ntile;
+    prow = blockIdx.x / P.mblocks;
   }
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int iters = MODE == 0 ? (P.K >> 5) * 3 : P.ntaps * ((P.K >> 5) / NSUB);
   if (pt >= pt_end) {   // (an XCD's range can be shorter than its blocks): this block's partial rows are zeros
     if (P.partials != nullptr && lane < 64) {
-      float* row = P.partials + (size_t)((blockIdx.x / P.mblocks) * WN + wn) * (2 * P.Mpad);
+      float* row = P.partials + (size_t)(prow * WN + wn) * (2 * P.Mpad);
       const int mrow = m0 + wm * 64 + lane;
       if (mrow < P.Mpad) row[mrow] = row[P.Mpad + mrow] = 0.f;
     }
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's cells are written (the row below is read by the same wave)
   }
   if (P.partials != nullptr && lane < 64) {
-    float* row = P.partials + (size_t)((blockIdx.x / P.mblocks) * WN + wn) * (2 * P.Mpad);
+    float* row = P.partials + (size_t)(prow * WN + wn) * (2 * P.Mpad);
     const int mrow = m0 + wm * 64 + lane;
     if (mrow < P.Mpad) {
       row[mrow] = sSt[wave * 128 + lane];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence run (GPU box, repo root): rocprofv3 kernel stats of the bench command + the three PMC passes behind
 # profiles/traffic.json.  Results land in gpurun_out/ (copy the summaries into profiles/ afterwards).
-tag=${1:-r03_m}
+tag=${1:-r03_z}
 bash profiles/run_prof.sh ${tag}_fp32 --no-extra --steps 5 --warmup 2 > gpurun_out/${tag}_fp32_prof.log 2>&1
 echo "fp32 stats done"; head -8 gpurun_out/${tag}_fp32_stats.txt
 bash profiles/run_prof.sh ${tag}_bf16 --no-extra --dtype bf16 --steps 5 --warmup 2 > gpurun_out/${tag}_bf16_prof.log 2>&1

@@ -57,6 +57,9 @@ def assert_close_bf16(got, ref, what):
     (1, 33, 70, 32, 64, 96, 32, 64, 0),         # 64x512 tile, input is a channel slice
     (2, 17, 21, 96, 48, 96, 0, 80, 16),         # M not a multiple of 64, output is a channel slice, 3 chunks
     (1, 40, 53, 128, 256, 128, 0, 256, 0),      # two m-blocks
+    (2, 64, 64, 32, 256, 32, 0, 256, 0),        # 64 work items, two m-blocks: the XCD-aware item order is on (grid % 8 == 0)
+    (8, 64, 128, 32, 256, 32, 0, 256, 0),       # 512 items on 256 persistent blocks: two items per block in XCD order
+    (2, 32, 64, 64, 512, 64, 0, 512, 0),        # four m-blocks in XCD order
 ])
 def test_conv3x3_bf16(n, h, w, k, m, in_tot, in_off, out_tot, out_off):
     L = _lib()
@@ -85,6 +88,46 @@ def test_conv3x3_bf16(n, h, w, k, m, in_tot, in_off, out_tot, out_off):
     s = sums[:2 * m].cpu()
     assert torch.allclose(s[:m], got.double().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[m:], (got.double() ** 2).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+def test_conv3x3_bf16_item_order_is_only_an_order(monkeypatch):
+    """GSD_BF16_XCD (XCD-aware order of the persistent blocks' work items) changes which block computes which pixel tile,
+    nothing else: outputs bit-identical, BatchNorm sums equal to rounding, for the plain and the fused-BatchNorm-backward launch."""
+    L = _lib()
+    g = torch.Generator().manual_seed(77)
+    n, h, w, k, m = 4, 64, 128, 64, 256
+    x = to_nhwc(bf16r(torch.randn((n, k, h, w), generator=g)))
+    img = weight_image(bf16r(torch.randn((9, m, k), generator=g) / (3.0 * k ** 0.5)))
+    ybw = to_nhwc(bf16r(torch.randn((n, m, h, w), generator=g)))
+    vec = [(torch.rand(m, generator=g) + 0.5).cuda(), (torch.randn(m, generator=g) * 0.3).cuda(),
+           (torch.randn(m, generator=g) * 0.3).cuda(), (torch.rand(m, generator=g) + 0.5).cuda()]
+    rows, mp = L.lib.gsd_bf16_conv_partial_rows(n, h, w, m), L.lib.gsd_bf16_conv_mpad(m)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GSD_BF16_XCD", flag)
+        outs = []
+        for fused in (False, True):
+            out = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+            part = torch.full((rows, 2 * mp), float("nan"), dtype=torch.float32, device="cuda")
+            din, dout = L.make_nhwc(x), L.make_nhwc(out)
+            bw = None
+            if fused:
+                bw = L.gsd_bf16_bnbwd()
+                dyb = L.make_nhwc(ybw)
+                bw.y = C.pointer(dyb)
+                bw.scale, bw.shift, bw.mean, bw.invstd = [v.data_ptr() for v in vec]
+                bw = C.byref(bw)
+            L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(dout), k, m, part.data_ptr(), bw, L.stream_ptr()), "conv")
+            sums = torch.zeros((65 * 2 * m,), dtype=torch.float64, device="cuda")
+            L.check(L.lib.gsd_bn_reduce_partials(part.data_ptr(), rows, mp, m, sums.data_ptr(), L.stream_ptr()), "reduce")
+            outs += [out, sums[:2 * m].clone()]
+        res[flag] = outs
+    for i in (0, 2):
+        assert bool(torch.isfinite(res["1"][i].float()).all())
+        assert torch.equal(res["0"][i].view(torch.int16), res["1"][i].view(torch.int16))
+    for i in (1, 3):
+        assert bool(torch.isfinite(res["1"][i]).all())
+        np.testing.assert_allclose(res["1"][i].cpu().numpy(), res["0"][i].cpu().numpy(), rtol=1e-5, atol=1e-2)
 
 
 def test_dense_1x1_and_convT_bf16():

@@ -422,7 +422,7 @@ def test_bad_arguments_are_refused(gsd):
     assert gsd.lib.gsd_conv3x3(src, 1, None, 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
     assert gsd.lib.gsd_conv3x3(src, 3, wt.data_ptr(), 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
     with pytest.raises(gsd.GsdError):
-        gsd.check(gsd.lib.gsd_weight_layout(7, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
+        gsd.check(gsd.lib.gsd_weight_layout(8, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 6, 9, 9, 11), (1, 64, 130, 21, 29)])
