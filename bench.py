@@ -221,7 +221,7 @@ class Leg:
             extra = {"traffic": traffic, "traffic_source": traffic_src, "traffic_vs_algorithmic": round(traffic / by, 3),
                      "traffic_TBps": round(traffic / (avg * 1e-3) / 1e12, 3)}
         return {**extra, "bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
-                + ("im2col + 2 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
+                + ("first conv straight from x + 64->64 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
                    else "direct conv + Winograd conv + BN statistics launches"),
                 "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),
                 "algorithmic_bytes": int(by), "avg_ms": round(avg, 4), "launches_timed": len(ms),
