@@ -301,11 +301,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
-    if local_rank >= torch.cuda.device_count():
+    # Rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (timings are then meaningless): GSD_BENCH_BACKEND=gloo
+    # GSD_BENCH_SHARE_GPU=1 lets the ranks share device 0 over gloo; the measured configuration is always one rank per GPU on RCCL
+    backend = os.environ.get("GSD_BENCH_BACKEND", "nccl")
+    share = bool(os.environ.get("GSD_BENCH_SHARE_GPU")) and backend != "nccl"
+    if local_rank >= torch.cuda.device_count() and not share:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
                          "one rank per GPU is required (RCCL refuses duplicate devices)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     n_ranks_seen = 1
     if world > 1 or os.environ.get("GSD_FORCE_SYNC"):
@@ -319,7 +324,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
         pg = dist.group.WORLD
         n_ranks_seen = dist.get_world_size()
 
@@ -338,11 +346,11 @@ def main():
         """(max elapsed over ranks, [per-rank ms per step], rank-max of the collective times) -- rank 0 reports them."""
         if pg is None:
             return local_elapsed, [round(local_elapsed / args.steps * 1e3, 3)], comm
-        row = torch.tensor([local_elapsed, comm["allreduce_ms_per_step"] if comm else 0.0,
-                            comm["exposed_ms_per_step"] if comm else 0.0], device=dev, dtype=torch.float64)
-        rows = [torch.zeros_like(row) for _ in range(n_ranks_seen)]
-        torch.distributed.all_gather(rows, row)
-        tab = torch.stack(rows).cpu()
+        tab = torch.zeros((n_ranks_seen, 3), device=dev, dtype=torch.float64)     # a gather as a sum: every rank fills its own row
+        tab[rank] = torch.tensor([local_elapsed, comm["allreduce_ms_per_step"] if comm else 0.0,
+                                  comm["exposed_ms_per_step"] if comm else 0.0], dtype=torch.float64)
+        torch.distributed.all_reduce(tab)
+        tab = tab.cpu()
         if comm:
             comm = dict(comm, allreduce_ms_per_step=round(float(tab[:, 1].max()), 4),
                         exposed_ms_per_step=round(float(tab[:, 2].max()), 4),
@@ -415,7 +423,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": workload_name(args.dtype, args.workload, B),
+            "config": {"workload": workload_name(args.dtype, args.workload, B) +
+                                   ("" if backend == "nccl" else f" [REHEARSAL over {backend}, ranks sharing a GPU: {share} -- not a measurement]"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6),
                        "conv3x3_form": ("bf16 MFMA implicit GEMM" if args.dtype == "bf16" else
