@@ -58,6 +58,25 @@ struct GConvP {
 #ifndef GCONV_ABL   // diagnostic builds (profiles/build_diag_one.sh; results are then garbage): 1 the iteration barrier does not wait
 #define GCONV_ABL 0 // for the fills, 2 no fills after an item's first, 4 no epilogue stores, 8 no barrier (wait only)
 #endif
+#ifndef GCONV_CONTIG   // 0 (default): instruction k of wave w fills piece 4k + w.  1 (diagnostic builds): a wave's DMA instructions fill
+#define GCONV_CONTIG 0 // ONE contiguous LDS range, up to four sharing an LDS base (M0 set once, the 1-KiB steps in the instruction's
+#endif                 // immediate offset) -- measured 17 % SLOWER over the layer set (5.93 vs 5.08 ms): the interleaved order stays
+// LDS-DMA of one 1-KiB piece into piece index `pc` of the buffer at `buf`: with GCONV_CONTIG the LDS base is that of the
+// piece's group of four and the remainder is the instruction's immediate, which moves the global address alike (undone here)
+__device__ __forceinline__ void gconv_dma_piece(const void* g, unsigned char* buf, int pc) {
+#if GCONV_CONTIG
+  unsigned char* base = buf + (pc & ~3) * 1024;
+  const char* gp = (const char*)g;
+  switch (pc & 3) {
+    case 0: __builtin_amdgcn_global_load_lds((const void*)gp, base, 16, 0, 0); break;
+    case 1: __builtin_amdgcn_global_load_lds((const void*)(gp - 1024), base, 16, 1024, 0); break;
+    case 2: __builtin_amdgcn_global_load_lds((const void*)(gp - 2048), base, 16, 2048, 0); break;
+    default: __builtin_amdgcn_global_load_lds((const void*)(gp - 3072), base, 16, 3072, 0); break;
+  }
+#else
+  __builtin_amdgcn_global_load_lds(g, buf + pc * 1024, 16, 0, 0);
+#endif
+}
 template <int MODE, int WM, int WN>
 __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   constexpr int BM = WM * 64, NPX = WN * 128;
@@ -83,6 +102,8 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, j = lane & 15;
+  // piece (1 KiB) index inside a buffer that instruction k of this wave fills (NI = instructions per wave for that buffer)
+  auto piece = [&](int k, int ni) { return GCONV_CONTIG ? wave * ni + k : k * 4 + wave; };
 
   // Persistent block: it walks pixel tiles pt, pt + pt_step, ... < pt_end for ONE m-block (gridDim.x is a multiple of mblocks),
   // so every weight address and coefficient is fixed per block.
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   int woff[NWI];
 #pragma unroll
   for (int k = 0; k < NWI; ++k) {
-    const int idx = (k * 4 + wave) * 64 + lane;
+    const int idx = piece(k, NWI) * 64 + lane;
     const int tapk = idx / (BM * 4);
     const int row = (idx >> 2) % BM;
     const int gg = (idx & 3) ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3);   // {0,2,3,1}
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   int xpk[MAXX];
 #pragma unroll
   for (int k = 0; k < MAXX; ++k) {
-    const int o = ((MODE == 0 ? k : k % XPP) * 4 + wave) * 1024 + lane * 16;
+    const int o = piece(MODE == 0 ? k : k % XPP, MODE == 0 ? MAXX : XPP) * 1024 + lane * 16;
     const int px = o / 96, slot = (o - px * 96) >> 4;
     const int rowlen = MODE == 0 ? P.HC : P.TW;
     int v = -2;
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     }
     if (slot < NWI) {
       const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
-      __builtin_amdgcn_global_load_lds((const void*)(wsrc + woff[slot]), Wl + (git & 1) * WBUF + (slot * 4 + wave) * 1024, 16, 0, 0);
+      gconv_dma_piece((const void*)(wsrc + woff[slot]), Wl + (git & 1) * WBUF, piece(slot, NWI));
       return;
     }
     const int k = slot - NWI;
@@ -209,14 +230,14 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
     const void* sp = (const void*)gsd_zero16;
     if (MODE == 0) {
       if (xoff[k] >= 0) sp = (const void*)(src + xoff[k]);
-      __builtin_amdgcn_global_load_lds(sp, Xl + ((git / 3) & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);
+      gconv_dma_piece(sp, Xl + ((git / 3) & 1) * XBUF, piece(k, MAXX));
     } else {
       if (xoff[k] >= 0) {
         const int hi = P.stride * (h0 + (xoff[k] >> 16)) + P.ty[tap0], wi = P.stride * (w0 + ((xoff[k] >> 4) & 0xfff)) + P.tx[tap0];
         if ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win)
           sp = (const void*)(src + (long long)(hi * P.Win + wi) * P.in_pitch + (k / XPP) * 32 + (xoff[k] & 15) * 8);
       }
-      __builtin_amdgcn_global_load_lds(sp, Xl + (git & 1) * XBUF + (k * 4 + wave) * 1024, 16, 0, 0);   // plane k / XPP
+      gconv_dma_piece(sp, Xl + (git & 1) * XBUF + (k / XPP) * (XPP * 4096), piece(k % XPP, XPP));   // plane k / XPP
     }
   };
   // slots of one iteration: the weights always; the activations with every iteration (MODE 1) or with a chunk's first
