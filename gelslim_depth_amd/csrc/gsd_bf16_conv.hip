@@ -533,7 +533,9 @@ Plan make_plan(int H, int W, int M) {
   p.BM = p.wide ? 64 : 128;
   p.NPX = p.wide ? 512 : 256;
   long best = -1;
+  const int force_tw = gsd_env_int("GSD_BF16_TW", 0);   // tuning: force the tile width (16, 32 or 64)
   for (int tw = 16; tw <= 64; tw *= 2) {
+    if (force_tw && tw != force_tw) continue;
     const int th = p.NPX / tw;
     const long cost = (long)ceil_div(H, th) * ceil_div(W, tw);   // tiles; ties -> wider rows (longer DMA row segments)
     if (best < 0 || cost <= best) {
