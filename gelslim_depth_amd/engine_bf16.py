@@ -21,6 +21,7 @@ flow (/root/reference/gelslim_depth/models/unet.py:79-88), different data layout
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -124,7 +125,6 @@ class UNetEngineBF16:
         f32 = dict(device=dev, dtype=torch.float32)
         # first layer: straight from x (gsd_bf16_conv3x3_first / gsd_bf16_wgrad_first) where the shape is served, else through the
         # im2col'd input (col0) and the dense-tap kernels; GSD_BF16_FIRST=0 forces the im2col path
-        import os
         self.first_direct = bool(lib.gsd_bf16_conv3x3_first_supported(self.n_channels, self.dims[0])) and \
             os.environ.get("GSD_BF16_FIRST", "1") != "0"
         self.col0 = None if self.first_direct else torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
@@ -166,6 +166,13 @@ class UNetEngineBF16:
                 max_ws = max(max_ws, lib.gsd_bf16_channel_sums_workspace(n, 2 * hs[li], 2 * ws[li], up.cout))
         self.partials = torch.empty((max_part,), **f32)
         self.wspace = torch.empty((max(max_ws, 64),), **f32) if train else None
+        # weight gradients on a SIDE stream: dW(u) only needs d_raw(u) and the unit's input, nothing downstream of it waits for
+        # it, and it is MFMA-bound while the backward chain it leaves behind alternates with HBM-bound BatchNorm passes (20 % of
+        # the bf16 step): the two overlap where neither fills the chip.  Own split-K workspace; joined before a block's
+        # gradients are handed to the all-reduce and at the end of backward.  GSD_BF16_SIDE_DW=0: everything on one stream.
+        self.side_dw = train and os.environ.get("GSD_BF16_SIDE_DW", "1") != "0"
+        self.side = torch.cuda.Stream(device=dev) if self.side_dw else None
+        self.wspace_side = torch.empty((max(max_ws, 64),), **f32) if self.side_dw else None
 
     def _alloc_unit(self, u: _Unit, n: int, dev: torch.device, train: bool) -> None:
         lh, lw = self.hs[u.level], self.ws[u.level]
@@ -380,25 +387,44 @@ class UNetEngineBF16:
         dz, dy = L.make_nhwc(u.g), L.make_nhwc(u.y)
         if u.first and self.first_direct:
             # no dX for the first layer, so dW is d_raw's only reader: it forms d_raw from (dz, y) itself -- no apply pass, no im2col
-            done = self._log("bf16_wgrad", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
-            check(lib.gsd_bf16_wgrad_first(self._x.data_ptr(), n, u.cin, lh, lw, C.byref(dz), C.byref(dy), u.scale.data_ptr(),
-                                           u.mean.data_ptr(), u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(),
-                                           G[u.wname].data_ptr(), self.wspace.data_ptr(), self.wspace.numel(), st), "wgrad_first")
-            done()
+            def launch(sst, ws):
+                done = self._log("bf16_wgrad", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
+                check(lib.gsd_bf16_wgrad_first(self._x.data_ptr(), n, u.cin, lh, lw, C.byref(dz), C.byref(dy), u.scale.data_ptr(),
+                                               u.mean.data_ptr(), u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(),
+                                               G[u.wname].data_ptr(), ws.data_ptr(), ws.numel(), sst), "wgrad_first")
+                done()
+            self._on_side(launch)
             return
         check(lib.gsd_bf16_bn_bwd_apply(C.byref(dz), C.byref(dy), u.scale.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
                                         u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_apply")
         db = L.make_nhwc(*u.src)
-        if u.first:
-            z = L.int_array([0])
-            done = self._log("bf16_wgrad", 2.0 * u.cout * u.src[2] * n * lh * lw)
-            check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 1, 1, z, z, G[u.wname].data_ptr(), 9 * u.cin, self.wspace.data_ptr(),
-                                     self.wspace.numel(), st), "wgrad(first)")
-        else:
-            done = self._log("bf16_wgrad", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
-            check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 9, 1, L.int_array(T3Y), L.int_array(T3X), G[u.wname].data_ptr(),
-                                     u.cin, self.wspace.data_ptr(), self.wspace.numel(), st), "wgrad")
-        done()
+
+        def launch(sst, ws):
+            if u.first:
+                z = L.int_array([0])
+                done = self._log("bf16_wgrad", 2.0 * u.cout * u.src[2] * n * lh * lw)
+                check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 1, 1, z, z, G[u.wname].data_ptr(), 9 * u.cin, ws.data_ptr(),
+                                         ws.numel(), sst), "wgrad(first)")
+            else:
+                done = self._log("bf16_wgrad", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+                check(lib.gsd_bf16_wgrad(C.byref(dz), C.byref(db), 9, 1, L.int_array(T3Y), L.int_array(T3X), G[u.wname].data_ptr(),
+                                         u.cin, ws.data_ptr(), ws.numel(), sst), "wgrad")
+            done()
+        self._on_side(launch)
+
+    def _on_side(self, launch) -> None:
+        """Run launch(stream pointer, workspace tensor) -- one weight-gradient launch -- behind everything issued so far, on the
+        side stream when there is one."""
+        if not self.side_dw:
+            launch(L.stream_ptr(), self.wspace)
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            launch(L.stream_ptr(), self.wspace_side)
+
+    def _join_side(self) -> None:
+        if self.side_dw:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _bnbwd(self, tgt: _Unit):
         """gsd_bf16_bnbwd for fusing pass 1 of tgt's BatchNorm+ReLU backward into the dX launch that produces tgt.g."""
@@ -450,10 +476,12 @@ class UNetEngineBF16:
             oy, ox = self._pad_off(lvl)
             gup = L.make_nhwc(self.gcat[lvl], self.dims[lvl], up.cout)
             ty, tx = L.int_array([oy, oy, oy + 1, oy + 1]), L.int_array([ox, ox + 1, ox, ox + 1])
-            done = self._log("bf16_wgrad", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
-            check(lib.gsd_bf16_wgrad(C.byref(prev.a), C.byref(gup), 4, 2, ty, tx, G[up.wname].data_ptr(), up.cout, self.wspace.data_ptr(),
-                                     self.wspace.numel(), st), "convT wgrad")
-            done()
+            def launch(sst, ws, up=up, prev=prev, gup=gup, ty=ty, tx=tx, hi=hi, wi=wi):
+                done = self._log("bf16_wgrad", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
+                check(lib.gsd_bf16_wgrad(C.byref(prev.a), C.byref(gup), 4, 2, ty, tx, G[up.wname].data_ptr(), up.cout, ws.data_ptr(),
+                                         ws.numel(), sst), "convT wgrad")
+                done()
+            self._on_side(launch)
             check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), self.wspace.data_ptr(),
                                             self.wspace.numel(), st), "convT bias grad")
             check(lib.gsd_bf16_weight_image(4, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_image")
@@ -465,6 +493,7 @@ class UNetEngineBF16:
             done()
             prev_fused = prev
             if self.block_done_cb is not None:
+                self._join_side()
                 self.block_done_cb(f"dec{j}")
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
@@ -476,6 +505,8 @@ class UNetEngineBF16:
             self._dgrad(u1, P, u0.g, st, fuse=u0)
             self._tail(u0, G, st, fused=True)
             if self.block_done_cb is not None:
+                self._join_side()
                 self.block_done_cb(f"enc{lvl}")
             if lvl > 0:
                 self._dgrad(u0, P, self.dpooled[lvl], st)
+        self._join_side()
