@@ -125,6 +125,7 @@ class UNetEngineBF16:
         f32 = dict(device=dev, dtype=torch.float32)
         # first layer: straight from x (gsd_bf16_conv3x3_first / gsd_bf16_wgrad_first) where the shape is served, else through the
         # im2col'd input (col0) and the dense-tap kernels; GSD_BF16_FIRST=0 forces the im2col path
+        self._wready, self._wevents = {}, {}
         self.first_direct = bool(lib.gsd_bf16_conv3x3_first_supported(self.n_channels, self.dims[0])) and \
             os.environ.get("GSD_BF16_FIRST", "1") != "0"
         self.col0 = None if self.first_direct else torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
@@ -238,35 +239,35 @@ class UNetEngineBF16:
                                          P[u.rvname].data_ptr(), BN_EPS, u.cout, u.scale.data_ptr(), u.shift.data_ptr(), st),
                   "bn_eval_coeffs")
             if u.first and self.first_direct:
-                check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                self._wimage(2, P[u.wname], u.cout, u.cin, u.wt_f, st)
                 check(lib.gsd_bf16_conv3x3_first(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(u.a), u.cout, None,
                                                  u.scale.data_ptr(), u.shift.data_ptr(), st), "conv3x3_first")
             elif u.first:
-                check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                self._wimage(2, P[u.wname], u.cout, u.cin, u.wt_f, st)
                 check(lib.gsd_bf16_conv1x1_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), src[2], u.cout, u.scale.data_ptr(),
                                                   u.shift.data_ptr(), st), "conv1x1_bnrelu")
             else:
-                check(lib.gsd_bf16_weight_image(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+                self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
                 done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
                 check(lib.gsd_bf16_conv3x3_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), u.cin, u.cout, u.scale.data_ptr(),
                                                   u.shift.data_ptr(), st), "conv3x3_bnrelu")
                 done()
             return
         if u.first and self.first_direct:
-            check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            self._wimage(2, P[u.wname], u.cout, u.cin, u.wt_f, st)
             done = self._log("bf16_conv_first", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
             check(lib.gsd_bf16_conv3x3_first(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(dy), u.cout, part, None,
                                              None, st), "conv3x3_first")
             done()
         elif u.first:
-            check(lib.gsd_bf16_weight_image(2, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            self._wimage(2, P[u.wname], u.cout, u.cin, u.wt_f, st)
             z = L.int_array([0])
             done = self._log("bf16_conv_dense", 2.0 * u.cout * src[2] * n * lh * lw)
             check(lib.gsd_bf16_conv_dense(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), src[2], u.cout, 1, 1, z, z, lh, lw, 0, 0, 0,
                                           None, part, None, st), "conv_dense(first)")
             done()
         else:
-            check(lib.gsd_bf16_weight_image(0, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_image")
+            self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
             done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
             check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
@@ -305,6 +306,9 @@ class UNetEngineBF16:
         self._nbt = []
         self.generation += 1       # every forward overwrites the saved activations
         self._x = x
+        self._wready = {}
+        if train and os.environ.get("GSD_BF16_SIDE_WIMG", "0") != "0":     # measured: 30.7 vs 30.4 ms per step -- off by default
+            self._prepare_weight_images(P)
         region = self._region_begin()         # bench hook: the `inc` double-conv forward (2 convs, BN statistics + apply)
         if not self.first_direct:
             dcol = L.make_nhwc(self.col0)
@@ -329,7 +333,7 @@ class UNetEngineBF16:
         for j in range(self.L):
             up = self.ups[j]
             lvl = self.L - 1 - j
-            check(lib.gsd_bf16_weight_image(3, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_image")
+            self._wimage(3, P[up.wname], up.cout, up.cin, up.wt_f, st)
             oy, ox = self._pad_off(lvl)
             dslice = L.make_nhwc(self.cat[lvl], self.dims[lvl], up.cout)
             done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * self.hs[lvl + 1] * self.ws[lvl + 1])
@@ -412,6 +416,50 @@ class UNetEngineBF16:
             done()
         self._on_side(launch)
 
+    def _prepare_weight_images(self, P) -> None:
+        """Train mode: every bf16 weight image of the step (43 small launches: forward and dX images of the 18 conv units, the
+        two images of each transposed conv) is produced on the SIDE stream at the start of the forward, in the order the main
+        stream will want them, each followed by an event; `_wimage` then only waits for the event.  They depend on nothing but
+        the parameters, and as latency-bound launches between the convolutions they cost 0.45 ms of the step.  Measured: beside
+        the first convolutions they cost MORE than in line (30.7 vs 30.4 ms per step); kept as an option (GSD_BF16_SIDE_WIMG=1)."""
+        self._wready = {}
+        if not self.side_dw:
+            return
+        self.side.wait_stream(torch.cuda.current_stream())     # the previous step's Adam update, and its last readers of the images
+        with torch.cuda.stream(self.side):
+            sst = L.stream_ptr()
+
+            def one(mode, w, cout, cin, buf):
+                check(lib.gsd_bf16_weight_image(mode, w.data_ptr(), cout, cin, buf.data_ptr(), sst), "weight_image")
+                ev = self._wevents.get(buf.data_ptr())
+                if ev is None:
+                    ev = self._wevents[buf.data_ptr()] = torch.cuda.Event()
+                ev.record()
+                self._wready[buf.data_ptr()] = ev
+            for pair in self.enc:
+                for u in pair:
+                    one(2 if u.first else 0, P[u.wname], u.cout, u.cin, u.wt_f)
+            for j in range(self.L):
+                up = self.ups[j]
+                one(3, P[up.wname], up.cout, up.cin, up.wt_f)
+                for u in self.dec[j]:
+                    one(0, P[u.wname], u.cout, u.cin, u.wt_f)
+            for j in reversed(range(self.L)):      # backward order
+                for u in reversed(self.dec[j]):
+                    one(1, P[u.wname], u.cout, u.cin, u.wt_d)
+                one(4, P[self.ups[j].wname], self.ups[j].cout, self.ups[j].cin, self.ups[j].wt_d)
+            for lvl in reversed(range(self.L + 1)):
+                for u in reversed(self.enc[lvl]):
+                    if u.need_dgrad:
+                        one(1, P[u.wname], u.cout, u.cin, u.wt_d)
+
+    def _wimage(self, mode: int, w: torch.Tensor, cout: int, cin: int, buf: torch.Tensor, st: int) -> None:
+        ev = self._wready.pop(buf.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)        # produced on the side stream at the start of this step
+            return
+        check(lib.gsd_bf16_weight_image(mode, w.data_ptr(), cout, cin, buf.data_ptr(), st), "weight_image")
+
     def _on_side(self, launch) -> None:
         """Run launch(stream pointer, workspace tensor) -- one weight-gradient launch -- behind everything issued so far, on the
         side stream when there is one."""
@@ -439,7 +487,7 @@ class UNetEngineBF16:
         """dX of unit u (u.g holds dy) into the plain tensor dst (N,H,W,u.cin); with `fuse` (the unit whose activation is
         u's input, dst == fuse.g) the epilogue also does pass 1 of that unit's BatchNorm+ReLU backward."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_bf16_weight_image(1, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_image")
+        self._wimage(1, P[u.wname], u.cout, u.cin, u.wt_d, st)
         din, dout = L.make_nhwc(u.g), L.make_nhwc(dst)
         bw = keep = None
         if fuse is not None:
@@ -484,7 +532,7 @@ class UNetEngineBF16:
             self._on_side(launch)
             check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), self.wspace.data_ptr(),
                                             self.wspace.numel(), st), "convT bias grad")
-            check(lib.gsd_bf16_weight_image(4, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_image")
+            self._wimage(4, P[up.wname], up.cout, up.cin, up.wt_d, st)
             dprev = L.make_nhwc(prev.g)
             done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
             bw, keep = self._bnbwd(prev)
