@@ -524,14 +524,15 @@ class UNetEngineBF16:
             oy, ox = self._pad_off(lvl)
             gup = L.make_nhwc(self.gcat[lvl], self.dims[lvl], up.cout)
             ty, tx = L.int_array([oy, oy, oy + 1, oy + 1]), L.int_array([ox, ox + 1, ox, ox + 1])
-            def launch(sst, ws, up=up, prev=prev, gup=gup, ty=ty, tx=tx, hi=hi, wi=wi):
+            def launch(sst, ws, up=up, prev=prev, gup=gup, ty=ty, tx=tx, hi=hi, wi=wi, oy=oy, ox=ox):
                 done = self._log("bf16_wgrad", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
                 check(lib.gsd_bf16_wgrad(C.byref(prev.a), C.byref(gup), 4, 2, ty, tx, G[up.wname].data_ptr(), up.cout, ws.data_ptr(),
                                          ws.numel(), sst), "convT wgrad")
                 done()
+                # (the bias gradient -- per-channel sums of the same gradient slice -- is off the critical path too)
+                check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                sst), "convT bias grad")
             self._on_side(launch)
-            check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), self.wspace.data_ptr(),
-                                            self.wspace.numel(), st), "convT bias grad")
             self._wimage(4, P[up.wname], up.cout, up.cin, up.wt_d, st)
             dprev = L.make_nhwc(prev.g)
             done = self._log("bf16_convT", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
