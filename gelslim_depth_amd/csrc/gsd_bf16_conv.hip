@@ -56,7 +56,8 @@ struct GConvP {
 };
 
 #ifndef GCONV_ABL   // diagnostic builds (profiles/build_diag_one.sh; results are then garbage): 1 the iteration barrier does not wait
-#define GCONV_ABL 0 // for the fills, 2 no fills after an item's first, 4 no epilogue stores, 8 no barrier (wait only)
+#define GCONV_ABL 0 // for the fills, 2 no fills after an item's first, 4 no epilogue stores, 8 no barrier (wait only), 16 no operand
+                    // reads after an iteration's first tap, 32 no MFMAs
 #endif
 #ifndef GCONV_CONTIG   // 0 (default): instruction k of wave w fills piece 4k + w.  1 (diagnostic builds): a wave's DMA instructions fill
 #define GCONV_CONTIG 0 // ONE contiguous LDS range, up to four sharing an LDS base (M0 set once, the 1-KiB steps in the instruction's
@@ -77,6 +78,15 @@ __device__ __forceinline__ void gconv_dma_piece(const void* g, unsigned char* bu
   __builtin_amdgcn_global_load_lds(g, buf + pc * 1024, 16, 0, 0);
 #endif
 }
+#ifndef GCONV_STAMP   // diagnostic builds only: every block leaves (shader cycles, 100-MHz ticks) of its K-loop life in a buffer of
+#define GCONV_STAMP 0 // its own -> the clock the chip holds under this kernel (profiles/bench_bf16_conv.py, GSD_DIAG_STAMPS=1)
+#endif
+#if GCONV_STAMP
+__device__ unsigned long long gconv_stamp_buf[2 * 4096];
+extern "C" int gsd_diag_gconv_stamps(unsigned long long* host, int nblocks) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(gconv_stamp_buf), sizeof(unsigned long long) * 2 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : 1;
+}
+#endif
 template <int MODE, int WM, int WN>
 __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   constexpr int BM = WM * 64, NPX = WN * 128;
@@ -276,6 +286,9 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   decode(pt, n, h0, w0);
   prep(h0, w0);
   issue(0, 0, n, h0, w0);
+#if GCONV_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   float s1[MT][4], s2[MT][4];   // this lane's running BatchNorm sums over all the block's items
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -345,8 +358,14 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
 #pragma unroll
       for (int i = 0; i < MT * NT / 2; ++i) {
         const int m = i % MT, t = 2 * (i / MT);
+#if (GCONV_ABL) & 32   // no MFMAs (one VALU op keeps the operand reads alive)
+        acc[m][t][0] += __uint_as_float(a[kw & 1][m][0] ^ b[t][0]);
+        acc[m][t + 1][0] += __uint_as_float(a[kw & 1][m][1] ^ b[t + 1][1]);
+#else
         acc[m][t] = mfma_bf16(a[kw & 1][m], b[t], acc[m][t]);
         acc[m][t + 1] = mfma_bf16(a[kw & 1][m], b[t + 1], acc[m][t + 1]);
+#endif
+#if !((GCONV_ABL) & 16)   // 16: no operand reads after an iteration's first tap
         if (kw + 1 < NTAPI) {
           if (i < MT) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(Wc + (kw + 1) * BM * 64 + i * 1024);
           if (i >= MT && (i % MT) < 2) {   // i = 4, 5 -> b[0], b[1]; 8, 9 -> b[2], b[3]; 12, 13 -> b[4], b[5]
@@ -355,6 +374,7 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
           }
         }
         if (kw > 0 && i < 2) b[NT - 2 + i] = *reinterpret_cast<const u32x4*>(Xc + boff[NT - 2 + i] + kw * BSTEP);   // the last pair
+#endif
         if (i < SPT && kw * SPT + i < NS && !(((GCONV_ABL) & 2) && git > 0)) dma_slot(kw * SPT + i, f_it, git + 1, f_n, f_h0, f_w0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -492,6 +512,12 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
   w0 = nw0;
   }
   gsd_dma_barrier();   // vmcnt(0): the last (unread) fill must have landed before the block gives its LDS back
+#if GCONV_STAMP
+  if (tid == 0 && blockIdx.x < 4096) {
+    gconv_stamp_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+    gconv_stamp_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
   if (P.partials != nullptr) {
     // The block is persistent, so its statistics are too: every lane has summed its pixels of ALL the block's items in
     // registers; the 16-lane rows are summed with DPP once, here, and ONE partial row per (block, wave) leaves for HBM (a few

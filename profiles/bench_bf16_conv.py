@@ -37,5 +37,13 @@ for h, w, k, m in SHAPES:
     fl = 2.0 * m * k * 9 * N * h * w
     tot_f += fl
     tot_t += ms
-    print(f"{h}x{w} K{k} M{m}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+    clk = ""
+    if os.environ.get("GSD_DIAG_STAMPS"):   # a -DGCONV_STAMP=1 build (profiles/build_diag_one.sh): the clock the chip held in the kernel
+        import numpy as np
+        buf = (C.c_ulonglong * (2 * 256))()
+        L.lib.gsd_diag_gconv_stamps(buf, 256)
+        a_ = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 2).astype(np.float64)
+        a_ = a_[a_[:, 1] > 0]
+        clk = f"  in-kernel clock {np.median(a_[:, 0] / a_[:, 1]) * 0.1:.2f} GHz over {len(a_)} blocks, {np.median(a_[:, 0]) / 1e3:.1f} kcycles per block (max {a_[:, 0].max() / 1e3:.1f})"
+    print(f"{h}x{w} K{k} M{m}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s{clk}", flush=True)
 print(f"total {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TFLOP/s")

@@ -1,0 +1,156 @@
+// Micro-benchmark (tuning aid, not product): cycles per v_mfma_f32_16x16x32_bf16 for ONE wave per SIMD with the conv kernel's
+// register pattern -- 32 accumulator tiles (4 m x 8 pixel tiles), A/B operands in registers -- and, optionally, the conv
+// kernel's operand traffic (12 ds_read_b128 per 32 MFMAs) and its barrier per 96 MFMAs.  Random operands (the clock depends on
+// the data).  Reports shader cycles per MFMA (s_memtime) and the clock the chip held (s_memtime / s_memrealtime).
+//   hipcc --offload-arch=gfx950 -O3 mfma_bf16_rate.hip -o mfma_bf16_rate && ./mfma_bf16_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// READS: 0 none (operands stay in registers), 1 the conv kernel's 12 ds_read_b128 per tap, interleaved as there, every tap's
+//        operands read during the tap before it (also across the barrier); 2 the same but the FIRST tap's operands are read
+//        after the iteration's barrier, as the conv kernel has to (the data lands with the barrier).
+// NDMA:  LDS-DMA pieces (1 KiB, L2-resident source) per wave and iteration, one per micro-step from the iteration's start.
+// BARRIER: 1 = s_barrier per 3 taps.  WAVES: waves per block (4 = one per SIMD, 8 = two).
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART, int DSTEP, int PW>
+__global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src, float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 49152 / 4; i += WAVES * 64) reinterpret_cast<unsigned*>(smem)[i] = src[(blockIdx.x * 97 + i) & 0xffff];
+  __syncthreads();
+  f32x4 acc[4][8];
+  for (int m = 0; m < 4; ++m)
+    for (int t = 0; t < 8; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
+  u32x4 a[2][4], b[8];
+  const unsigned char* A0 = smem + (wave & 1) * 4096 + lane * 16;
+  const unsigned char* B0 = smem + 16384 + (wave >> 1 & 1) * 12288 + (lane & 15) * 96 + (lane >> 4) * 16;
+  for (int m = 0; m < 4; ++m) a[0][m] = a[1][m] = *reinterpret_cast<const u32x4*>(A0 + m * 1024);
+  for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(B0 + t * 1536);
+  unsigned long long t0, r0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+  if (PW && wave >= 4) {   // producer wave: after each barrier, NDMA pieces (DSTART: s_sleep units before the first, DSTEP: between pieces)
+    for (int it = 0; it < iters; ++it) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      if (DSTART) __builtin_amdgcn_s_sleep(DSTART);
+#pragma unroll
+      for (int d = 0; d < NDMA; ++d) {
+        __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + d) & 63) * 256 + lane * 4, smem + 65536 + ((it & 1) * 16 + d) * 4096 + (wave & 3) * 1024, 16, 0, 0);
+        if (DSTEP > 1) __builtin_amdgcn_s_sleep(DSTEP);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (lane == 0) cyc[(blockIdx.x * WAVES + wave) * 2] = 0, cyc[(blockIdx.x * WAVES + wave) * 2 + 1] = 1;
+    return;
+  }
+  for (int it = 0; it < iters; ++it) {
+    if (BARRIER) { if (NDMA && !PW) __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
+    if (READS == 2) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(A0 + (it & 3) * 2048 + m * 1024);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(B0 + t * 1536 + (it & 1) * 96);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = i % 4, t = 2 * (i / 4);
+        acc[m][t] = mfma(a[kw & 1][m], b[t], acc[m][t]);
+        acc[m][t + 1] = mfma(a[kw & 1][m], b[t + 1], acc[m][t + 1]);
+        if (READS && !(READS == 2 && kw == 2)) {
+          if (i < 4) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(A0 + ((kw + 1 + it) & 3) * 8192 / 4 + i * 1024);
+          if (i >= 4 && (i % 4) < 2) {
+            const int bt = 2 * (i / 4 - 1) + (i % 4);
+            b[bt] = *reinterpret_cast<const u32x4*>(B0 + bt * 1536 + ((kw + 1) & 1) * 96);
+          }
+          if (i < 2) b[6 + i] = *reinterpret_cast<const u32x4*>(B0 + (6 + i) * 1536 + (kw & 1) * 96);
+        }
+        {
+          constexpr int ms = 0;  // placeholder
+          const int step = kw * 16 + i - DSTART;
+          if (!PW && step >= 0 && step % DSTEP == 0 && step / DSTEP < NDMA)
+            __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + step / DSTEP) & 63) * 256 + lane * 4, smem + 65536 + ((it & 1) * 16 + step / DSTEP) * 4096 + wave * 1024, 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  unsigned long long t1, r1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+  float s = 0;
+  for (int m = 0; m < 4; ++m)
+    for (int t = 0; t < 8; ++t) s += acc[m][t][0] + acc[m][t][3];
+  out[blockIdx.x * WAVES * 64 + tid] = s;
+  if (lane == 0) {
+    cyc[(blockIdx.x * WAVES + wave) * 2] = t1 - t0;
+    cyc[(blockIdx.x * WAVES + wave) * 2 + 1] = r1 - r0;
+  }
+}
+
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART = 0, int DSTEP = 1, int PW = 0>
+void run(const char* name, const unsigned* src, float* out, unsigned long long* cyc, int blocks, size_t lds) {
+  const int iters = 4000;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipEventRecord(e1, 0);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h((size_t)blocks * WAVES * 2);
+  hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> c, clk;
+  for (int i = 0; i < blocks * WAVES; ++i) if (h[2 * i] > 0) { c.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }
+  std::sort(c.begin(), c.end()); std::sort(clk.begin(), clk.end());
+  const double mf = 96.0 * iters;
+  const double tf = 2.0 * 16 * 16 * 32 * mf * blocks * (PW ? 4 : WAVES) / (ms * 1e-3) / 1e12;
+  printf("%-44s %6.2f cyc/MFMA/wave  clock %.2f GHz  %.3f ms  %7.1f TFLOP/s\n", name, c[c.size() / 2] / mf, clk[clk.size() / 2], ms, tf);
+}
+
+int main() {
+  unsigned* src; float* out; unsigned long long* cyc;
+  hipMalloc(&src, 65536 * 4); hipMalloc(&out, 512 * 512 * 4); hipMalloc(&cyc, 512 * 8 * 2 * 8);
+  std::vector<unsigned> h(65536);
+  srand(1);
+  for (auto& v : h) {   // two random bf16 in [-1, 1)
+    auto bf = [](float f) { unsigned u; memcpy(&u, &f, 4); return u >> 16; };
+    v = bf(rand() / (float)RAND_MAX * 2 - 1) | (bf(rand() / (float)RAND_MAX * 2 - 1) << 16);
+  }
+  hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  const size_t big = 150 * 1024;   // one block per CU, as in the conv kernel
+  run<1, 1, 4, 0>("reads ahead + barrier", src, out, cyc, 256, big);
+  run<2, 1, 4, 0>("first tap read after the barrier", src, out, cyc, 256, big);
+  run<2, 1, 4, 9>("first tap after barrier + 9 DMA from step 0", src, out, cyc, 256, big);
+  run<1, 1, 4, 9>("ahead + 9 DMA from step 0", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 0, 2>("ahead + 9 DMA every 2nd step", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 0, 4>("ahead + 9 DMA every 4th step", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 2, 4>("ahead + 9 DMA every 4th step from 2", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 3, 5>("ahead + 9 DMA every 5th step from 3", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 16, 2>("ahead + 9 DMA every 2nd step from 16", src, out, cyc, 256, big);
+  run<0, 1, 4, 9, 0, 4>("NO reads + 9 DMA every 4th step", src, out, cyc, 256, big);
+  run<1, 1, 8, 9, 0, 1, 1>("ahead, 4 producer waves: 9 DMA at once", src, out, cyc, 256, big);
+  run<1, 1, 8, 9, 0, 8, 1>("ahead, producers: 9 DMA, s_sleep 8 between", src, out, cyc, 256, big);
+  run<1, 1, 8, 9, 0, 16, 1>("ahead, producers: 9 DMA, s_sleep 16 between", src, out, cyc, 256, big);
+  run<1, 1, 8, 16, 0, 8, 1>("ahead, producers: 16 DMA, s_sleep 8 between", src, out, cyc, 256, big);
+  run<2, 1, 8, 9, 0, 8, 1>("first tap after barrier, producers 9 DMA sleep 8", src, out, cyc, 256, big);
+  return 0;
+}
