@@ -20,21 +20,22 @@ __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
 // READS: 0 none (operands stay in registers), 1 the conv kernel's 12 ds_read_b128 per tap, interleaved as there, every tap's
 //        operands read during the tap before it (also across the barrier); 2 the same but the FIRST tap's operands are read
 //        after the iteration's barrier, as the conv kernel has to (the data lands with the barrier).
+// RDOFF: byte offset of the operand image inside the 150-KiB LDS allocation (0, or 81920: reads above 64 KiB, fills below).
 // NDMA:  LDS-DMA pieces (1 KiB, L2-resident source) per wave and iteration, one per micro-step from the iteration's start.
 // BARRIER: 1 = s_barrier per 3 taps.  WAVES: waves per block (4 = one per SIMD, 8 = two).
-template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART, int DSTEP, int PW>
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART, int DSTEP, int PW, int RDOFF>
 __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src, float* out, unsigned long long* cyc, int iters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 49152 / 4; i += WAVES * 64) reinterpret_cast<unsigned*>(smem)[i] = src[(blockIdx.x * 97 + i) & 0xffff];
+  for (int i = tid; i < 49152 / 4; i += WAVES * 64) reinterpret_cast<unsigned*>(smem + RDOFF)[i] = src[(blockIdx.x * 97 + i) & 0xffff];
   __syncthreads();
   f32x4 acc[4][8];
   for (int m = 0; m < 4; ++m)
     for (int t = 0; t < 8; ++t) acc[m][t] = f32x4{0, 0, 0, 0};
   u32x4 a[2][4], b[8];
-  const unsigned char* A0 = smem + (wave & 1) * 4096 + lane * 16;
-  const unsigned char* B0 = smem + 16384 + (wave >> 1 & 1) * 12288 + (lane & 15) * 96 + (lane >> 4) * 16;
+  const unsigned char* A0 = smem + RDOFF + (wave & 1) * 4096 + lane * 16;
+  const unsigned char* B0 = smem + RDOFF + 16384 + (wave >> 1 & 1) * 12288 + (lane & 15) * 96 + (lane >> 4) * 16;
   for (int m = 0; m < 4; ++m) a[0][m] = a[1][m] = *reinterpret_cast<const u32x4*>(A0 + m * 1024);
   for (int t = 0; t < 8; ++t) b[t] = *reinterpret_cast<const u32x4*>(B0 + t * 1536);
   unsigned long long t0, r0;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
           constexpr int ms = 0;  // placeholder
           const int step = kw * 16 + i - DSTART;
           if (!PW && step >= 0 && step % DSTEP == 0 && step / DSTEP < NDMA)
-            __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + step / DSTEP) & 63) * 256 + lane * 4, smem + 65536 + ((it & 1) * 16 + step / DSTEP) * 4096 + wave * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + step / DSTEP) & 63) * 256 + lane * 4, smem + (RDOFF ? 0 : 65536) + ((it & 1) * 16 + step / DSTEP) * 4096 + wave * 1024, 16, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -103,15 +104,15 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
   }
 }
 
-template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART = 0, int DSTEP = 1, int PW = 0>
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART = 0, int DSTEP = 1, int PW = 0, int RDOFF = 0>
 void run(const char* name, const unsigned* src, float* out, unsigned long long* cyc, int blocks, size_t lds) {
   const int iters = 4000;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms = 0;
@@ -138,19 +139,13 @@ int main() {
   hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   const size_t big = 150 * 1024;   // one block per CU, as in the conv kernel
   run<1, 1, 4, 0>("reads ahead + barrier", src, out, cyc, 256, big);
+  run<1, 1, 4, 0, 0, 1, 0, 81920>("reads ahead + barrier, image above 64 KiB", src, out, cyc, 256, big);
   run<2, 1, 4, 0>("first tap read after the barrier", src, out, cyc, 256, big);
-  run<2, 1, 4, 9>("first tap after barrier + 9 DMA from step 0", src, out, cyc, 256, big);
-  run<1, 1, 4, 9>("ahead + 9 DMA from step 0", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 0, 2>("ahead + 9 DMA every 2nd step", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 0, 4>("ahead + 9 DMA every 4th step", src, out, cyc, 256, big);
   run<1, 1, 4, 9, 2, 4>("ahead + 9 DMA every 4th step from 2", src, out, cyc, 256, big);
+  run<1, 1, 4, 9, 2, 4, 0, 81920>("ahead + 9 DMA (from 2, every 4th), image above 64 KiB", src, out, cyc, 256, big);
   run<1, 1, 4, 9, 3, 5>("ahead + 9 DMA every 5th step from 3", src, out, cyc, 256, big);
   run<1, 1, 4, 9, 16, 2>("ahead + 9 DMA every 2nd step from 16", src, out, cyc, 256, big);
-  run<0, 1, 4, 9, 0, 4>("NO reads + 9 DMA every 4th step", src, out, cyc, 256, big);
+  run<2, 1, 4, 9, 2, 4>("first tap after barrier + 9 DMA (from 2, every 4th)", src, out, cyc, 256, big);
   run<1, 1, 8, 9, 0, 1, 1>("ahead, 4 producer waves: 9 DMA at once", src, out, cyc, 256, big);
-  run<1, 1, 8, 9, 0, 8, 1>("ahead, producers: 9 DMA, s_sleep 8 between", src, out, cyc, 256, big);
-  run<1, 1, 8, 9, 0, 16, 1>("ahead, producers: 9 DMA, s_sleep 16 between", src, out, cyc, 256, big);
-  run<1, 1, 8, 16, 0, 8, 1>("ahead, producers: 16 DMA, s_sleep 8 between", src, out, cyc, 256, big);
-  run<2, 1, 8, 9, 0, 8, 1>("first tap after barrier, producers 9 DMA sleep 8", src, out, cyc, 256, big);
   return 0;
 }
