@@ -99,6 +99,8 @@ SIGNATURES = {
     "gsd_sum_planes": (_I, [_P, _I, _I, _L, _P, _P, _P]),
     "gsd_maxpool2": (_I, [_SRC, _P, _I, _I, _I, _I, _P]),
     "gsd_conv1x1_out": (_I, [_SRC, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "gsd_conv1x1_out_wgrad_rows": (_I, [_I, _I, _I]),
+    "gsd_conv1x1_out_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "gsd_loss_fwd_bwd": (_I, [_I, _P, _P, _L, _F, _P, _P, _P, _GUARD, _P]),
     "gsd_guard_snapshot": (_I, [_P, _P, _L, _P]),
     "gsd_guard_restore": (_I, [_GUARD, _P, _P, _L, _P]),

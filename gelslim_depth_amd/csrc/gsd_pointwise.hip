@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams P)
       for (int k = 0; k < P.K; ++k) {
         const float d = P.dout[((size_t)n * P.K + k) * HW + e];
         g = fmaf(d, P.wout[(size_t)k * P.C + c], g);
-        if (k == 0) s3 = fmaf(d, fmaxf(y, 0.f), s3);  // dW_out[0][c] (K==1 fast path; K>1 handled on host side)
+        if (k == 0) s3 = fmaf(d, fmaxf(y, 0.f), s3);  // dW_out[0][c] (all of dW_out when K == 1; K > 1: gsd_conv1x1_out_wgrad)
       }
     } else {
       g = 0.f;
@@ -711,7 +711,7 @@ extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale,
   if (mode == 1) GSD_REQUIRE(dpool != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode POOL needs dpool");
   if (mode == 2) {
     GSD_REQUIRE(dout != nullptr && wout != nullptr, GSD_ERR_BAD_ARG, "gsd_bn_bwd_reduce: mode OUTC needs dout, wout");
-    GSD_REQUIRE(K == 1, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_reduce: backward of the output conv supports n_classes == 1 only (got %d)", K);
+    GSD_REQUIRE(K >= 1 && K <= 8, GSD_ERR_UNSUPPORTED, "gsd_bn_bwd_reduce: backward of the output conv supports 1 <= n_classes <= 8 (got %d)", K);
   }
   P.dpool = dpool; P.dout = dout; P.wout = wout; P.K = K;
   P.dz = dz; P.partials = partials;
@@ -724,7 +724,7 @@ extern "C" int gsd_bn_bwd_reduce(int mode, const float* raw, const float* scale,
                    (mode == 2 || (P.da.ns % 4 == 0 && P.da.cs % 4 == 0));
   if (mode == 1 && !scalar) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, P);
   else if (mode == 0 && vec) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
-  else if (mode == 2 && vec) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+  else if (mode == 2 && vec && K == 1) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
   else if (mode == 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, P);
   else if (mode == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, P);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, P);
@@ -961,6 +961,62 @@ extern "C" int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* 
     hipLaunchKernelGGL(conv1x1_out_kernel, dim3(ceil_div(H * W, 256), N), dim3(256), 0, (hipStream_t)stream, to_srcd(*src),
                        w, b, C, K, out, H * W);
   GSD_LAUNCH_CHECK("gsd_conv1x1_out");
+  return GSD_OK;
+}
+
+// dW of the output conv for n_classes > 1 (the K == 1 case comes out of gsd_bn_bwd_reduce mode 2 as its third sum):
+//   dw[k][c] = sum_{n,p} dout[n,k,p] * max(0, raw[n,c,p]*scale[c] + shift[c])
+// One block per (pixel chunk, channel, image) leaves K partial sums; the column sums (fp64, then fp32) finish it.
+constexpr int OUTW_CHUNK = 8192;
+__global__ __launch_bounds__(256) void conv1x1_out_wgrad_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ dout,
+                                                                int K, int C, int HW, int chunks, float* __restrict__ partials) {
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float sc = scale[c], sh = shift[c];
+  const float* x = raw + ((size_t)n * C + c) * HW;
+  const float* d = dout + (size_t)n * K * HW;
+  float s[OUTC_MAXK];
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k) s[k] = 0.f;
+  const int e_end = min((chunk + 1) * OUTW_CHUNK, HW);
+  for (int e = chunk * OUTW_CHUNK + threadIdx.x; e < e_end; e += 256) {
+    const float a = fmaxf(fmaf(x[e], sc, sh), 0.f);
+#pragma unroll
+    for (int k = 0; k < OUTC_MAXK; ++k)
+      if (k < K) s[k] = fmaf(d[(size_t)k * HW + e], a, s[k]);
+  }
+  __shared__ float red[OUTC_MAXK][4];
+#pragma unroll
+  for (int k = 0; k < OUTC_MAXK; ++k) {
+    const float v = wave_sum_f(s[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int row = n * chunks + chunk;
+    partials[(size_t)row * K * C + (size_t)threadIdx.x * C + c] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+extern "C" int gsd_conv1x1_out_wgrad_rows(int N, int H, int W) {
+  return (N > 0 && H > 0 && W > 0) ? N * ceil_div(H * W, OUTW_CHUNK) : 0;
+}
+extern "C" int gsd_conv1x1_out_wgrad(const float* raw, const float* scale, const float* shift, const float* dout, int C, int K,
+                                     float* dw, float* partials, double* sums, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(raw && scale && shift && dout && dw && partials && sums && N > 0 && C > 0 && K > 0 && H > 0 && W > 0, GSD_ERR_BAD_ARG,
+              "gsd_conv1x1_out_wgrad: bad argument");
+  GSD_REQUIRE(K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out_wgrad: n_classes %d > %d", K, OUTC_MAXK);
+  GSD_REQUIRE(N <= 65535 && C <= 65535, GSD_ERR_UNSUPPORTED, "gsd_conv1x1_out_wgrad: N, C must be <= 65535");
+  const int chunks = ceil_div(H * W, OUTW_CHUNK), rows = N * chunks, cols = K * C;
+  hipLaunchKernelGGL(conv1x1_out_wgrad_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, dout, K, C,
+                     H * W, chunks, partials);
+  GSD_LAUNCH_CHECK("gsd_conv1x1_out_wgrad");
+  double* tmp = sums + cols;
+  hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 64), RG, 1), dim3(64 * CS_LANES), 0, (hipStream_t)stream, partials, rows, cols,
+                     cols, 0, tmp);
+  GSD_LAUNCH_CHECK("gsd_conv1x1_out_wgrad stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256), 1), dim3(256), 0, (hipStream_t)stream, tmp, cols, sums, dw, 0, cols);
+  GSD_LAUNCH_CHECK("gsd_conv1x1_out_wgrad stage2");
   return GSD_OK;
 }
 

@@ -200,6 +200,11 @@ class UNetEngine:
         # fp64 column sums of a dX launch's statistics (ConvT bias gradients): gsd_bn_reduce_partials wants (1 + 64) x 2 C doubles
         self.db_sums = torch.empty((65 * 2 * max(u.cin for u in self.units),), device=dev, dtype=torch.float64) if train else None
         self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
+        self.outw_partials = self.outw_sums = None
+        if train and self.n_classes > 1:    # dW of the output conv for K > 1 (gsd_conv1x1_out_wgrad)
+            kc = self.n_classes * self.dims[0]
+            self.outw_partials = torch.empty((lib.gsd_conv1x1_out_wgrad_rows(n, hs[0], ws[0]) * kc,), **f32)
+            self.outw_sums = torch.empty((65 * kc,), device=dev, dtype=torch.float64)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -418,6 +423,14 @@ class UNetEngine:
         check(lib.gsd_sum_planes(dout.data_ptr(), n, self.n_classes, dout.shape[2] * dout.shape[3],
                                  G["outc.conv.bias"].data_ptr(), self.wgrad_ws.data_ptr(), st), "sum_planes")
         dwout = G["outc.conv.weight"]
+        if self.n_classes > 1:
+            # K > 1: the reduce above leaves only row 0 of dW_out among its sums; all K rows come from a pass of their own
+            # (aten::convolution_backward of unet.py:54; no reference config uses it, so it is not on the tuned path)
+            lh, lw = self.hs[last.level], self.ws[last.level]
+            check(lib.gsd_conv1x1_out_wgrad(last.raw.data_ptr(), last.scale.data_ptr(), last.shift.data_ptr(), dout.data_ptr(),
+                                            last.cout, self.n_classes, dwout.data_ptr(), self.outw_partials.data_ptr(),
+                                            self.outw_sums.data_ptr(), n, lh, lw, st), "conv1x1_out_wgrad")
+            dwout = None
         for j in reversed(range(self.L)):
             u0, u1 = self.dec[j]
             up = self.ups[j]

@@ -226,8 +226,9 @@ int gsd_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
  *   mode 0 PLAIN: da given by `da` (gsd_src, plain).
  *   mode 1 POOL : da = da (may be NULL ptr => 0) + max-pool routed `dpool` (N,C,H/2,W/2):
  *                 the 2x2 arg-max is recomputed from raw (first maximum wins, like aten).
- *   mode 2 OUTC : da[c] = dout*wout[c]   (1x1 output conv unet.py:54 with n_classes K == 1), extra
- *                 partial dWout[c] = sum dout*a[c]  (a = relu(bn(raw))).
+ *   mode 2 OUTC : da[c] = sum_k dout[k]*wout[k][c]   (1x1 output conv unet.py:54, n_classes K <= 8), extra
+ *                 partial dWout[0][c] = sum dout[0]*a[c]  (a = relu(bn(raw))): all of dWout for K == 1; for K > 1 see
+ *                 gsd_conv1x1_out_wgrad.
  * partial layout: [rows][3*C] (third block only meaningful in mode 2), rows from
  * gsd_bn_bwd_partial_rows. */
 int gsd_bn_bwd_partial_rows(int N, int C, int H, int W);
@@ -272,6 +273,12 @@ int gsd_maxpool2(const gsd_src* src, float* y, int N, int C, int H, int W, void*
 /* out[n,k,p] = b[k] + sum_c w[k][c] * max(0, raw[c]*scale[c]+shift[c]). */
 int gsd_conv1x1_out(const gsd_src* src, const float* w, const float* b, int C, int K,
                     float* out, int N, int H, int W, void* stream);
+/* dW of the output conv for n_classes K > 1 (1 <= K <= 8; for K == 1 it is the third sum of gsd_bn_bwd_reduce mode 2):
+ * dw[k][c] = sum_{n,p} dout[n,k,p] * max(0, raw[n,c,p]*scale[c]+shift[c])  (aten::convolution_backward of unet.py:54).
+ * raw: dense (N,C,H,W); partials: gsd_conv1x1_out_wgrad_rows(N,H,W) * K*C floats; sums: 65*K*C doubles of scratch. */
+int gsd_conv1x1_out_wgrad_rows(int N, int H, int W);
+int gsd_conv1x1_out_wgrad(const float* raw, const float* scale, const float* shift, const float* dout, int C, int K,
+                          float* dw, float* partials, double* sums, int N, int H, int W, void* stream);
 /* loss = mean((o-t)^2) (kind 0) or mean(|o-t|) (kind 1); grad = d loss/d o * grad_scale.
  * loss_out: 1 float (device). workspace >= 2048 floats. grad and guard may be NULL. */
 int gsd_loss_fwd_bwd(int kind, const float* o, const float* t, int64_t numel, float grad_scale,

@@ -228,6 +228,35 @@ def test_other_resolutions_vs_oracle(h, w, dims):
         assert rel_l1(p.grad.cpu().numpy(), first["grads"][k]) < 2e-2, k
 
 
+@pytest.mark.parametrize("k,h,w,dims", [(3, 37, 53, [8, 16, 32]), (8, 21, 27, [16]), (2, 64, 64, [16, 32])])
+def test_more_than_one_output_class_vs_oracle(k, h, w, dims):
+    """UNet(n_channels, n_classes > 1) (unet.py:61,77: OutConv(dims[0], n_classes)): forward, loss and EVERY gradient against the
+    oracle -- the output conv's dX sums over the classes (gsd_bn_bwd_reduce mode 2, K <= 8) and its dW has K rows
+    (gsd_conv1x1_out_wgrad).  No reference config trains with n_classes > 1; the constructor accepts it, so the drop-in does."""
+    from oracle import unet_numpy as on
+    from gelslim_depth_amd.models.unet import UNet
+    st = synth.make_state(3, k, dims, 900 + k, "conditioned")
+    x, tgt = synth.make_batch(2, h, w, 17 * k, n_classes=k)
+    m = UNet(n_channels=3, n_classes=k, layer_dimensions=dims)
+    m.load_state_dict({n_: torch.from_numpy(v.copy()) for n_, v in st.items()}, strict=True)
+    m = m.to("cuda")
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    m.eval()
+    y = m(x=xd)
+    assert tuple(y.shape) == (2, k, h, w)
+    assert rel_l1(y.cpu().numpy(), on.UNetOracle(st).forward(x, train=False)) < 1e-4
+    m.train()
+    out = m(x=xd)
+    loss = torch.mean((out - td) ** 2)
+    loss.backward()
+    net, losses, first, _ = on.train_steps(st, x, tgt, 1)
+    assert abs(loss.item() - losses[0]) < 2e-4 * losses[0]
+    for name, p_ in m.named_parameters():
+        assert p_.grad.shape == p_.shape
+        tol = 1e-4 if name.startswith("outc.") else 2e-2     # outc: no upstream error; the rest: test_other_resolutions' bound
+        assert rel_l1(p_.grad.cpu().numpy(), first["grads"][name]) < tol, name
+
+
 def test_winograd_and_direct_forms_agree(monkeypatch):
     """The two forms of the fp32 conv3x3 kernels (direct taps / Winograd F(4,3) along rows) through the
     whole network on the same weights and batch.
