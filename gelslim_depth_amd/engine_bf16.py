@@ -463,7 +463,7 @@ class UNetEngineBF16:
     def _on_side(self, launch) -> None:
         """Run launch(stream pointer, workspace tensor) -- one weight-gradient launch -- behind everything issued so far, on the
         side stream when there is one."""
-        if not self.side_dw:
+        if not self.side_dw or self.kernel_log is not None:   # (a per-kernel timing pass wants every kernel alone on the chip)
             launch(L.stream_ptr(), self.wspace)
             return
         self.side.wait_stream(torch.cuda.current_stream())
