@@ -56,6 +56,11 @@ class gsd_bf16_bnbwd(C.Structure):
                 ("invstd", C.c_void_p)]
 
 
+class gsd_bf16_wimg_job(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("mode", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 _NHWC = C.POINTER(gsd_nhwc)
 _BNBWD = C.POINTER(gsd_bf16_bnbwd)
 _IP = C.POINTER(C.c_int)
@@ -122,6 +127,7 @@ SIGNATURES = {
     "gsd_bf16_conv1x1_bnrelu": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P, _P]),
     "gsd_bf16_weight_image_size": (_L, [_I, _I, _I]),
     "gsd_bf16_weight_image": (_I, [_I, _P, _I, _I, _P, _P]),
+    "gsd_bf16_weight_images": (_I, [C.POINTER(gsd_bf16_wimg_job), _I, _P]),
     "gsd_bf16_im2col3x3": (_I, [_P, _I, _I, _I, _I, _NHWC, _P]),
     "gsd_bf16_conv3x3_first_supported": (_I, [_I, _I]),
     "gsd_bf16_conv3x3_first_partial_rows": (_I, [_I, _I, _I, _I]),

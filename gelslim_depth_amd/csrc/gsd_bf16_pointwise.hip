@@ -36,9 +36,10 @@ WImg wimg_dims(int mode, int Cout, int Cin) {
   return d;
 }
 
-__global__ void weight_image_kernel(int mode, const float* __restrict__ w, int Cout, int Cin, u16* __restrict__ out, WImg d) {
+__device__ __forceinline__ void weight_image_elements(int mode, const float* __restrict__ w, int Cout, int Cin, u16* __restrict__ out,
+                                                      const WImg& d, long long first, long long stride) {
   const long long total = (long long)d.T * d.Mp * d.Kp;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+  for (long long e = first; e < total; e += stride) {
     const int k = (int)(e % d.Kp);
     const int m = (int)((e / d.Kp) % d.Mp);
     const int t = (int)(e / ((long long)d.Kp * d.Mp));
@@ -53,6 +54,41 @@ __global__ void weight_image_kernel(int mode, const float* __restrict__ w, int C
       }
     }
     out[e] = f32_to_bf16(v);
+  }
+}
+__global__ void weight_image_kernel(int mode, const float* __restrict__ w, int Cout, int Cin, u16* __restrict__ out, WImg d) {
+  weight_image_elements(mode, w, Cout, Cin, out, d, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+// every image of a step in one launch (blockIdx.y = job): as 43 separate launches between the convolutions they are latency,
+// 10 us each
+constexpr int WJOBS = 32;
+constexpr int WCHUNK = 16384;   // elements per block: a job gets blocks in proportion to its size
+struct WJob { const float* w; u16* out; int mode, Cout, Cin, first_block; WImg d; };
+struct WJobs { WJob j[WJOBS]; int n; };
+__global__ __launch_bounds__(256) void weight_images_kernel(WJobs jobs) {
+  int q = 0;
+  while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].first_block) ++q;   // (<= 32 jobs: a linear search)
+  const WJob& J = jobs.j[q];
+  const long long base = (long long)((int)blockIdx.x - J.first_block) * WCHUNK;
+  const long long total = (long long)J.d.T * J.d.Mp * J.d.Kp;
+  const long long end = base + WCHUNK < total ? base + WCHUNK : total;
+  WImg d = J.d;
+  // the element loop of weight_image_elements over [base, end)
+  for (long long e = base + threadIdx.x; e < end; e += 256) {
+    const int k = (int)(e % d.Kp);
+    const int m = (int)((e / d.Kp) % d.Mp);
+    const int t = (int)(e / ((long long)d.Kp * d.Mp));
+    float v = 0.f;
+    if (m < d.M && k < d.K) {
+      switch (J.mode) {
+        case 0: v = J.w[((size_t)m * J.Cin + k) * 9 + t]; break;
+        case 1: v = J.w[((size_t)k * J.Cin + m) * 9 + (8 - t)]; break;
+        case 2: v = J.w[(size_t)m * J.Cin * 9 + k]; break;
+        case 3: { const int qq = m / J.Cout, co = m - qq * J.Cout; v = J.w[((size_t)k * J.Cout + co) * 4 + qq]; break; }
+        default: v = J.w[((size_t)m * J.Cout + k) * 4 + t]; break;
+      }
+    }
+    J.out[e] = f32_to_bf16(v);
   }
 }
 
@@ -462,6 +498,28 @@ extern "C" int gsd_bf16_weight_image(int mode, const float* w, int Cout, int Cin
   const int grid = (int)(ceil_div64(total, 256) < 8192 ? ceil_div64(total, 256) : 8192);
   hipLaunchKernelGGL(weight_image_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Cout, Cin, (u16*)out, d);
   GSD_LAUNCH_CHECK("gsd_bf16_weight_image");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_weight_images(const gsd_bf16_wimg_job* jobs, int n, void* stream) {
+  GSD_REQUIRE(jobs && n > 0, GSD_ERR_BAD_ARG, "gsd_bf16_weight_images: bad argument");
+  for (int i = 0; i < n; ++i)
+    GSD_REQUIRE(jobs[i].w && jobs[i].out && jobs[i].mode >= 0 && jobs[i].mode <= 4 && jobs[i].Cout > 0 && jobs[i].Cin > 0, GSD_ERR_BAD_ARG,
+                "gsd_bf16_weight_images: bad job %d", i);
+  for (int base = 0; base < n; base += WJOBS) {
+    WJobs a;
+    a.n = n - base < WJOBS ? n - base : WJOBS;
+    long long blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const gsd_bf16_wimg_job& q = jobs[base + i];
+      const WImg d = wimg_dims(q.mode, q.Cout, q.Cin);
+      a.j[i] = WJob{q.w, (u16*)q.out, q.mode, q.Cout, q.Cin, (int)blocks, d};
+      blocks += ceil_div64((long long)d.T * d.Mp * d.Kp, WCHUNK);
+    }
+    GSD_REQUIRE(blocks < 2147483647LL, GSD_ERR_UNSUPPORTED, "gsd_bf16_weight_images: images too large");
+    hipLaunchKernelGGL(weight_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GSD_LAUNCH_CHECK("gsd_bf16_weight_images");
+  }
   return GSD_OK;
 }
 

@@ -125,7 +125,7 @@ class UNetEngineBF16:
         f32 = dict(device=dev, dtype=torch.float32)
         # first layer: straight from x (gsd_bf16_conv3x3_first / gsd_bf16_wgrad_first) where the shape is served, else through the
         # im2col'd input (col0) and the dense-tap kernels; GSD_BF16_FIRST=0 forces the im2col path
-        self._wready, self._wevents = {}, {}
+        self._wready, self._wevents, self._wdone = {}, {}, set()
         self.first_direct = bool(lib.gsd_bf16_conv3x3_first_supported(self.n_channels, self.dims[0])) and \
             os.environ.get("GSD_BF16_FIRST", "1") != "0"
         self.col0 = None if self.first_direct else torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
@@ -306,9 +306,7 @@ class UNetEngineBF16:
         self._nbt = []
         self.generation += 1       # every forward overwrites the saved activations
         self._x = x
-        self._wready = {}
-        if train and os.environ.get("GSD_BF16_SIDE_WIMG", "0") != "0":     # measured: 30.7 vs 30.4 ms per step -- off by default
-            self._prepare_weight_images(P)
+        self._prepare_weight_images(P, train)
         region = self._region_begin()         # bench hook: the `inc` double-conv forward (2 convs, BN statistics + apply)
         if not self.first_direct:
             dcol = L.make_nhwc(self.col0)
@@ -416,44 +414,60 @@ class UNetEngineBF16:
             done()
         self._on_side(launch)
 
-    def _prepare_weight_images(self, P) -> None:
-        """Train mode: every bf16 weight image of the step (43 small launches: forward and dX images of the 18 conv units, the
-        two images of each transposed conv) is produced on the SIDE stream at the start of the forward, in the order the main
-        stream will want them, each followed by an event; `_wimage` then only waits for the event.  They depend on nothing but
-        the parameters, and as latency-bound launches between the convolutions they cost 0.45 ms of the step.  Measured: beside
-        the first convolutions they cost MORE than in line (30.7 vs 30.4 ms per step); kept as an option (GSD_BF16_SIDE_WIMG=1)."""
+    def _image_jobs(self, P, train: bool):
+        """(mode, weights, cout, cin, image buffer) of every weight image a step reads: the forward images, and in train mode
+        the dX images of the units that have a dX."""
+        jobs = []
+        for pair in self.enc:
+            for u in pair:
+                jobs.append((2 if u.first else 0, P[u.wname], u.cout, u.cin, u.wt_f))
+        for j in range(self.L):
+            up = self.ups[j]
+            jobs.append((3, P[up.wname], up.cout, up.cin, up.wt_f))
+            for u in self.dec[j]:
+                jobs.append((0, P[u.wname], u.cout, u.cin, u.wt_f))
+        if train:
+            for j in range(self.L):
+                for u in self.dec[j]:
+                    jobs.append((1, P[u.wname], u.cout, u.cin, u.wt_d))
+                jobs.append((4, P[self.ups[j].wname], self.ups[j].cout, self.ups[j].cin, self.ups[j].wt_d))
+            for pair in self.enc:
+                for u in pair:
+                    if u.need_dgrad:
+                        jobs.append((1, P[u.wname], u.cout, u.cin, u.wt_d))
+        return jobs
+
+    def _prepare_weight_images(self, P, train: bool) -> None:
+        """Every bf16 weight image of the step in ONE launch per 32 images at the start of the forward (gsd_bf16_weight_images):
+        they depend on nothing but the parameters, and as 43 latency-bound launches between the convolutions they cost 0.45 ms
+        of a 30-ms step.  `_wimage` then finds the image done.  GSD_BF16_BATCH_WIMG=0: one launch per image, where it is used.
+        (GSD_BF16_SIDE_WIMG=1, the per-image launches on the side stream instead, measured slower: 30.7 vs 30.4 ms.)"""
         self._wready = {}
-        if not self.side_dw:
+        self._wdone = set()
+        if os.environ.get("GSD_BF16_BATCH_WIMG", "1") != "0":
+            jobs = self._image_jobs(P, train)
+            arr = (L.gsd_bf16_wimg_job * len(jobs))()
+            for i, (mode, w, cout, cin, buf) in enumerate(jobs):
+                arr[i].w, arr[i].out, arr[i].mode, arr[i].Cout, arr[i].Cin = w.data_ptr(), buf.data_ptr(), mode, cout, cin
+                self._wdone.add(buf.data_ptr())
+            check(lib.gsd_bf16_weight_images(arr, len(jobs), L.stream_ptr()), "weight_images")
+            return
+        if not (train and self.side_dw and os.environ.get("GSD_BF16_SIDE_WIMG", "0") == "1"):
             return
         self.side.wait_stream(torch.cuda.current_stream())     # the previous step's Adam update, and its last readers of the images
         with torch.cuda.stream(self.side):
             sst = L.stream_ptr()
-
-            def one(mode, w, cout, cin, buf):
+            for mode, w, cout, cin, buf in self._image_jobs(P, train):
                 check(lib.gsd_bf16_weight_image(mode, w.data_ptr(), cout, cin, buf.data_ptr(), sst), "weight_image")
                 ev = self._wevents.get(buf.data_ptr())
                 if ev is None:
                     ev = self._wevents[buf.data_ptr()] = torch.cuda.Event()
                 ev.record()
                 self._wready[buf.data_ptr()] = ev
-            for pair in self.enc:
-                for u in pair:
-                    one(2 if u.first else 0, P[u.wname], u.cout, u.cin, u.wt_f)
-            for j in range(self.L):
-                up = self.ups[j]
-                one(3, P[up.wname], up.cout, up.cin, up.wt_f)
-                for u in self.dec[j]:
-                    one(0, P[u.wname], u.cout, u.cin, u.wt_f)
-            for j in reversed(range(self.L)):      # backward order
-                for u in reversed(self.dec[j]):
-                    one(1, P[u.wname], u.cout, u.cin, u.wt_d)
-                one(4, P[self.ups[j].wname], self.ups[j].cout, self.ups[j].cin, self.ups[j].wt_d)
-            for lvl in reversed(range(self.L + 1)):
-                for u in reversed(self.enc[lvl]):
-                    if u.need_dgrad:
-                        one(1, P[u.wname], u.cout, u.cin, u.wt_d)
 
     def _wimage(self, mode: int, w: torch.Tensor, cout: int, cin: int, buf: torch.Tensor, st: int) -> None:
+        if buf.data_ptr() in self._wdone:                     # produced by the batched launch at the start of this step
+            return
         ev = self._wready.pop(buf.data_ptr(), None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)        # produced on the side stream at the start of this step

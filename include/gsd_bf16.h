@@ -76,6 +76,14 @@ int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out,
  *      4 ConvTranspose2d dX:                         [kh*2+kw][ci][co]                                             */
 int64_t gsd_bf16_weight_image_size(int mode, int Cout, int Cin);
 int gsd_bf16_weight_image(int mode, const float* w, int Cout, int Cin, void* out, void* stream);
+/* n images in one launch per 32 jobs (a train step wants 43: as separate launches between the convolutions they are pure
+ * latency); same values as gsd_bf16_weight_image job by job.  `jobs` is a host array. */
+typedef struct gsd_bf16_wimg_job {
+  const float* w;   /* fp32 master weights */
+  void* out;        /* gsd_bf16_weight_image_size(mode, Cout, Cin) bf16 elements */
+  int32_t mode, Cout, Cin, reserved;
+} gsd_bf16_wimg_job;
+int gsd_bf16_weight_images(const gsd_bf16_wimg_job* jobs, int n, void* stream);
 
 /* First layer WITHOUT the im2col tensor (unet.py:11 for `inc`, 9*C <= 32 and M in {32, 64}: gsd_bf16_conv3x3_first_supported):
  *   out[n,h,w,m] = sum_{c,t} bf16(x[n,c,h+t/3-1,w+t%3-1]) * wt[m][c*9+t]       x (N,C,H,W) fp32, wt: weight image mode 2

@@ -38,6 +38,7 @@ def test_struct_layout_matches_header():
     assert _lib.gsd_src.w_stride.offset == 48 and _lib.gsd_src.slack.offset == 52 and _lib.gsd_src.n_stride.offset == 56
     assert _lib.gsd_dst.w_stride.offset == 28 and _lib.gsd_dst.n_stride.offset == 32
     assert ctypes.sizeof(_lib.gsd_nhwc) == 8 + 8 + 4 * 4 and _lib.gsd_nhwc.N.offset == 16
+    assert ctypes.sizeof(_lib.gsd_bf16_wimg_job) == 8 + 8 + 4 * 4 and _lib.gsd_bf16_wimg_job.mode.offset == 16
 
 
 def test_product_never_imports_oracle():

@@ -130,6 +130,32 @@ def test_conv3x3_bf16_item_order_is_only_an_order(monkeypatch):
         np.testing.assert_allclose(res["1"][i].cpu().numpy(), res["0"][i].cpu().numpy(), rtol=1e-5, atol=1e-2)
 
 
+def test_weight_images_batched_equal_one_by_one():
+    """gsd_bf16_weight_images (every image of a step in one launch per 32 jobs) writes what gsd_bf16_weight_image writes job by
+    job -- all five layouts, 40 jobs (two launches), sizes with and without padding."""
+    L = _lib()
+    g = torch.Generator().manual_seed(99)
+    shapes = [(0, 64, 3), (0, 64, 64), (1, 64, 64), (2, 64, 3), (3, 32, 64), (4, 32, 64), (0, 128, 96), (1, 128, 96), (0, 48, 160),
+              (3, 64, 128)] * 4
+    jobs = (L.gsd_bf16_wimg_job * len(shapes))()
+    keep, one_by_one = [], []
+    for i, (mode, cout, cin) in enumerate(shapes):
+        kk = 2 if mode >= 3 else 3
+        w = (torch.randn((cin, cout, kk, kk) if mode >= 3 else (cout, cin, kk, kk), generator=g)).cuda()
+        n = L.lib.gsd_bf16_weight_image_size(mode, cout, cin)
+        a = torch.full((n,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        b = torch.full((n,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib.gsd_bf16_weight_image(mode, w.data_ptr(), cout, cin, a.data_ptr(), L.stream_ptr()), "weight_image")
+        jobs[i].w, jobs[i].out, jobs[i].mode, jobs[i].Cout, jobs[i].Cin = w.data_ptr(), b.data_ptr(), mode, cout, cin
+        keep.append(w)
+        one_by_one.append((a, b))
+    L.check(L.lib.gsd_bf16_weight_images(jobs, len(shapes), L.stream_ptr()), "weight_images")
+    for a, b in one_by_one:
+        assert bool(torch.isfinite(b.float()).all())
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert L.lib.gsd_bf16_weight_images(jobs, 0, L.stream_ptr()) != 0      # refused: no jobs
+
+
 def test_dense_1x1_and_convT_bf16():
     L = _lib()
     g = torch.Generator().manual_seed(5)
