@@ -21,10 +21,12 @@ __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
 //        operands read during the tap before it (also across the barrier); 2 the same but the FIRST tap's operands are read
 //        after the iteration's barrier, as the conv kernel has to (the data lands with the barrier).
 // RDOFF: byte offset of the operand image inside the 150-KiB LDS allocation (0, or 81920: reads above 64 KiB, fills below).
+//        3 = the single-buffered two-blocks-per-CU model: {barrier, NDMA fills in a burst, vmcnt(0), barrier, first tap's reads,
+//        96 MFMAs with the other taps' reads interleaved}; launch 2 x 256 blocks with <= 75 KiB of LDS each.
 // NDMA:  LDS-DMA pieces (1 KiB, L2-resident source) per wave and iteration, one per micro-step from the iteration's start.
 // BARRIER: 1 = s_barrier per 3 taps.  WAVES: waves per block (4 = one per SIMD, 8 = two).
-template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART, int DSTEP, int PW, int RDOFF>
-__global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src, float* out, unsigned long long* cyc, int iters) {
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART, int DSTEP, int PW, int RDOFF, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void k(const unsigned* __restrict__ src, float* out, unsigned long long* cyc, int iters, size_t srcmask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
       if (DSTART) __builtin_amdgcn_s_sleep(DSTART);
 #pragma unroll
       for (int d = 0; d < NDMA; ++d) {
-        __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + d) & 63) * 256 + lane * 4, smem + 65536 + ((it & 1) * 16 + d) * 4096 + (wave & 3) * 1024, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + (((size_t)blockIdx.x * 8 + wave + it * 16 + d) & srcmask) * 256 + lane * 4, smem + 49152 + (d % 6) * 4096 + (wave & 3) * 1024, 16, 0, 0);
         if (DSTEP > 1) __builtin_amdgcn_s_sleep(DSTEP);
       }
     }
@@ -58,7 +60,14 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
   }
   for (int it = 0; it < iters; ++it) {
     if (BARRIER) { if (NDMA && !PW) __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
-    if (READS == 2) {
+    if (READS == 3) {
+#pragma unroll
+      for (int d = 0; d < NDMA; ++d)
+        __builtin_amdgcn_global_load_lds(src + (((size_t)blockIdx.x * 8 + wave + it * 16 + d) & srcmask) * 256 + lane * 4, smem + 49152 + (d % 6) * 4096 + wave * 1024, 16, 0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    if (READS == 2 || READS == 3) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) a[0][m] = *reinterpret_cast<const u32x4*>(A0 + (it & 3) * 2048 + m * 1024);
 #pragma unroll
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
         const int m = i % 4, t = 2 * (i / 4);
         acc[m][t] = mfma(a[kw & 1][m], b[t], acc[m][t]);
         acc[m][t + 1] = mfma(a[kw & 1][m], b[t + 1], acc[m][t + 1]);
-        if (READS && !(READS == 2 && kw == 2)) {
+        if (READS && !((READS == 2 || READS == 3) && kw == 2)) {
           if (i < 4) a[(kw + 1) & 1][i] = *reinterpret_cast<const u32x4*>(A0 + ((kw + 1 + it) & 3) * 8192 / 4 + i * 1024);
           if (i >= 4 && (i % 4) < 2) {
             const int bt = 2 * (i / 4 - 1) + (i % 4);
@@ -83,8 +92,8 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
         {
           constexpr int ms = 0;  // placeholder
           const int step = kw * 16 + i - DSTART;
-          if (!PW && step >= 0 && step % DSTEP == 0 && step / DSTEP < NDMA)
-            __builtin_amdgcn_global_load_lds(src + ((blockIdx.x * 8 + wave + it * 16 + step / DSTEP) & 63) * 256 + lane * 4, smem + (RDOFF ? 0 : 65536) + ((it & 1) * 16 + step / DSTEP) * 4096 + wave * 1024, 16, 0, 0);
+          if (!PW && READS != 3 && step >= 0 && step % DSTEP == 0 && step / DSTEP < NDMA)
+            __builtin_amdgcn_global_load_lds(src + (((size_t)blockIdx.x * 8 + wave + it * 16 + step / DSTEP) & srcmask) * 256 + lane * 4, smem + (RDOFF ? 0 : 49152) + (step / DSTEP % 6) * 4096 + wave * 1024, 16, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -104,15 +113,15 @@ __global__ __launch_bounds__(WAVES * 64) void k(const unsigned* __restrict__ src
   }
 }
 
-template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART = 0, int DSTEP = 1, int PW = 0, int RDOFF = 0>
-void run(const char* name, const unsigned* src, float* out, unsigned long long* cyc, int blocks, size_t lds) {
+template <int READS, int BARRIER, int WAVES, int NDMA, int DSTART = 0, int DSTEP = 1, int PW = 0, int RDOFF = 0, int OCC = 1>
+void run(const char* name, const unsigned* src, float* out, unsigned long long* cyc, int blocks, size_t lds, size_t srcmask = 63) {
   const int iters = 4000;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF, OCC>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters, srcmask);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters);
+  hipLaunchKernelGGL((k<READS, BARRIER, WAVES, NDMA, DSTART, DSTEP, PW, RDOFF, OCC>), dim3(blocks), dim3(WAVES * 64), lds, 0, src, out, cyc, iters, srcmask);
   hipEventRecord(e1, 0);
   hipDeviceSynchronize();
   float ms = 0;
@@ -129,23 +138,26 @@ void run(const char* name, const unsigned* src, float* out, unsigned long long* 
 
 int main() {
   unsigned* src; float* out; unsigned long long* cyc;
-  hipMalloc(&src, 65536 * 4); hipMalloc(&out, 512 * 512 * 4); hipMalloc(&cyc, 512 * 8 * 2 * 8);
+  const size_t SRCW = (size_t)64 << 20;   // 256 MiB of source words: fills that miss L2
+  hipMalloc(&src, SRCW * 4); hipMalloc(&out, 1024 * 512 * 4); hipMalloc(&cyc, 1024 * 8 * 2 * 8);
   std::vector<unsigned> h(65536);
   srand(1);
   for (auto& v : h) {   // two random bf16 in [-1, 1)
     auto bf = [](float f) { unsigned u; memcpy(&u, &f, 4); return u >> 16; };
     v = bf(rand() / (float)RAND_MAX * 2 - 1) | (bf(rand() / (float)RAND_MAX * 2 - 1) << 16);
   }
-  hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  for (size_t o = 0; o < SRCW; o += h.size()) hipMemcpy(src + o, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   const size_t big = 150 * 1024;   // one block per CU, as in the conv kernel
+  const size_t hbm = (SRCW / 256) - 1;   // piece mask over the whole 256-MiB source
   run<1, 1, 4, 0>("reads ahead + barrier", src, out, cyc, 256, big);
-  run<1, 1, 4, 0, 0, 1, 0, 81920>("reads ahead + barrier, image above 64 KiB", src, out, cyc, 256, big);
   run<2, 1, 4, 0>("first tap read after the barrier", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 2, 4>("ahead + 9 DMA every 4th step from 2", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 2, 4, 0, 81920>("ahead + 9 DMA (from 2, every 4th), image above 64 KiB", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 3, 5>("ahead + 9 DMA every 5th step from 3", src, out, cyc, 256, big);
-  run<1, 1, 4, 9, 16, 2>("ahead + 9 DMA every 2nd step from 16", src, out, cyc, 256, big);
-  run<2, 1, 4, 9, 2, 4>("first tap after barrier + 9 DMA (from 2, every 4th)", src, out, cyc, 256, big);
-  run<1, 1, 8, 9, 0, 1, 1>("ahead, 4 producer waves: 9 DMA at once", src, out, cyc, 256, big);
+  run<2, 1, 4, 9, 2, 4>("product model: first tap after barrier + 9 DMA (L2 source)", src, out, cyc, 256, big);
+  run<2, 1, 4, 9, 2, 4>("product model, fills from HBM", src, out, cyc, 256, big, hbm);
+  run<1, 1, 4, 9, 2, 4>("reads ahead + 9 DMA, fills from HBM", src, out, cyc, 256, big, hbm);
+  run<3, 1, 4, 6>("single-buffered, ONE block/CU, 6 DMA burst (L2)", src, out, cyc, 256, big);
+  run<3, 1, 4, 6, 0, 1, 0, 0, 2>("single-buffered, TWO blocks/CU, 6 DMA burst (L2)", src, out, cyc, 512, 75 * 1024);
+  run<3, 1, 4, 6, 0, 1, 0, 0, 2>("single-buffered, TWO blocks/CU, 6 DMA burst (HBM)", src, out, cyc, 512, 75 * 1024, hbm);
+  run<3, 1, 4, 11, 0, 1, 0, 0, 2>("single-buffered, TWO blocks/CU, 11 DMA burst (HBM)", src, out, cyc, 512, 75 * 1024, hbm);
+  run<2, 1, 4, 9, 2, 4, 0, 0, 2>("double-buffered product model, TWO blocks/CU (L2)", src, out, cyc, 512, 75 * 1024);
   return 0;
 }
