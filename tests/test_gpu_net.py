@@ -257,6 +257,36 @@ def test_more_than_one_output_class_vs_oracle(k, h, w, dims):
         assert rel_l1(p_.grad.cpu().numpy(), first["grads"][name]) < tol, name
 
 
+@pytest.mark.parametrize("nch", [1, 4, 8])
+def test_other_input_channel_counts_vs_oracle(nch):
+    """UNet(n_channels != 3) (unet.py:61,67: DoubleConv(n_channels, ...)): the first layer has no Winograd form below 16 input
+    channels and no dX; every other count takes the same direct-tap kernels as the RGB difference image.  fp32: loss and every
+    gradient against the oracle; bf16 (the first-layer kernels fall back to im2col + dense taps when 9 C > 32): the loss within
+    the bf16 bound of the fp32 one."""
+    from oracle import unet_numpy as on
+    from gelslim_depth_amd.models.unet import UNet
+    dims = [32, 64]
+    st = synth.make_state(nch, 1, dims, 5 + nch, "conditioned")
+    x, tgt = synth.make_batch(2, 40, 52, 3, n_channels=nch)
+    net, losses, first, _ = on.train_steps(st, x, tgt, 1)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    for prec in ("fp32", "bf16"):
+        m = UNet(n_channels=nch, n_classes=1, layer_dimensions=dims, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        m = m.to("cuda")
+        m.train()
+        out = m(x=xd)
+        loss = torch.mean((out - td) ** 2)
+        loss.backward()
+        if prec == "fp32":
+            assert abs(loss.item() - losses[0]) < 2e-4 * losses[0]
+            for k, p_ in m.named_parameters():
+                assert rel_l1(p_.grad.cpu().numpy(), first["grads"][k]) < 2e-2, k
+        else:
+            assert abs(loss.item() - losses[0]) < 5e-3 * losses[0]
+            assert all(bool(torch.isfinite(p_.grad).all()) for p_ in m.parameters())
+
+
 def test_winograd_and_direct_forms_agree(monkeypatch):
     """The two forms of the fp32 conv3x3 kernels (direct taps / Winograd F(4,3) along rows) through the
     whole network on the same weights and batch.
