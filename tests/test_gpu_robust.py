@@ -103,6 +103,32 @@ def test_backward_of_a_stale_forward_raises():
         y3.sum().backward()
 
 
+def test_gradient_accumulation_over_forward_backward_pairs():
+    """What the one-node autograd function does support: accumulation over forward/backward PAIRS (the usual micro-batch loop:
+    `for mb: loss(model(mb)).backward()`, then one optimiser step).  .grad after two pairs is the bitwise sum of the two
+    gradients taken alone (autograd adds the second backward's result to .grad), on the plain module (no TrainStep arena)."""
+    from gelslim_depth_amd.models.unet import UNet
+    st = synth.make_state(3, 1, DIMS, 9, "conditioned")
+
+    def fresh():
+        m = UNet(n_channels=3, n_classes=1, layer_dimensions=DIMS)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+        return m.to("cuda").train()
+    xa, ta = synth.make_batch(2, 21, 27, 6)
+    xb, tb = synth.make_batch(2, 21, 27, 7)
+    batches = [(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()) for x, t in ((xa, ta), (xb, tb))]
+    alone = []
+    for x, t in batches:
+        m = fresh()
+        torch.mean((m(x=x) - t) ** 2).backward()
+        alone.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    m = fresh()
+    for x, t in batches:
+        torch.mean((m(x=x) - t) ** 2).backward()
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, alone[0][k] + alone[1][k]), k
+
+
 def test_target_dtype_is_cast_not_reinterpreted():
     from gelslim_depth_amd._lib import GsdError
     from gelslim_depth_amd.train import loss_fwd_bwd
