@@ -44,7 +44,7 @@ def parse_args(argv=None):
                     help="strong scaling: fixed GLOBAL batch split over the ranks (configs[3]: 64); overrides --batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the short configs[1] (batch-16 inference) and configs[4]-share (bf16 batch 32) legs at N=1")
+                    help="skip the short extra legs at N=1 (configs[1] inference, configs[3] shares at batch 16 / 8, bf16 at 16 / 32)")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -145,8 +145,9 @@ class Leg:
         st = synth.make_state(3, 1, DIMS, 0, "conditioned")            # random-init weights of the named architecture
         model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
         self.model = model.to(dev).train()
+        # the production path: GradSync(timing=False).  The collectives are timed in a short pass of their own (Leg.comm)
         self.step = TrainStep(self.model, lr=1e-3, weight_decay=1e-6, ema_decay=0.995, loss="mse", process_group=pg,
-                              sync_bn=sync_bn, time_allreduce=pg is not None)
+                              sync_bn=sync_bn)
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
         self.x = torch.rand((batch, 3, H, W), device=dev, generator=g)                  # U[0,1)  (post /255 difference image)
@@ -171,8 +172,6 @@ class Leg:
         for _ in range(warmup):
             self.one_step()
         barrier()
-        if getattr(self.step, "sync", None) is not None and self.step.sync.timing:
-            self.step.sync.pop_timing()          # the warm-up steps' collectives are not part of the timed region
         eng = self.model._engine
         # The bf16 engine runs its weight gradients on a side stream, beside the backward chain: events around a kernel of the
         # main stream then time it WITH a co-runner.  Its timed region is therefore run without the per-kernel events, and the
@@ -197,13 +196,20 @@ class Leg:
         eng.kernel_log = eng.region_log = None
         return elapsed, klog, rlog
 
-    def comm(self, steps):
-        """Gradient all-reduce time of the timed region (HIP events on a side stream that waits for RCCL's stream around every
-        bucket, gelslim_depth_amd/distributed.py): per step, and the part the compute stream had to wait for."""
+    def comm(self, barrier, steps=3):
+        """Gradient all-reduce time (HIP events on a side stream that waits for RCCL's stream around every bucket,
+        gelslim_depth_amd/distributed.py): per step, and the part the compute stream had to wait for.  Measured in `steps`
+        extra steps BEHIND the timed region with GradSync's instrumented path switched on -- the metric itself runs the
+        production path (no side-stream hop, no events)."""
         sync = getattr(self.step, "sync", None)
-        if sync is None or not sync.timing:
+        if sync is None:
             return None
+        sync.set_timing(True)
+        for _ in range(steps):
+            self.one_step()
+        barrier()
         t = sync.pop_timing()
+        sync.set_timing(False)
         n = max(1, t["steps"])
         ms = t["allreduce_ms"] / n
         return {"allreduce_ms_per_step": round(ms, 4), "exposed_ms_per_step": round(t["exposed_ms"] / n, 4),
@@ -298,7 +304,9 @@ def workload_name(dtype, workload, B):
     if dtype == "f32":
         head = "BASELINE.json configs[2]: batch-%d full train step (fwd+MSE+bwd+Adam+EMA) fp32, " % B
     else:
-        head = ("BASELINE.json configs[4] (per-GPU share): batch-%d full train step, bf16 mixed precision "
+        head = (("BASELINE.json configs[4] (per-GPU share of 128 on 8 GPUs): " if B == 16 else
+                 "bf16 mixed-precision form of configs[2] (configs[4]'s arithmetic at the metric's batch): ") +
+                "batch-%d full train step, bf16 mixed precision "
                 "(bf16 NHWC activations on bf16 MFMA, fp32 master weights/statistics/Adam), " % B)
     return head + "3x320x427 -> 1x320x427, U-Net [64,128,256,512,1024], all HIP kernels"
 
@@ -373,7 +381,7 @@ def main():
     leg = Leg(dev, rank, args.dtype, args.workload, B, pg=pg, sync_bn=args.sync_bn, graph=args.graph)
     elapsed, klog, rlog = leg.run(args.steps, args.warmup, barrier)
     loss = float(leg.step.last_loss.item())
-    elapsed, per_rank_ms, comm = over_ranks(elapsed, leg.comm(args.steps))
+    elapsed, per_rank_ms, comm = over_ranks(elapsed, leg.comm(barrier))
     hbm = leg.inc_hbm(rlog) if rank == 0 else None
     logged_steps = leg.logged_steps
 
@@ -387,7 +395,7 @@ def main():
         sb, ssteps, swarm = 64 // world, 5, 2
         lg = Leg(dev, rank, "f32", "train", sb, pg=pg, sync_bn=args.sync_bn)
         el, _, _ = lg.run(ssteps, swarm, barrier)
-        sc = lg.comm(ssteps)
+        sc = lg.comm(barrier)
         if pg is not None:
             t2 = torch.tensor([el, sc["allreduce_ms_per_step"] if sc else 0.0, sc["exposed_ms_per_step"] if sc else 0.0],
                               device=dev, dtype=torch.float64)
@@ -457,8 +465,15 @@ def main():
             # the other single-GPU configurations BASELINE.json names, a few steps each, AFTER the timed region of the metric
             leg = None
             torch.cuda.empty_cache()
-            for key, dt, wl, b in (("configs[1] batch-16 inference fp32", "f32", "infer", 16),
-                                   ("configs[4] per-GPU share: batch-32 bf16 train step", "bf16", "train", 32)):
+            # configs[3]'s strong-scaling endpoints on ONE GPU: the per-GPU share of the global batch of 64 on 4 and on 8 GPUs
+            # (16, 8) -- t(B64) / (t(B8) + ring all-reduce) bounds what 8 GPUs can give before any multi-GPU box is available;
+            # configs[4]'s per-GPU share is 128 / 8 = 16 images in bf16; the bf16 step at batch 32 is the bf16 twin of the metric
+            legs = (("configs[1] batch-16 inference fp32", "f32", "infer", 16),
+                    ("configs[3] per-GPU share on 4 GPUs: batch-16 fp32 train step", "f32", "train", 16),
+                    ("configs[3] per-GPU share on 8 GPUs: batch-8 fp32 train step", "f32", "train", 8),
+                    ("configs[4] per-GPU share: batch-16 bf16 train step", "bf16", "train", 16),
+                    ("bf16 twin of the metric: batch-32 bf16 train step", "bf16", "train", 32))
+            for key, dt, wl, b in legs:
                 lg = Leg(dev, 0, dt, wl, b)
                 el, kl, rl = lg.run(5, 2, barrier)
                 _, rf = conv_roofline(kl, dt, lg.logged_steps, el / 5 * 1e3)
@@ -475,6 +490,18 @@ def main():
                 extra[key] = e
                 del lg
                 torch.cuda.empty_cache()
+            if strong is not None:
+                # what one GPU says about the 8-GPU strong-scaling target (north star: >= 6x on batch 64): the 8-GPU step is at
+                # best t(B8) + the ring all-reduce of 124 MB over xGMI (~1.4 ms when nothing of it is overlapped)
+                t64 = strong["ms_per_step"]
+                t16 = extra["configs[3] per-GPU share on 4 GPUs: batch-16 fp32 train step"]["ms_per_step"]
+                t8 = extra["configs[3] per-GPU share on 8 GPUs: batch-8 fp32 train step"]["ms_per_step"]
+                extra["configs[3] strong-scaling bound from one GPU"] = {
+                    "t_B64_ms": t64, "t_B16_ms": t16, "t_B8_ms": t8, "assumed_ring_allreduce_ms": 1.4,
+                    "speedup_bound_4_gpus": round(t64 / (t16 + 1.4), 3), "speedup_bound_8_gpus": round(t64 / (t8 + 1.4), 3),
+                    "per_image_ms": {"B64": round(t64 / 64, 4), "B32": round(ms_per_step / 32, 4) if B == 32 else None,
+                                     "B16": round(t16 / 16, 4), "B8": round(t8 / 8, 4)},
+                    "note": "single-GPU measurements; an upper bound on the multi-GPU speedup, not a scaling measurement"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -636,7 +636,21 @@ extern "C" int gsd_convT2x2_dgrad_layout(const gsd_src* src, int Cin, int Cout, 
 
 extern "C" int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, int N,
                                   int H, int W, void* stream) {
+  return gsd_convT2x2_dgrad_as(gsd_convT2x2_dgrad_layout(src, Cin, Cout, N, H, W), src, wt, Cin, Cout, dst, N, H, W, stream);
+}
+
+// The same with the layout of `wt` stated by the caller (the mode it passed to gsd_weight_layout: 3 or 7) instead of re-derived
+// at launch: a caller that built its weight image once (the engine does, per buffer shape) cannot be handed the other kernel
+// by an environment switch or a different `slack` at launch time -- a mode the arguments do not admit is refused.
+extern "C" int gsd_convT2x2_dgrad_as(int wt_mode, const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, int N,
+                                     int H, int W, void* stream) {
   GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: null argument");
+  GSD_REQUIRE(wt_mode == 3 || wt_mode == 7, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: weight layout mode %d is neither 3 nor 7", wt_mode);
+  if (wt_mode == 7)
+    GSD_REQUIRE(!((W & 1) && src->slack < 2) && (int64_t)N * src->n_stride < (1LL << 40), GSD_ERR_BAD_ARG,
+                "gsd_convT2x2_dgrad: a mode-7 weight image needs the LDS-DMA kernel, which these arguments do not admit "
+                "(odd W = %d needs src->slack >= 2, got %d); build the image with the mode gsd_convT2x2_dgrad_layout returns",
+                W, src->slack);
   GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: bad sizes");
   if (int e = gsd_check_src(*src, "gsd_convT2x2_dgrad src")) return e;
   if (int e = gsd_check_dst(*dst, "gsd_convT2x2_dgrad dst")) return e;
@@ -647,7 +661,7 @@ extern "C" int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, 
               GSD_ERR_UNSUPPORTED, "gsd_convT2x2_dgrad: src must be 8-byte aligned with even strides");
   GSD_REQUIRE(dst->C == Cin && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
               "gsd_convT2x2_dgrad: dst must be (Cin,H,W)");
-  if (gsd_convT2x2_dgrad_layout(src, Cin, Cout, N, H, W) == 7) {
+  if (wt_mode == 7) {
     GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad: the weight image must be 16-byte aligned");
     ConvTDgParams Q;
     Q.src = to_srcd(*src);

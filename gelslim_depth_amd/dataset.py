@@ -293,6 +293,29 @@ class DeviceLoader:
             return self
         return DeviceLoader(self.dataset, self.batch_size * self.world_size, self.shuffle, self.drop_last, rank=0, world_size=1)
 
+    def eval_shares(self) -> Iterator[Tuple[Optional[Dict[str, torch.Tensor]], int, int]]:
+        """Evaluation walk of the GLOBAL batches (batch_size * world_size samples, ragged tail as DataLoader(drop_last=False)
+        leaves it): yields (batch, valid, global_count) per global batch, where `batch` holds this rank's contiguous share of
+        it -- samples [rank*batch_size, (rank+1)*batch_size) of the global batch, NO wrap-around padding -- or None when the
+        ragged tail leaves this rank nothing.  A short share is padded up to batch_size by repeating its last sample, so every
+        forward keeps the per-rank train shape (no activation buffer is reallocated); only the first `valid` samples count.
+        harness.evaluate_loader sums per-sample losses over them and all-reduces (sum, count) per global batch: every rank
+        gets the single-process value without evaluating the whole set."""
+        perm = self.order().to(self.dataset.device)
+        n, bs, per = perm.numel(), self.batch_size, self.batch_size * self.world_size
+        for s in range(0, n, per):
+            g = perm[s:s + per]
+            if g.numel() < per and self.drop_last:
+                break
+            mine = g[self.rank * bs:(self.rank + 1) * bs]
+            valid = int(mine.numel())
+            if valid == 0:
+                yield None, 0, int(g.numel())
+                continue
+            if valid < bs:
+                mine = torch.cat([mine, mine[-1:].expand(bs - valid)])
+            yield self.dataset.batch(mine), valid, int(g.numel())
+
     def order(self) -> torch.Tensor:
         n = len(self.dataset)
         if not self.shuffle:

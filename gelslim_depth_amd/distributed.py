@@ -55,10 +55,19 @@ class GradSync:
         self.force = force or bool(os.environ.get("GSD_FORCE_SYNC"))   # exercise the collectives with one rank
         self._works: List = []
         self._done: List[str] = []
-        self.timing = bool(timing) and g_flat.is_cuda
-        self._side = torch.cuda.Stream(device=g_flat.device) if self.timing else None
+        self.timing = False
+        self._side = None
         self._ev: List[Tuple[str, int, torch.cuda.Event, torch.cuda.Event]] = []     # (tag, bytes, start, end) on the side stream
         self._exposed: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []          # compute stream: around the final wait
+        self.set_timing(timing)
+
+    def set_timing(self, on: bool) -> None:
+        """Switch the instrumented path on or off between steps (bench.py times the metric on the production path and the
+        collectives in a short pass of their own behind it)."""
+        self.timing = bool(on) and self.g.is_cuda
+        if self.timing and self._side is None:
+            self._side = torch.cuda.Stream(device=self.g.device)
+        self._ev, self._exposed = [], []
 
     def _reduce(self, tag: str, lo: int, hi: int) -> None:
         if not self.timing:

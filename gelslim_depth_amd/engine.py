@@ -456,7 +456,7 @@ class UNetEngine:
                                          self.wgrad_ws.numel(), n, hi, wi, st), "convT2x2_wgrad")
             check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
-            check(lib.gsd_convT2x2_dgrad(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
+            check(lib.gsd_convT2x2_dgrad_as(up.mode_d, C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
                   "convT2x2_dgrad")
             self._reduce(0, prev, st)
             if self.block_done_cb is not None:

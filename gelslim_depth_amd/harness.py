@@ -61,23 +61,46 @@ def _mean_loss(losses: List[float], n_batches: int) -> float:
 
 
 def evaluate_loader(step, loader: Iterable[Dict], loss_kind: str = "mse") -> float:
-    """Mean over the loader's batches of the loss under the EMA weights, NaN batches counted as 0 (train_unet.py:379-419)."""
+    """Mean over the loader's batches of the loss under the EMA weights, NaN batches counted as 0 (train_unet.py:379-419).
+
+    Data parallel (a `DeviceLoader` with world_size > 1): the walk is over the GLOBAL batches, every rank evaluates only its
+    contiguous share of each at the per-rank train shape (`DeviceLoader.eval_shares`: no wrap-around padding, no activation
+    buffer reallocated, nothing evaluated twice), and ONE all-reduce at the end of the pass sums (loss sum, element count) per
+    global batch -- every rank then holds the single-process value of every batch loss, bit for bit the same on all ranks.
+    The batch losses stay on the device until the pass ends (one host sync per pass; the reference syncs per batch)."""
     import torch
     from .train import loss_fwd_bwd
-    vals = []
-    nb = 0
+    sharded = getattr(loader, "world_size", 1) > 1 and hasattr(loader, "eval_shares")
     buf = ws = None
-    for data in loader:
+    rows = []          # per (global) batch: device tensor [loss sum over this rank's valid elements, their count]
+    dev = None
+    walk = loader.eval_shares() if sharded else ((data, None, None) for data in loader)
+    for data, valid, _ in walk:
+        if data is None:                  # the ragged tail left this rank nothing of this global batch
+            rows.append(None)
+            continue
         x, t = data["tactile_image"], data["depth_image"]
         out = step.evaluate(x, use_ema=True)
         if buf is None:
-            buf = torch.zeros((1,), device=out.device, dtype=torch.float32)
-            ws = torch.empty((2048,), device=out.device, dtype=torch.float64)
-        loss_fwd_bwd(loss_kind, out, t.float().contiguous(), None, buf, ws)
-        v = float(buf.item())
-        vals.append(0.0 if v != v else v)
-        nb += 1
-    return _mean_loss(vals, nb)
+            dev = out.device
+            buf = torch.zeros((1,), device=dev, dtype=torch.float32)
+            ws = torch.empty((2048,), device=dev, dtype=torch.float64)
+        t = t.float().contiguous()
+        if valid is not None and valid < out.shape[0]:
+            out, t = out[:valid], t[:valid]       # leading-dimension slices stay contiguous: the padding is not scored
+        loss_fwd_bwd(loss_kind, out, t, None, buf, ws)
+        cnt = float(out.numel())
+        rows.append(torch.stack([buf[0].double() * cnt, torch.tensor(cnt, device=dev, dtype=torch.float64)]))
+    if not rows:
+        return 0.0
+    if dev is None:
+        dev = getattr(getattr(step, "p_flat", None), "device", None) or torch.device("cpu")
+    zero = torch.zeros((2,), device=dev, dtype=torch.float64)
+    tab = torch.stack([r if r is not None else zero for r in rows])
+    if sharded:
+        step.dist.all_reduce(tab, group=step.pg)
+    vals = (tab[:, 0] / tab[:, 1]).cpu().tolist()
+    return _mean_loss([0.0 if v != v else v for v in vals], len(vals))
 
 
 def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_name: str, loss_values_path: Optional[str] = None,
@@ -93,8 +116,9 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
     Data parallel (a build-side addition, the reference is single-process): every rank runs the same epochs on its shard
     of each batch; the epoch losses are averaged over the ranks (`step.mean_across_ranks`) so that all ranks take the
     same stopping and checkpoint decisions, and only rank 0 writes checkpoints, the log file and the echo.  Validation and
-    test passes run UNSHARDED on every rank (`DeviceLoader.unsharded()`): they issue no collective, every rank gets the
-    single-process value, and the wrap-around padding of a sharded loader cannot bias the loss early stopping reads."""
+    test passes walk the GLOBAL batches with every rank scoring its own share (`evaluate_loader`): the value is the
+    single-process one (no wrap-around padding in the loss early stopping reads), identical on every rank, at the per-rank
+    train shape; `across()` of it is then the identity up to the last bit."""
     if train_pass is None:
         from .dataset import train_epoch as train_pass
     if eval_pass is None:
@@ -102,8 +126,6 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
     if save is None:
         def save(st, path):
             st.save_checkpoint(path, use_ema=True)
-    val_loader = val_loader.unsharded() if hasattr(val_loader, "unsharded") else val_loader
-    test_loader = test_loader.unsharded() if hasattr(test_loader, "unsharded") else test_loader
     H: Dict[str, List[float]] = {"train_loss": [], "validation_loss": [], "test_loss": []}
     stopper = EarlyStopping(val_loss_SMA_window, validation_loss_count_threshold, train_indefinitely)
     is_main = getattr(step, "rank", 0) == 0

@@ -195,6 +195,11 @@ class UNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("gelslim_depth_amd.UNet runs on an MI355X through libgsd; move the model and the input "
                                "to the GPU (there is no CPU path in this package)")
+        if x.requires_grad and torch.is_grad_enabled():
+            # the reference module is differentiable w.r.t. its input (unet.py:79-88); nothing in the reference asks for that
+            # gradient (train_unet.py:344-347) and the first convolution's dX is not built: say so instead of returning None
+            raise NotImplementedError("gelslim_depth_amd.UNet does not compute the gradient with respect to its input "
+                                      "(x.requires_grad is set); detach x, or use the reference model for input gradients")
         x = x.float()
         if self.training and torch.is_grad_enabled():
             return _UNetFunction.apply(self, x, *self.parameters())

@@ -147,6 +147,12 @@ class TrainStep:
                 b.data = self.bn_flat[o:o + b.numel()].view(b.shape)
                 o += b.numel()
             self.bn_snap = torch.empty_like(self.bn_flat)
+        # A later model.to(...) / .float() / .half() re-allocates the module's tensors and silently detaches them from the arenas
+        # (the kernels would go on updating arenas nobody reads; the guard's snapshot would cover stale memory): remember where
+        # every parameter and arena-backed buffer must live and check it at every step (a host-side pointer compare).
+        self._pinned = [(n, p, p.data_ptr()) for n, p in model.named_parameters()]
+        if self.bn_flat is not None:
+            self._pinned += [(n, b, b.data_ptr()) for n, b in model.named_buffers() if b.dtype == torch.float32]
         self._dout = None
         self._out = None
         eng = model._engine
@@ -163,9 +169,18 @@ class TrainStep:
             self.sync = GradSync(self.g_flat, make_buckets(names, self.offsets, eng.L), group=self.pg,
                                  overlap=overlap_allreduce, force=force_sync, timing=time_allreduce)
 
+    def _check_arenas(self) -> None:
+        for n, t, ptr in self._pinned:
+            if t.data_ptr() != ptr or t.dtype != torch.float32:
+                raise L.GsdError(
+                    f"TrainStep: '{n}' no longer lives in the step's flat arena (the model was moved or cast -- model.to(...), "
+                    ".float(), .half(), load with assign=True -- after TrainStep was built).  Move / cast the model first, then "
+                    "construct TrainStep; load_state_dict() and in-place updates keep the arenas.")
+
     def __call__(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         model = self.model
         eng = model._engine
+        self._check_arenas()
         x = x.contiguous()
         target = target.float().contiguous()     # the kernels read raw fp32 (a float64 / uint8 depth target is cast, as _LossFn does)
         if not target.is_cuda:

@@ -163,6 +163,11 @@ int gsd_convT2x2(const gsd_src* src, const float* wt, const float* bias, int Cin
 int gsd_convT2x2_dgrad_layout(const gsd_src* src, int Cin, int Cout, int N, int H, int W);
 int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout,
                        const gsd_dst* dst, int N, int H, int W, void* stream);
+/* The same with the layout mode of `wt` (3 or 7) STATED by the caller instead of re-derived at launch: a caller that lays its
+ * weights out once per buffer shape cannot be handed the other kernel by GSD_CONVT_DG_DMA or a different `slack` at launch
+ * time; a mode the arguments do not admit is refused with GSD_ERR_BAD_ARG. */
+int gsd_convT2x2_dgrad_as(int wt_mode, const gsd_src* src, const float* wt, int Cin, int Cout,
+                          const gsd_dst* dst, int N, int H, int W, void* stream);
 
 /* dW of conv3x3: dW[co][ci][kh][kw] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1].
  * `a` is given as up to two segments with deferred BN (recomputed on load), `dy` plain.

@@ -11,13 +11,27 @@ python3 - "$f" <<'PY' > gpurun_out/${tag}_pmc.txt
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 seen = set()
+def kname(n):
+    # kernel name with its template arguments, without return type and parameter list (a 60-character cut used to merge
+    # or hide template variants)
+    n = n.strip()
+    if n.startswith('void '):
+        n = n[5:]
+    d = 0
+    for i, ch in enumerate(n):
+        d += ch == '<'
+        d -= ch == '>'
+        if ch == '(' and d == 0:
+            n = n[:i]
+            break
+    return n[:160]
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r['Kernel_Name'][:60]
+    k = kname(r['Kernel_Name'])
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
     key = (r['Dispatch_Id'], k)
     if key not in seen:
         seen.add(key); cnt[k] += 1
-for k, n in cnt.most_common(20):
+for k, n in cnt.most_common():
     print(k, "dispatches", n)
     for c, v in sorted(agg[k].items()):
         print("    %-32s total %.4g  per-dispatch %.4g" % (c, v, v / n))

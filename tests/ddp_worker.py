@@ -1,6 +1,7 @@
 """Worker for tests/test_gpu_ddp.py: one rank of a 2-rank data-parallel fused train step.
-Both ranks use cuda:0 (the GPU box has one card) and the gloo backend; the production backend is
-"nccl" (RCCL), which needs one GPU per rank.  Writes its results to <outdir>/rank<r>.npz."""
+On a node with at least WORLD_SIZE GPUs every rank takes cuda:LOCAL_RANK and the production backend "nccl" (RCCL over xGMI);
+on the one-card GPU box both ranks share cuda:0 over gloo (RCCL refuses two ranks on one device).  Same assertions either
+way.  GSD_DDP_BACKEND=gloo forces the shared-card form.  Writes its results to <outdir>/rank<r>.npz."""
 import os
 import sys
 
@@ -12,12 +13,33 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+class _TensorSet:
+    """What DeviceLoader needs from a DeviceDataset, over two resident tensors."""
+
+    def __init__(self, x, t):
+        self.x, self.t, self.device = x, t, x.device
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def batch(self, idx):
+        return {"tactile_image": self.x[idx], "depth_image": self.t[idx], "object_index": idx}
+
+
 def main():
-    outdir, mode = sys.argv[1], sys.argv[2]          # mode: "local_bn" | "sync_bn"
+    outdir, mode = sys.argv[1], sys.argv[2]          # mode: "local_bn" | "sync_bn" | "eval"
     precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    use_rccl = torch.cuda.device_count() >= world and os.environ.get("GSD_DDP_BACKEND", "nccl") == "nccl"
+    dev = torch.device("cuda", local if use_rccl else 0)
+    torch.cuda.set_device(dev)
+    if use_rccl:
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from gelslim_depth_amd import synth
     from gelslim_depth_amd.models.unet import UNet
     from gelslim_depth_amd.train import TrainStep
@@ -30,12 +52,27 @@ def main():
     xs, ts = x[rank * per:(rank + 1) * per], t[rank * per:(rank + 1) * per]
     m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision=precision)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
-    m = m.to("cuda:0").train()
+    m = m.to(dev).train()
     step = TrainStep(m, process_group=dist.group.WORLD, sync_bn=(mode == "sync_bn"), overlap_allreduce=True)
+    if mode == "eval":
+        # validation pass under data parallelism (harness.evaluate_loader): 7 samples, batch 2 per rank -> global batches of
+        # 4 and 3 (rank 1 scores ONE sample of the tail); 5 samples -> 4 and 1 (rank 1 gets nothing of the tail)
+        from gelslim_depth_amd import harness
+        from gelslim_depth_amd.dataset import DeviceLoader
+        out = {"backend": dist.get_backend()}
+        for n in (7, 5, 8):
+            xe, te = synth.make_batch(n, 37, 53, 9)
+            ds = _TensorSet(torch.from_numpy(xe).to(dev), torch.from_numpy(te).to(dev))
+            out[f"val{n}"] = harness.evaluate_loader(step, DeviceLoader(ds, batch_size=2, rank=rank, world_size=world))
+            out[f"shape{n}"] = np.array(m._engine._shape[:3])
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     p0 = step.p_flat.cpu().numpy().copy()
-    loss = step(torch.from_numpy(xs).cuda(), torch.from_numpy(ts).cuda()).item()
+    loss = step(torch.from_numpy(xs).to(dev), torch.from_numpy(ts).to(dev)).item()
     torch.cuda.synchronize()
-    out = {"loss": loss, "p0": p0, "g_sum": step.g_flat.cpu().numpy(), "p1": step.p_flat.cpu().numpy()}
+    out = {"backend": dist.get_backend(), "loss": loss, "p0": p0, "g_sum": step.g_flat.cpu().numpy(), "p1": step.p_flat.cpu().numpy()}
     for k, v in m.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             out["buf/" + k] = v.cpu().numpy()

@@ -205,3 +205,52 @@ def test_bf16_full_size_eval_vs_reference_golden():
         out = m(x=torch.from_numpy(x).cuda()).cpu().numpy()
     assert out.shape == (1, 1, 320, 427)
     assert rel_l1(out, g["y_eval"]) < 2e-2, rel_l1(out, g["y_eval"])
+
+
+def _bf16_step_state(dims, monkeypatch, env, steps=2, n=3, h=37, w=53):
+    from gelslim_depth_amd.train import TrainStep
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    st = synth.make_state(3, 1, dims, 11, "conditioned")
+    x, t = synth.make_batch(n, h, w, 3)
+    m = _model(dims, st, "bf16").train()
+    step = TrainStep(m)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    losses = [float(step(xd, td)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    bufs = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    eng = m._engine
+    for k in env:
+        monkeypatch.delenv(k)
+    return eng, losses, step.g_flat.clone(), step.p_flat.clone(), bufs
+
+
+@pytest.mark.parametrize("dims", [[32, 64, 128], [64, 128]])
+def test_bf16_side_stream_weight_gradients_change_nothing(dims, monkeypatch):
+    """GSD_BF16_SIDE_DW (default on) moves the weight-gradient launches to a side stream; every kernel is deterministic, so a
+    missing stream dependency is the only way the two schedules can differ: gradients, parameters and BatchNorm buffers after
+    two steps must be bit-equal."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_SIDE_DW": "0"})
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_SIDE_DW": "1"})
+    assert not e0.side_dw and e1.side_dw
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
+
+
+@pytest.mark.parametrize("dims,direct", [([32, 64, 128], True), ([64, 128], True), ([96, 192], False)])
+def test_bf16_first_layer_direct_kernels_match_the_im2col_path(dims, direct, monkeypatch):
+    """GSD_BF16_FIRST=0 forces the first layer through im2col + the dense-tap kernels; the direct kernels (default where
+    gsd_bf16_conv3x3_first_supported: dims[0] in {32, 64}) run the same products through the same MFMA: forward bit-identical
+    (same loss at step one), first-layer dW equal up to the summation order.  dims[0] = 96 is a shape the direct kernels do
+    not serve: both settings must then take the im2col path."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "0"}, steps=1)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "1"}, steps=1)
+    assert not e0.first_direct and e1.first_direct == direct
+    assert l0 == l1
+    assert all(torch.equal(b0[k], b1[k]) for k in b0), "same forward, same statistics"
+    if not direct:
+        assert torch.equal(g0, g1)
+        return
+    nw = dims[0] * 27                          # inc.double_conv.0.weight is the arena's first tensor
+    assert rel_l1(g1[:nw].cpu().numpy(), g0[:nw].cpu().numpy()) < 2e-5
+    assert torch.equal(g0[nw:], g1[nw:]), "everything behind the first layer's dW is untouched"

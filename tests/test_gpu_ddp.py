@@ -23,7 +23,11 @@ def run_two_ranks(tmp_path, mode, precision="fp32", size="small"):
            "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode, precision, size]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
+    res = [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
+    import torch
+    want = "nccl" if (torch.cuda.device_count() >= 2 and os.environ.get("GSD_DDP_BACKEND", "nccl") == "nccl") else "gloo"
+    assert all(str(r["backend"]) == want for r in res), "two GPUs or more: the ranks must have met over RCCL"
+    return res
 
 
 def oracle_flat(grads, names):
@@ -179,3 +183,30 @@ def test_two_rank_full_size_step_is_the_sum_of_its_shards(tmp_path):
         torch.cuda.empty_cache()
     assert np.array_equal(res[0]["g_sum"], shards[0] + shards[1])
     assert res[0]["g_sum"].size == 31037633
+
+
+def test_two_rank_validation_pass_is_the_single_process_value(tmp_path):
+    """harness.evaluate_loader under data parallelism: every rank scores its own share of each GLOBAL batch at the per-rank train
+    shape (ragged tails: a short share, an empty share) and one all-reduce of (loss sum, count) per batch gives both ranks
+    the value ONE process gets from the unsharded loader -- the same float on both ranks."""
+    import torch
+    from gelslim_depth_amd import harness
+    from gelslim_depth_amd.dataset import DeviceLoader
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    from ddp_worker import _TensorSet
+    res = run_two_ranks(tmp_path, "eval")
+    dims = [16, 32, 64]
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st0.items()}, strict=True)
+    m = m.to("cuda").train()
+    step = TrainStep(m)
+    for n in (7, 5, 8):
+        xe, te = synth.make_batch(n, 37, 53, 9)
+        ds = _TensorSet(torch.from_numpy(xe).cuda(), torch.from_numpy(te).cuda())
+        one = harness.evaluate_loader(step, DeviceLoader(ds, batch_size=4))        # the global batches in one process
+        assert float(res[0][f"val{n}"]) == float(res[1][f"val{n}"]), "every rank takes the same early-stopping decision"
+        assert abs(float(res[0][f"val{n}"]) - one) <= 2e-6 * abs(one), (n, float(res[0][f"val{n}"]), one)
+        for r in range(2):
+            assert tuple(res[r][f"shape{n}"]) == (2, 37, 53), "evaluation keeps the per-rank train shape"

@@ -226,6 +226,19 @@ def test_convT_fwd_bwd(gsd, monkeypatch, n, ci, h, w):
     monkeypatch.delenv("GSD_CONVT_DG_DMA")
     if w % 2:      # an odd width without slack falls back to the register-staged kernel instead of reading past the tensor
         assert gsd.lib.gsd_convT2x2_dgrad_layout(C.byref(sdy), ci, co, n, h, w) == 3
+        # ... and a caller that STATES a mode-7 image for such arguments is refused, not handed the other kernel's layout
+        dx = torch.zeros((n, ci, h, w), device="cuda")
+        rc = gsd.lib.gsd_convT2x2_dgrad_as(7, C.byref(sdy), layout(gsd, 7, wd, co, ci).data_ptr(), ci, co, C.byref(gsd.make_dst(dx)),
+                                           n, h, w, gsd.stream_ptr())
+        assert rc != 0 and "mode-7" in gsd.lib.gsd_last_error().decode()
+    # the stated-mode entry runs either kernel on demand, whatever the environment says (the engine lays its image out once)
+    monkeypatch.setenv("GSD_CONVT_DG_DMA", "0")
+    for mode in (7, 3):
+        dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_convT2x2_dgrad_as(mode, C.byref(gsd.make_src(dys, slack=gsd.SLACK)), layout(gsd, mode, wd, co, ci).data_ptr(),
+                                                ci, co, C.byref(gsd.make_dst(dx)), n, h, w, gsd.stream_ptr()))
+        assert rel_l1(dx.cpu().numpy(), dxr) < TOL, mode
+    monkeypatch.delenv("GSD_CONVT_DG_DMA")
     need = gsd.lib.gsd_convT2x2_wgrad_workspace(n, h, w, ci, co)
     ws = torch.zeros(need, device="cuda")
     dw = torch.full((ci, co, 2, 2), float("nan"), device="cuda")

@@ -298,3 +298,32 @@ def test_skipped_step_leaves_no_trace_in_any_running_statistic(precision):
     assert step.skipped_steps() == 1 and bool(torch.isfinite(step.p_flat).all())
     rm = m.state_dict()["inc.double_conv.1.running_mean"]
     assert not torch.equal(rm, before["inc.double_conv.1.running_mean"])          # a healthy step moves them again
+
+
+def test_input_gradient_request_raises_instead_of_returning_none():
+    """The reference module is differentiable w.r.t. its input (unet.py:79-88); libgsd builds no dX for the first convolution
+    (nothing in the reference asks for it, train_unet.py:344-347): asking must raise, not hand back a silent None."""
+    m, _ = make()
+    x, _ = synth.make_batch(2, 21, 27, 6)
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="gradient with respect to its input"):
+        m(x=xd)
+    with torch.no_grad():
+        m(x=xd)                                    # no graph asked for: fine
+    m(x=xd.detach()).sum().backward()
+
+
+@pytest.mark.parametrize("nan_policy", [None, "skip"])
+def test_moving_the_model_after_trainstep_raises(nan_policy):
+    """TrainStep re-points the module's parameters (and, with a nan_policy, its BatchNorm buffers) at flat arenas; a later
+    model.to(...) / .double().float() re-allocates them and would leave the kernels updating arenas nobody reads."""
+    from gelslim_depth_amd._lib import GsdError
+    m, step = make(nan_policy=nan_policy)
+    x, t = synth.make_batch(2, 21, 27, 6)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    step(xd, td)
+    m.load_state_dict(m.state_dict())              # in place: the arenas stay
+    step(xd, td)
+    m.double().float()                             # re-allocates every tensor
+    with pytest.raises(GsdError, match="no longer lives in the step's flat arena"):
+        step(xd, td)
