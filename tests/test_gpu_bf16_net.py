@@ -207,13 +207,16 @@ def test_bf16_full_size_eval_vs_reference_golden():
     assert rel_l1(out, g["y_eval"]) < 2e-2, rel_l1(out, g["y_eval"])
 
 
-def _bf16_step_state(dims, monkeypatch, env, steps=2, n=3, h=37, w=53):
+def _bf16_step_state(dims, monkeypatch, env, steps=2, n=3, h=37, w=53, cin=3):
+    from gelslim_depth_amd.models.unet import UNet
     from gelslim_depth_amd.train import TrainStep
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    st = synth.make_state(3, 1, dims, 11, "conditioned")
-    x, t = synth.make_batch(n, h, w, 3)
-    m = _model(dims, st, "bf16").train()
+    st = synth.make_state(cin, 1, dims, 11, "conditioned")
+    x, t = synth.make_batch(n, h, w, 3, n_channels=cin)
+    m = UNet(n_channels=cin, n_classes=1, layer_dimensions=dims, precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st.items()}, strict=True)
+    m = m.to("cuda").train()
     step = TrainStep(m)
     xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
     losses = [float(step(xd, td)) for _ in range(steps)]
@@ -237,20 +240,20 @@ def test_bf16_side_stream_weight_gradients_change_nothing(dims, monkeypatch):
     assert all(torch.equal(b0[k], b1[k]) for k in b0)
 
 
-@pytest.mark.parametrize("dims,direct", [([32, 64, 128], True), ([64, 128], True), ([96, 192], False)])
-def test_bf16_first_layer_direct_kernels_match_the_im2col_path(dims, direct, monkeypatch):
+@pytest.mark.parametrize("dims,cin,direct", [([32, 64, 128], 3, True), ([64, 128], 3, True), ([64, 128], 1, True), ([32, 64], 4, False)])
+def test_bf16_first_layer_direct_kernels_match_the_im2col_path(dims, cin, direct, monkeypatch):
     """GSD_BF16_FIRST=0 forces the first layer through im2col + the dense-tap kernels; the direct kernels (default where
-    gsd_bf16_conv3x3_first_supported: dims[0] in {32, 64}) run the same products through the same MFMA: forward bit-identical
-    (same loss at step one), first-layer dW equal up to the summation order.  dims[0] = 96 is a shape the direct kernels do
-    not serve: both settings must then take the im2col path."""
-    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "0"}, steps=1)
-    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "1"}, steps=1)
+    gsd_bf16_conv3x3_first_supported: 9 * n_channels <= 32) run the same products through the same MFMA: forward bit-identical
+    (same loss at step one), first-layer dW equal up to the summation order.  Four input channels (K = 36) is a shape the direct
+    kernels do not serve: both settings must then take the im2col path."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "0"}, steps=1, cin=cin)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FIRST": "1"}, steps=1, cin=cin)
     assert not e0.first_direct and e1.first_direct == direct
     assert l0 == l1
     assert all(torch.equal(b0[k], b1[k]) for k in b0), "same forward, same statistics"
     if not direct:
         assert torch.equal(g0, g1)
         return
-    nw = dims[0] * 27                          # inc.double_conv.0.weight is the arena's first tensor
+    nw = dims[0] * 9 * cin                     # inc.double_conv.0.weight is the arena's first tensor
     assert rel_l1(g1[:nw].cpu().numpy(), g0[:nw].cpu().numpy()) < 2e-5
     assert torch.equal(g0[nw:], g1[nw:]), "everything behind the first layer's dW is untouched"
