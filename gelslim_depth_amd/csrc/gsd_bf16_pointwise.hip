@@ -140,6 +140,49 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(NhwcD y, const float* __r
   st16(a.p + p * a.pitch + gk * 8, pack8(f));
 }
 
+// ---- a = relu(y * scale + shift) AND pooled = MaxPool2d(2)(a) in one pass (unet.py:15-16 followed by :26) ---------------
+// The encoder's second unit feeds a max-pool: the stand-alone pool re-reads the activation the apply pass has just written.
+// Thread = one 2x2 window x 8 channels over the ceil(H/2) x ceil(W/2) window grid: it reads the window's four raw values,
+// writes their four activations (into the concat buffer's skip slice) and, where the window is whole (floor mode drops an
+// odd last row / column), their maximum.  Rounding to bf16 is monotonic, so max of the rounded activations == rounded max:
+// bit-identical to gsd_bf16_bn_apply + gsd_bf16_maxpool2.
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(NhwcD y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            NhwcD a, NhwcD o, int wh, int ww) {
+  const int groups = y.C >> 3;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)y.N * wh * ww * groups) return;
+  const int gk = (int)(e % groups);
+  const long long p = e / groups;
+  const int wp = (int)(p % ww);
+  const int hp = (int)((p / ww) % wh);
+  const int n = (int)(p / ((long long)ww * wh));
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + gk * 8), s1 = *reinterpret_cast<const f32x4*>(scale + gk * 8 + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + gk * 8), h1 = *reinterpret_cast<const f32x4*>(shift + gk * 8 + 4);
+  const bool col2 = 2 * wp + 1 < y.W, row2 = 2 * hp + 1 < y.H;
+  const long long pix = ((long long)n * y.H + 2 * hp) * y.W + 2 * wp;
+  uint4 raw[4];
+  raw[0] = ld16(y.p + pix * y.pitch + gk * 8);
+  raw[1] = col2 ? ld16(y.p + (pix + 1) * y.pitch + gk * 8) : raw[0];
+  raw[2] = row2 ? ld16(y.p + (pix + y.W) * y.pitch + gk * 8) : raw[0];
+  raw[3] = (row2 && col2) ? ld16(y.p + (pix + y.W + 1) * y.pitch + gk * 8) : raw[0];
+  float m[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float f[8];
+    unpack8(raw[q], f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[i] = fmaxf(fmaf(f[i], s0[i], h0[i]), 0.f);
+      f[4 + i] = fmaxf(fmaf(f[4 + i], s1[i], h1[i]), 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = q == 0 ? f[i] : fmaxf(m[i], f[i]);
+    const bool ok = (q == 0) || (q == 1 && col2) || (q == 2 && row2) || (q == 3 && row2 && col2);
+    if (ok) st16(a.p + (pix + (q >> 1) * y.W + (q & 1)) * a.pitch + gk * 8, pack8(f));
+  }
+  if (row2 && col2) st16(o.p + (((long long)n * o.H + hp) * o.W + wp) * o.pitch + gk * 8, pack8(m));
+}
+
 // ---- MaxPool2d(2), floor mode (unet.py:26) --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2_bf16_kernel(NhwcD a, NhwcD o) {
   const int groups = a.C >> 3;
@@ -545,6 +588,22 @@ extern "C" int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const fl
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
                      scale, shift, to_nhwc(*a), relu, np);
   GSD_LAUNCH_CHECK("gsd_bf16_bn_apply");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
+                                      const gsd_nhwc* pooled, void* stream) {
+  if (int e = check_c8(y, "gsd_bf16_bn_apply_pool y")) return e;
+  if (int e = check_c8(a, "gsd_bf16_bn_apply_pool a")) return e;
+  if (int e = check_c8(pooled, "gsd_bf16_bn_apply_pool pooled")) return e;
+  GSD_REQUIRE(scale && shift && same_extent(y, a), GSD_ERR_BAD_ARG, "gsd_bf16_bn_apply_pool: bad argument");
+  GSD_REQUIRE(y->H > 1 && y->W > 1 && pooled->N == y->N && pooled->C == y->C && pooled->H == y->H / 2 && pooled->W == y->W / 2,
+              GSD_ERR_BAD_ARG, "gsd_bf16_bn_apply_pool: pooled must be (N,H/2,W/2,C)");
+  const int wh = (y->H + 1) / 2, ww = (y->W + 1) / 2;
+  const long long total = (long long)y->N * wh * ww * (y->C / 8);
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
+                     scale, shift, to_nhwc(*a), to_nhwc(*pooled), wh, ww);
+  GSD_LAUNCH_CHECK("gsd_bf16_bn_apply_pool");
   return GSD_OK;
 }
 

@@ -171,6 +171,8 @@ class UNetEngineBF16:
         # it, and it is MFMA-bound while the backward chain it leaves behind alternates with HBM-bound BatchNorm passes (20 % of
         # the bf16 step): the two overlap where neither fills the chip.  Own split-K workspace; joined before a block's
         # gradients are handed to the all-reduce and at the end of backward.  GSD_BF16_SIDE_DW=0: everything on one stream.
+        # BatchNorm apply + max-pool of the encoder's skip units in one pass (gsd_bf16_bn_apply_pool); GSD_BF16_APPLY_POOL=0: two
+        self.apply_pool = os.environ.get("GSD_BF16_APPLY_POOL", "1") != "0"
         self.side_dw = train and os.environ.get("GSD_BF16_SIDE_DW", "1") != "0"
         self.side = torch.cuda.Stream(device=dev) if self.side_dw else None
         self.wspace_side = torch.empty((max(max_ws, 64),), **f32) if self.side_dw else None
@@ -226,7 +228,9 @@ class UNetEngineBF16:
             self.kernel_log.append((name, flops, e0, e1, None))
         return close
 
-    def _run_unit(self, u: _Unit, src: Tuple[torch.Tensor, int, int], P, train: bool, st: int) -> None:
+    def _run_unit(self, u: _Unit, src: Tuple[torch.Tensor, int, int], P, train: bool, st: int,
+                  pool_to: Optional[torch.Tensor] = None) -> None:
+        """pool_to (train mode): the unit's activation feeds a max-pool -- BatchNorm apply and the pool are one pass over y."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         u.src = src
         din = L.make_nhwc(*src) if src[0] is not None else None     # the first layer's direct kernels read x itself
@@ -290,7 +294,12 @@ class UNetEngineBF16:
                                       self.guard, st),
                   "bn_finalize")
         self._nbt.append(P[u.nbtname])   # int64 counters: one libgsd launch for all of them at the end of the forward
-        check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
+        if pool_to is not None:
+            dp = L.make_nhwc(pool_to)
+            check(lib.gsd_bf16_bn_apply_pool(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), C.byref(dp), st),
+                  "bn_apply_pool")
+        else:
+            check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], train: bool, out: Optional[torch.Tensor] = None
@@ -319,11 +328,13 @@ class UNetEngineBF16:
                 src = (None, 0, 0) if self.first_direct else (self.col0, 0, self.col0.shape[3])
             else:
                 prev = self.enc[lvl - 1][1]
-                dp = L.make_nhwc(self.pooled[lvl])
-                check(lib.gsd_bf16_maxpool2(C.byref(prev.a), C.byref(dp), st), "maxpool2")
+                if not (train and self.apply_pool):     # (train mode: the pool rode in the previous unit's BatchNorm apply)
+                    dp = L.make_nhwc(self.pooled[lvl])
+                    check(lib.gsd_bf16_maxpool2(C.byref(prev.a), C.byref(dp), st), "maxpool2")
                 src = (self.pooled[lvl], 0, prev.cout)
             self._run_unit(u0, src, P, train, st)
-            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st)
+            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st,
+                           pool_to=self.pooled[lvl + 1] if (train and self.apply_pool and lvl < self.L) else None)
         if self.L == 0:
             self._region_end("inc_forward", region)
         cur = self.enc[self.L][1]

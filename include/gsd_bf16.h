@@ -113,6 +113,13 @@ int gsd_bf16_im2col3x3(const float* x, int N, int C, int H, int W, const gsd_nhw
  * by gsd_bn_finalize / gsd_bn_eval_coeffs) + ReLU (unet.py:12-13,15-16). `a` may be a channel slice of a concat buffer. */
 int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a, int relu, void* stream);
 
+/* The two above in one pass where a unit's activation feeds a max-pool (the encoder's skip units, unet.py:15-16 then :26):
+ * a = relu(y*scale+shift) is written (into the concat buffer's skip slice) AND pooled = MaxPool2d(2)(a), floor mode, from the
+ * same read of y -- the stand-alone pool's re-read of the activation disappears.  Bit-identical to gsd_bf16_bn_apply(relu=1)
+ * followed by gsd_bf16_maxpool2. */
+int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
+                           const gsd_nhwc* pooled, void* stream);
+
 /* MaxPool2d(2), floor mode (unet.py:26). */
 int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream);
 

@@ -326,6 +326,36 @@ def test_pointwise_forward_bf16():
     assert float((out.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("h,w", [(11, 15), (12, 16), (2, 3), (7, 8), (20, 27)])
+def test_bn_apply_pool_is_apply_then_pool_bf16(h, w):
+    """gsd_bf16_bn_apply_pool (BatchNorm apply + ReLU + MaxPool2d(2) from one read of y) == gsd_bf16_bn_apply followed by
+    gsd_bf16_maxpool2, bit for bit, on odd and even sizes (floor mode drops the odd last row / column), writing the activation
+    into a channel slice of a wider (concat) buffer and touching nothing else of it."""
+    L = _lib()
+    g = torch.Generator().manual_seed(40 + h)
+    n, c = 3, 40
+    y = bf16r(torch.randn((n, c, h, w), generator=g))
+    scale, shift = torch.rand((c,), generator=g) + 0.5, torch.randn((c,), generator=g)
+    ybuf = to_nhwc(y)
+    sc_d, sh_d = scale.cuda(), shift.cuda()
+    res = []
+    for fused in (False, True):
+        cat = torch.full((n, h, w, c + 24), 7.0, dtype=torch.bfloat16, device="cuda")
+        pooled = torch.full((n, h // 2, w // 2, c), -3.0, dtype=torch.bfloat16, device="cuda")
+        dy_, da_, dp_ = L.make_nhwc(ybuf), L.make_nhwc(cat, 0, c), L.make_nhwc(pooled)
+        if fused:
+            L.check(L.lib.gsd_bf16_bn_apply_pool(C.byref(dy_), sc_d.data_ptr(), sh_d.data_ptr(), C.byref(da_), C.byref(dp_),
+                                                 L.stream_ptr()), "bn_apply_pool")
+        else:
+            L.check(L.lib.gsd_bf16_bn_apply(C.byref(dy_), sc_d.data_ptr(), sh_d.data_ptr(), C.byref(da_), 1, L.stream_ptr()), "bn_apply")
+            L.check(L.lib.gsd_bf16_maxpool2(C.byref(da_), C.byref(dp_), L.stream_ptr()), "maxpool")
+        torch.cuda.synchronize()
+        res.append((cat.clone(), pooled.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[1][0][..., c:].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(from_nhwc(res[1][1], 0, c), F.max_pool2d(from_nhwc(res[1][0], 0, c), 2))
+
+
 @pytest.mark.parametrize("mode,h,w", [(0, 13, 18), (1, 13, 18), (1, 12, 17), (1, 9, 11), (1, 8, 10), (2, 13, 18)])
 def test_bn_bwd_bf16(mode, h, w):
     """Pass 1 (mask, pooled-gradient routing, output-conv gradient, per-channel sums) and pass 2 against torch fp64."""

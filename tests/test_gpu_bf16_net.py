@@ -261,3 +261,14 @@ def test_bf16_first_layer_direct_kernels_match_the_im2col_path(dims, cin, direct
     nw = dims[0] * 9 * cin                     # inc.double_conv.0.weight is the arena's first tensor
     assert rel_l1(g1[:nw].cpu().numpy(), g0[:nw].cpu().numpy()) < 2e-2
     assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.999
+
+
+def test_bf16_apply_pool_fusion_changes_nothing(monkeypatch):
+    """GSD_BF16_APPLY_POOL (default on): the encoder's skip units write their activation and its max-pool from one read of the
+    raw output; bit-identical to the two separate passes, so two train steps agree bit for bit."""
+    dims = [32, 64, 128]
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_APPLY_POOL": "0"})
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_APPLY_POOL": "1"})
+    assert not e0.apply_pool and e1.apply_pool
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
