@@ -129,6 +129,11 @@ class UNetEngineBF16:
         self.first_direct = bool(lib.gsd_bf16_conv3x3_first_supported(self.n_channels, self.dims[0])) and \
             os.environ.get("GSD_BF16_FIRST", "1") != "0"
         self.col0 = None if self.first_direct else torch.empty((n, h, w, _r32(9 * self.n_channels)), **bf)
+        # train mode: the `inc` double convolution without its first convolution's raw output in HBM (gsd_bf16_inc.hip: statistics
+        # from a write-free pass over x, the 64 -> 64 kernel rebuilds relu(bn(conv(x))) per halo tile, the backward recomputes the
+        # raw output from x); GSD_BF16_FUSED_INC=0: the four unfused launches
+        self.fused_inc = self.first_direct and bool(lib.gsd_bf16_inc_supported(self.n_channels, self.dims[0])) and \
+            os.environ.get("GSD_BF16_FUSED_INC", "1") != "0"
         # concat buffers (zeroed once: the F.pad border of the `up` slice is never written again)
         self.cat = [torch.zeros((n, hs[l], ws[l], self.dims[l] + self.dims[l + 1] // 2), **bf) for l in range(self.L)]
         self.gcat = [torch.empty_like(c) for c in self.cat] if train else [None] * self.L
@@ -150,6 +155,8 @@ class UNetEngineBF16:
             direct = u.first and self.first_direct
             rows = lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout) if direct else lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)
             max_part = max(max_part, rows * 2 * mp)
+            if self.fused_inc and u is self.enc[0][1]:
+                max_part = max(max_part, lib.gsd_bf16_inc_conv_partial_rows(n, lh, lw) * 2 * mp)
             if train:
                 max_part = max(max_part, lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw) * 3 * u.cout)
                 if direct:
@@ -277,7 +284,35 @@ class UNetEngineBF16:
             done()
         rows = (lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout) if (u.first and self.first_direct)
                 else lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout))
-        count = float(n * lh * lw)
+        self._finalize_stats(u, rows, float(n * lh * lw), P, st)
+        self._apply(u, dy, st, pool_to)
+
+    def _run_inc_fused(self, u0: _Unit, u1: _Unit, P, st: int, pool_to: Optional[torch.Tensor]) -> None:
+        """Train-mode `inc` (unet.py:7-20, :67) without u0's raw output: statistics of conv(x) from a write-free pass, then ONE
+        kernel that rebuilds relu(bn(conv(x))) per halo tile, writes it once (u1's dW reads it) and runs the 64 -> 64
+        convolution on it from LDS (gsd_bf16_inc.hip)."""
+        n, lh, lw = u1.y.shape[0], self.hs[0], self.ws[0]
+        x = self._x
+        u0.src, u1.src = (None, 0, 0), (u0.a_t, u0.a_off, u0.cout)
+        part = self.partials.data_ptr()
+        self._wimage(2, P[u0.wname], u0.cout, u0.cin, u0.wt_f, st)
+        self._wimage(0, P[u1.wname], u1.cout, u1.cin, u1.wt_f, st)
+        done = self._log("bf16_conv_first", 2.0 * u0.cout * 9 * u0.cin * n * lh * lw)
+        check(lib.gsd_bf16_conv3x3_first(x.data_ptr(), n, u0.cin, lh, lw, u0.wt_f.data_ptr(), None, u0.cout, part, None, None, st),
+              "conv3x3_first (statistics)")
+        done()
+        self._finalize_stats(u0, lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u0.cout), float(n * lh * lw), P, st)
+        dy1 = L.make_nhwc(u1.y)
+        done = self._log("bf16_inc_fused", 2.0 * u1.cout * (u1.cin + u0.cin) * 9 * n * lh * lw)
+        check(lib.gsd_bf16_inc_conv(x.data_ptr(), n, u0.cin, lh, lw, u0.wt_f.data_ptr(), u0.scale.data_ptr(), u0.shift.data_ptr(),
+                                    u1.wt_f.data_ptr(), C.byref(u0.a), C.byref(dy1), part, st), "inc_conv")
+        done()
+        self._finalize_stats(u1, lib.gsd_bf16_inc_conv_partial_rows(n, lh, lw), float(n * lh * lw), P, st)
+        self._apply(u1, dy1, st, pool_to)
+
+    def _finalize_stats(self, u: _Unit, rows: int, count: float, P, st: int) -> None:
+        """self.partials holds `rows` BatchNorm partial rows of unit u's raw output: batch statistics -> (mean, invstd, scale,
+        shift), running statistics, the batch counter."""
         if self.sync_fn is None:     # a few hundred partial rows: column sums and finalize in ONE launch
             check(lib.gsd_bn_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout), u.cout, u.sums.data_ptr(),
                                              count, P[u.gname].data_ptr(), P[u.bname].data_ptr(), BN_EPS, BN_MOMENTUM,
@@ -294,6 +329,8 @@ class UNetEngineBF16:
                                       self.guard, st),
                   "bn_finalize")
         self._nbt.append(P[u.nbtname])   # int64 counters: one libgsd launch for all of them at the end of the forward
+
+    def _apply(self, u: _Unit, dy, st: int, pool_to: Optional[torch.Tensor]) -> None:
         if pool_to is not None:
             dp = L.make_nhwc(pool_to)
             check(lib.gsd_bf16_bn_apply_pool(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), C.byref(dp), st),
@@ -332,9 +369,12 @@ class UNetEngineBF16:
                     dp = L.make_nhwc(self.pooled[lvl])
                     check(lib.gsd_bf16_maxpool2(C.byref(prev.a), C.byref(dp), st), "maxpool2")
                 src = (self.pooled[lvl], 0, prev.cout)
+            pool_to = self.pooled[lvl + 1] if (train and self.apply_pool and lvl < self.L) else None
+            if lvl == 0 and train and self.fused_inc:
+                self._run_inc_fused(u0, u1, P, st, pool_to)
+                continue
             self._run_unit(u0, src, P, train, st)
-            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st,
-                           pool_to=self.pooled[lvl + 1] if (train and self.apply_pool and lvl < self.L) else None)
+            self._run_unit(u1, (u0.a_t, u0.a_off, u0.cout), P, train, st, pool_to=pool_to)
         if self.L == 0:
             self._region_end("inc_forward", region)
         cur = self.enc[self.L][1]
@@ -374,12 +414,21 @@ class UNetEngineBF16:
                                          u.invstd.data_ptr(), C.byref(gsrc), C.byref(u.a), C.byref(dp), L.ptr(dout), L.ptr(wout),
                                          C.byref(dz), self.partials.data_ptr(), st), "bn_bwd_reduce")
 
-    def _tail(self, u: _Unit, G, st: int, dwout: Optional[torch.Tensor] = None, fused: bool = False) -> None:
+    def _tail(self, u: _Unit, G, st: int, dwout: Optional[torch.Tensor] = None, fused: bool = False, recompute: bool = False) -> None:
         """u.g holds dz and self.partials its sums: finish BatchNorm backward (dgamma, dbeta, dy in place), then dW.
-        fused: the sums come from a dX launch's epilogue (conv partial layout) instead of gsd_bf16_bn_bwd_reduce."""
+        fused: the sums come from a dX launch's epilogue (conv partial layout) instead of gsd_bf16_bn_bwd_reduce.
+        recompute (the fused `inc`'s first unit): u.g holds da, the gradient w.r.t. the unit's ACTIVATION, and its raw output
+        does not exist: pass 1 and dW recompute it from x (gsd_bf16_first_bn_bwd_reduce, gsd_bf16_wgrad_first_recompute)."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         count = float(n * lh * lw)
         rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout) if fused else lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
+        if recompute:
+            fused = True
+            rows = lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout)
+            da = L.make_nhwc(u.g)
+            check(lib.gsd_bf16_first_bn_bwd_reduce(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(da), u.scale.data_ptr(),
+                                                   u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(), self.partials.data_ptr(), st),
+                  "first_bn_bwd_reduce")
         dw_ptr = None if dwout is None else dwout.data_ptr()
         if self.sync_fn is None:
             check(lib.gsd_bn_bwd_reduce_finalize(self.partials.data_ptr(), rows, lib.gsd_bf16_conv_mpad(u.cout) if fused else 0, u.cout,
@@ -398,6 +447,16 @@ class UNetEngineBF16:
             check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), gsum.data_ptr(), u.cout, count, G[u.gname].data_ptr(),
                                           G[u.bname].data_ptr(), dw_ptr, u.c1.data_ptr(), u.c2.data_ptr(), st), "bn_bwd_finalize")
         dz, dy = L.make_nhwc(u.g), L.make_nhwc(u.y)
+        if recompute:
+            def launch(sst, ws):
+                done = self._log("bf16_wgrad", 2.0 * u.cout * 9 * u.cin * n * lh * lw)
+                check(lib.gsd_bf16_wgrad_first_recompute(self._x.data_ptr(), n, u.cin, lh, lw, u.wt_f.data_ptr(), C.byref(dz),
+                                                         u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
+                                                         u.c1.data_ptr(), u.c2.data_ptr(), G[u.wname].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         sst), "wgrad_first_recompute")
+                done()
+            self._on_side(launch)
+            return
         if u.first and self.first_direct:
             # no dX for the first layer, so dW is d_raw's only reader: it forms d_raw from (dz, y) itself -- no apply pass, no im2col
             def launch(sst, ws):
@@ -576,8 +635,9 @@ class UNetEngineBF16:
                 self._reduce(1, u1, st, g=gskip, dpool=self.dpooled[lvl + 1])
             self._tail(u1, G, st, dwout, fused=prev_fused is u1)
             dwout = None
-            self._dgrad(u1, P, u0.g, st, fuse=u0)
-            self._tail(u0, G, st, fused=True)
+            inc = lvl == 0 and self.fused_inc      # u0's raw output was never stored: no pass 1 in the dX epilogue
+            self._dgrad(u1, P, u0.g, st, fuse=None if inc else u0)
+            self._tail(u0, G, st, fused=True, recompute=inc)
             if self.block_done_cb is not None:
                 self._join_side()
                 self.block_done_cb(f"enc{lvl}")

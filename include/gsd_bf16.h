@@ -90,7 +90,7 @@ int gsd_bf16_weight_images(const gsd_bf16_wimg_job* jobs, int n, void* stream);
  * straight from x -- the layer is bound by the HBM write of its output (K = 27 is one MFMA k-step), and the im2col tensor
  * costs more traffic than the input.  Bit-identical to gsd_bf16_im2col3x3 + gsd_bf16_conv_dense.  partials (train): BatchNorm
  * partial sums, gsd_bf16_conv3x3_first_partial_rows rows of 2*gsd_bf16_conv_mpad(M) floats; ep_scale/ep_shift (eval): out =
- * relu(acc*scale+shift) instead of the raw output.
+ * relu(acc*scale+shift) instead of the raw output.  out == NULL (with partials): the statistics only, nothing is stored.
  * gsd_bf16_wgrad_first: dW (M,C,3,3) fp32 of the same layer from x and the gradient of its output.  With y != NULL the
  * BatchNorm backward of the layer's output is applied on the fly -- d_raw = scale*(dz - c1 - (y-mean)*invstd*c2), rounded to
  * bf16 exactly as gsd_bf16_bn_bwd_apply stores it: the first layer has no dX, so dW is d_raw's only reader and the apply
@@ -104,6 +104,37 @@ int64_t gsd_bf16_wgrad_first_workspace(int N, int H, int W, int M);
 int gsd_bf16_wgrad_first(const float* x, int N, int C, int H, int W, const gsd_nhwc* dz, const gsd_nhwc* y,
                          const float* scale, const float* mean, const float* invstd, const float* c1, const float* c2,
                          float* dw, float* workspace, int64_t workspace_elems, void* stream);
+
+/* ---- the `inc` double convolution in train mode without the raw output of its first convolution ------------------------
+ * (unet.py:7-20 for `inc`, :67: 3 -> 64 -> 64 at full resolution -- the north star's "320x427 double-conv kernel".)
+ * Unfused, the block writes the first convolution's raw output y0, reads it back to write a0 = relu(bn(y0)), and reads a0
+ * again (with halo overlap) in the 64 -> 64 convolution: 2.5x its algorithmic bytes.  Fused:
+ *   1. gsd_bf16_conv3x3_first(x, ..., out = NULL, partials): the statistics of y0 from a write-free pass over x (same kernel,
+ *      same partial rows as the storing form); gsd_bn_reduce_finalize turns them into (scale0, shift0, mean0, invstd0).
+ *   2. gsd_bf16_inc_conv: per pixel tile, a0 is rebuilt over the tile's halo from x (one MFMA k-step per 16 pixels), rounded
+ *      exactly as the two unfused passes round it, staged in LDS as the operand of the 64 -> 64 convolution, whose weights
+ *      (wt1: weight image mode 0) stay resident in LDS.  Writes a0 once (the second layer's dW reads it in backward), y1
+ *      (raw output of the second convolution) and y1's BatchNorm partial sums: gsd_bf16_inc_conv_partial_rows rows of
+ *      2*gsd_bf16_conv_mpad(64) floats (gsd_bn_reduce_partials / gsd_bn_reduce_finalize from gsd.h).  a0 and y1 are bit-identical
+ *      to gsd_bf16_conv3x3_first + gsd_bf16_bn_apply(relu) + gsd_bf16_conv3x3 under the same (scale0, shift0).
+ *   3. backward of the first layer, y0 recomputed from x the same way:
+ *      gsd_bf16_first_bn_bwd_reduce: pass 1 of its BatchNorm+ReLU backward from da (the gradient w.r.t. a0, as the second
+ *        layer's plain dX launch leaves it): partials = [sum dz | sum dz*xhat] with dz = da where y0*scale+shift > 0, in the
+ *        layout of the forward statistics (gsd_bf16_conv3x3_first_partial_rows rows); nothing is written back.
+ *      gsd_bf16_wgrad_first_recompute: gsd_bf16_wgrad_first with (da, wt) in place of (dz, y): the mask, xhat and
+ *        d_raw = scale*(dz - c1 - xhat*c2) are formed from the recomputed y0 -- the same d_raw values, bit for bit.
+ * Supported: 9*C <= 32 and 64 channels (gsd_bf16_inc_supported); the first-layer pieces also serve M = 32. */
+int gsd_bf16_inc_supported(int C, int M);
+int gsd_bf16_inc_conv_partial_rows(int N, int H, int W);
+int gsd_bf16_inc_conv(const float* x, int N, int C, int H, int W, const void* wt0, const float* scale0, const float* shift0,
+                      const void* wt1, const gsd_nhwc* a0, const gsd_nhwc* y1, float* partials, void* stream);
+int gsd_bf16_first_bn_bwd_reduce(const float* x, int N, int C, int H, int W, const void* wt, const gsd_nhwc* da,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 float* partials, void* stream);
+int gsd_bf16_wgrad_first_recompute(const float* x, int N, int C, int H, int W, const void* wt, const gsd_nhwc* da,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   const float* c1, const float* c2, float* dw, float* workspace, int64_t workspace_elems,
+                                   void* stream);
 
 /* First layer: x (N,C,H,W) fp32 NCHW -> col (N,H,W,round_up(9C,32)) bf16 with col[..,c*9+t] = x[n,c,h+t/3-1,w+t%3-1]
  * (zero padded), so that conv3x3(x) is a 1x1 convolution of col (gsd_bf16_conv_dense). unet.py:11 for `inc`. */

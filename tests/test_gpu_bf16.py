@@ -592,3 +592,101 @@ def test_first_layer_direct_kernels_bf16(n, c, h, w, m):
     assert float((dw2.cpu() - old).abs().max()) <= 2e-5 * scale_ref
     assert L.lib.gsd_bf16_wgrad_first(x_d.data_ptr(), n, c, h, w, C.byref(ddz), C.byref(d1), *[v.data_ptr() for v in vd],
                                       dw.data_ptr(), ws.data_ptr(), need - 1, L.stream_ptr()) == -4
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 19, 70), (1, 3, 8, 64), (3, 3, 21, 27), (2, 1, 33, 130), (1, 2, 5, 3), (2, 3, 40, 427)])
+def test_inc_block_fused_equals_its_unfused_kernels_bf16(n, c, h, w):
+    """The `inc` double convolution without the first convolution's raw output in HBM (gsd_bf16_inc.hip; unet.py:7-20, :67)
+    against the four unfused launches it replaces, fed the same statistics:
+      * gsd_bf16_conv3x3_first(out = NULL): the same BatchNorm partial rows as the storing form, bit for bit;
+      * gsd_bf16_inc_conv: a0 and y1 bit-identical to conv3x3_first -> bn_apply(relu) -> conv3x3 (tiles cut by the image edge,
+        images narrower than a tile, a halo that crosses the image border on every side), y1's partial sums equal to the sums
+        of the stored values;
+      * gsd_bf16_first_bn_bwd_reduce: [sum dz | sum dz*xhat] of the masked gradient against fp64 on the stored y0;
+      * gsd_bf16_wgrad_first_recompute: dW bit-identical to gsd_bf16_wgrad_first on (masked dz, stored y0)."""
+    L = _lib()
+    m = 64
+    g = torch.Generator().manual_seed(7 * n + h + w)
+    assert L.lib.gsd_bf16_inc_supported(c, m) == 1 and L.lib.gsd_bf16_inc_supported(c, 32) == 0 and L.lib.gsd_bf16_inc_supported(4, m) == 0
+    x = torch.rand((n, c, h, w), generator=g)
+    w0 = torch.randn((m, c, 3, 3), generator=g) * 0.3
+    w1 = torch.randn((m, m, 3, 3), generator=g) * 0.05
+    x_d, w0_d, w1_d = x.cuda(), w0.cuda(), w1.cuda()
+    img0 = torch.zeros(L.lib.gsd_bf16_weight_image_size(2, m, c), dtype=torch.bfloat16, device="cuda")
+    img1 = torch.zeros(L.lib.gsd_bf16_weight_image_size(0, m, m), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.gsd_bf16_weight_image(2, w0_d.data_ptr(), m, c, img0.data_ptr(), L.stream_ptr()), "wimg0")
+    L.check(L.lib.gsd_bf16_weight_image(0, w1_d.data_ptr(), m, m, img1.data_ptr(), L.stream_ptr()), "wimg1")
+    mp = L.lib.gsd_bf16_conv_mpad(m)
+    # ---- unfused forward
+    y0 = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    rows0 = L.lib.gsd_bf16_conv3x3_first_partial_rows(n, h, w, m)
+    part0 = torch.full((rows0, 2 * mp), float("nan"), device="cuda")
+    dy0 = L.make_nhwc(y0)
+    L.check(L.lib.gsd_bf16_conv3x3_first(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), C.byref(dy0), m, part0.data_ptr(), None, None,
+                                         L.stream_ptr()), "first")
+    part0s = torch.full((rows0, 2 * mp), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_conv3x3_first(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), None, m, part0s.data_ptr(), None, None,
+                                         L.stream_ptr()), "first, statistics only")
+    assert torch.equal(part0[:, :m], part0s[:, :m]) and torch.equal(part0[:, mp:mp + m], part0s[:, mp:mp + m])
+    assert L.lib.gsd_bf16_conv3x3_first(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), None, m, None, None, None, L.stream_ptr()) != 0
+    yv = y0.double()
+    cnt = n * h * w
+    mean = (yv.sum(dim=(0, 1, 2)) / cnt)
+    var = (yv * yv).sum(dim=(0, 1, 2)) / cnt - mean * mean
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma, beta = (torch.rand(m, generator=g) + 0.5).double().cuda(), (torch.randn(m, generator=g) * 0.3).double().cuda()
+    scale, shift = (gamma * invstd).float(), (beta - mean * gamma * invstd).float()
+    mean_f, invstd_f = mean.float(), invstd.float()
+    cat = torch.full((n, h, w, m + 32), 7.0, dtype=torch.bfloat16, device="cuda")       # a0 as a channel slice of a wider buffer
+    da_ref = L.make_nhwc(cat, 0, m)
+    L.check(L.lib.gsd_bf16_bn_apply(C.byref(dy0), scale.data_ptr(), shift.data_ptr(), C.byref(da_ref), 1, L.stream_ptr()), "apply")
+    y1_ref = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    rows1 = L.lib.gsd_bf16_conv_partial_rows(n, h, w, m)
+    part1 = torch.zeros((rows1, 2 * mp), device="cuda")
+    dy1r = L.make_nhwc(y1_ref)
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(da_ref), img1.data_ptr(), C.byref(dy1r), m, m, part1.data_ptr(), None, L.stream_ptr()), "conv3x3")
+    # ---- fused forward
+    cat2 = torch.full((n, h, w, m + 32), 7.0, dtype=torch.bfloat16, device="cuda")
+    y1 = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rowsf = L.lib.gsd_bf16_inc_conv_partial_rows(n, h, w)
+    partf = torch.full((rowsf, 2 * mp), float("nan"), device="cuda")
+    da2, dy1 = L.make_nhwc(cat2, 0, m), L.make_nhwc(y1)
+    L.check(L.lib.gsd_bf16_inc_conv(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), scale.data_ptr(), shift.data_ptr(), img1.data_ptr(),
+                                    C.byref(da2), C.byref(dy1), partf.data_ptr(), L.stream_ptr()), "inc_conv")
+    torch.cuda.synchronize()
+    assert torch.equal(cat.view(torch.int16), cat2.view(torch.int16)), "a0 (and the untouched rest of the buffer)"
+    assert torch.equal(y1_ref.view(torch.int16), y1.view(torch.int16)), "y1"
+    sf = partf.double().sum(0)
+    y1v = y1.double()
+    np.testing.assert_allclose(sf[:m].cpu().numpy(), y1v.sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sf[mp:mp + m].cpu().numpy(), (y1v * y1v).sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # ---- backward of the first layer without y0
+    da = bf16r(torch.randn((n, m, h, w), generator=g))
+    da_d = to_nhwc(da)
+    dda = L.make_nhwc(da_d)
+    partb = torch.full((rows0, 2 * mp), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_first_bn_bwd_reduce(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), C.byref(dda), scale.data_ptr(), shift.data_ptr(),
+                                               mean_f.data_ptr(), invstd_f.data_ptr(), partb.data_ptr(), L.stream_ptr()), "first_bn_bwd_reduce")
+    y0f = y0.float()
+    mask = (y0f.double() * scale.double() + shift.double()) > 0     # the sign of fma(y, scale, shift): exact in fp64
+    dz = torch.where(mask, da_d.float(), torch.zeros((), device="cuda"))
+    xhat = (y0f - mean_f) * invstd_f
+    sb = partb.double().sum(0)
+    s1_ref, s2_ref = dz.double().sum(dim=(0, 1, 2)), (dz.double() * xhat.double()).sum(dim=(0, 1, 2))
+    tol1 = 1e-5 * float(dz.double().abs().sum(dim=(0, 1, 2)).max()) + 1e-6
+    assert float((sb[:m] - s1_ref).abs().max()) <= tol1
+    assert float((sb[mp:mp + m] - s2_ref).abs().max()) <= 1e-5 * float((dz.double() * xhat.double()).abs().sum(dim=(0, 1, 2)).max()) + 1e-6
+    c1, c2 = (torch.randn(m, generator=g) * 0.1).cuda(), (torch.randn(m, generator=g) * 0.1).cuda()
+    need = L.lib.gsd_bf16_wgrad_first_workspace(n, h, w, m)
+    ws = torch.zeros(need, device="cuda")
+    dz_d = dz.to(torch.bfloat16).contiguous()
+    ddz = L.make_nhwc(dz_d)
+    dw_ref = torch.full((m, c, 3, 3), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_wgrad_first(x_d.data_ptr(), n, c, h, w, C.byref(ddz), C.byref(dy0), scale.data_ptr(), mean_f.data_ptr(),
+                                       invstd_f.data_ptr(), c1.data_ptr(), c2.data_ptr(), dw_ref.data_ptr(), ws.data_ptr(), need,
+                                       L.stream_ptr()), "wgrad_first")
+    dw = torch.full((m, c, 3, 3), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_wgrad_first_recompute(x_d.data_ptr(), n, c, h, w, img0.data_ptr(), C.byref(dda), scale.data_ptr(),
+                                                 shift.data_ptr(), mean_f.data_ptr(), invstd_f.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+                                                 dw.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "wgrad_first_recompute")
+    assert bool(torch.isfinite(dw).all()) and torch.equal(dw, dw_ref)

@@ -92,7 +92,18 @@ def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
             y_ref = torch.einsum("nkhw,mk->nmhw", a_in.double(), wcol.double())
         else:
             y_ref = F.conv2d(a_in.double(), wq.double(), padding=1)
-        y = _nchw(u.y)
+        fused0 = bool(getattr(eng, "fused_inc", False)) and u is eng.enc[0][0]
+        if fused0:
+            # the fused `inc` block never stores this unit's raw output (gsd_bf16_inc.hip rebuilds it tile by tile, the backward
+            # recomputes it): run the storing form of the same kernel on the same x and weight image to look at it
+            import ctypes as C
+            from gelslim_depth_amd import _lib as GL
+            ybuf = torch.empty_like(u.y)
+            GL.check(GL.lib.gsd_bf16_conv3x3_first(eng._x.data_ptr(), xt.shape[0], u.cin, xt.shape[2], xt.shape[3], u.wt_f.data_ptr(),
+                                                   C.byref(GL.make_nhwc(ybuf)), u.cout, None, None, None, GL.stream_ptr()), "first")
+            y = _nchw(ybuf)
+        else:
+            y = _nchw(u.y)
         _ulp_close(y, y_ref, f"{u.wname} forward")
         mean, var = y.double().mean(dim=(0, 2, 3)), y.double().var(dim=(0, 2, 3), unbiased=False)
         assert torch.allclose(u.mean.cpu().double(), mean, rtol=1e-4, atol=1e-5), u.gname
@@ -101,6 +112,8 @@ def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
         _ulp_close(_nchw(u.a_t, u.a_off, u.cout), a_ref, f"{u.gname} apply")
         # backward: u.g holds dy (gradient w.r.t. the raw conv output) after the step
         dy = _nchw(u.g)
+        if fused0:        # u.g holds da, the gradient w.r.t. the ACTIVATION (the second unit's plain dX): pass 1's mask is a > 0
+            dy = dy * (_nchw(u.a_t, u.a_off, u.cout) > 0)
         if u.first and u.src[0] is None:
             # gsd_bf16_wgrad_first applies the BatchNorm backward itself: u.g still holds dz, and d_raw -- rounded to bf16 as the
             # apply pass would have stored it -- exists only inside that kernel
@@ -272,3 +285,21 @@ def test_bf16_apply_pool_fusion_changes_nothing(monkeypatch):
     assert not e0.apply_pool and e1.apply_pool
     assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
     assert all(torch.equal(b0[k], b1[k]) for k in b0)
+
+
+@pytest.mark.parametrize("dims,n,h,w", [([64, 128], 3, 37, 53), ([64, 128, 256], 2, 40, 130), ([64], 2, 21, 70)])
+def test_bf16_fused_inc_block_tracks_the_unfused_step(dims, n, h, w, monkeypatch):
+    """GSD_BF16_FUSED_INC (default on where gsd_bf16_inc_supported): the `inc` double convolution without its first raw output in
+    HBM.  The first unit's statistics come from the same kernel with the store switched off (bit-equal running statistics), the
+    rebuilt activation and the second convolution's raw output are bit-identical given those; only the summation order of the
+    second unit's statistics (another grid) differs, so from there on the step agrees like two orders of one sum."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FUSED_INC": "0"}, steps=1, n=n, h=h, w=w)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FUSED_INC": "1"}, steps=1, n=n, h=h, w=w)
+    assert not e0.fused_inc and e1.fused_inc
+    for k in ("inc.double_conv.1.running_mean", "inc.double_conv.1.running_var"):
+        assert torch.equal(b0[k], b1[k]), k
+    assert abs(l0[0] - l1[0]) <= 1e-4 * abs(l0[0])
+    for k in b0:
+        assert rel_l1(b1[k].cpu().numpy(), b0[k].cpu().numpy()) < 2e-3, k
+    assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
+    assert not _model([32, 64], synth.make_state(3, 1, [32, 64], 1, "conditioned"), "bf16")._engine.__dict__.get("fused_inc", False)
