@@ -30,6 +30,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+// ReLU of two packed bf16 values: as 16-bit integers a bf16 is negative exactly when its sign bit is set, so a packed signed
+// max with 0 clears the negative ones (and turns -0 into +0, as fmaxf(x, 0) does); one instruction for two values
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned v) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0});
+  return __builtin_bit_cast(unsigned, r);
+}
+
 struct NhwcD {
   u16* p;
   long long pitch;
