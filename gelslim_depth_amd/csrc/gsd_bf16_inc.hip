@@ -19,6 +19,20 @@
 // Same products in the same order through the same MFMA as the unfused kernels: a0 and y1 are bit-identical to
 // gsd_bf16_conv3x3_first + gsd_bf16_bn_apply + gsd_bf16_conv3x3 given the same statistics.
 //
+// What bounds it (in-kernel stamps and ablation builds at batch 32, profiles/r04_inc_*.txt): the K loop is 0.20 ms of the
+// kernel's 0.46-0.48 (18.8 cycles per MFMA and SIMD against the instruction's 16); the rest is VECTOR work -- rebuild ~150
+// instructions per 16 halo pixels, epilogue ~250 per wave tile -- and the stores (0.09 ms).  Forms measured on the way:
+//   * 4 waves, one per SIMD, as the DMA-filled kernel runs: 0.54 ms.  A lone wave issues a vector instruction every ~4 cycles
+//     (MI355X_MICROARCH.md 'vector-instruction ISSUE cost'): rebuild 12.0k + K loop 10.9k + epilogue 5.4k cycles per tile.
+//   * 8 waves in the same phase (this file): rebuild 8.5k + K loop 10.8k + epilogue 4.6k.
+//   * 8 waves as two groups half a tile out of phase, so that every SIMD hosts a matrix wave beside a vector wave
+//     (profiles/ubench/gsd_bf16_inc_paired.hip, bit-identical): 0.62-0.71 ms.  The vector phase is the longer one, and beside
+//     a matrix wave a vector wave runs at a third of its rate (an MFMA holds the SIMD's issue port 8 cycles of 16; its own 4
+//     MFMAs per 16 pixels queue behind the partner's): 11-12k cycles per half-step against 5.7-7.2k for the K loop.  Along the
+//     way: a lane constant set up at kernel entry and spilled around the loop costs an HBM round trip per tile -- the reload's
+//     `s_waitcnt vmcnt(0)` in front of the K loop waits for the x prefetch issued just before it (K loop 10.5k -> 5.7k cycles
+//     once the constants were recomputed in place behind an opaque asm).
+//
 // LDS image of the activation tile: [chunk of 32 channels][halo pixel q = r*66 + c][64 B], 16-byte piece p of pixel (r, c) at
 // slot p ^ (2 * ((c >> 2) & 1)): with that swizzle the ds_read_b128 of a B operand (16 consecutive pixels x one piece, lanes
 // grouped as the hardware groups them) is bank-conflict free for EVERY tap shift without the 32 B of padding per pixel the
