@@ -317,3 +317,125 @@ def test_winograd_and_direct_forms_agree(monkeypatch):
     dev = {k: rel_l1(res["1"][1][k], res["0"][1][k]) for k in res["0"][1]}
     assert dev["up.2.conv.double_conv.3.weight"] < 2e-4, dev["up.2.conv.double_conv.3.weight"]
     assert max(dev.values()) < 5e-2, max(dev.values())
+
+
+@pytest.mark.parametrize("dims,h,w", [([64, 128, 256, 512, 1024], 320, 427), ([16, 32, 64], 37, 53)])
+def test_backward_teacher_forced_unit_by_unit(dims, h, w):
+    """The whole-network gradient bounds above (2e-2 / 3e-2) rest on the argument that a ReLU / max-pool network amplifies
+    last-bit differences; this test replaces the argument by a measurement at BASELINE's size (one 3x320x427 image through
+    [64..1024]): every unit of the backward pass is checked TIGHTLY against the oracle fed with the HIP path's OWN upstream
+    tensors (teacher forcing), so no error can hide behind another unit's amplification:
+      forward   raw conv output of every unit vs oracle conv3x3 on the HIP path's input activation (1e-5), BatchNorm statistics;
+      BatchNorm backward  d_gamma = sum dz*xhat, d_beta = sum dz from the HIP path's dz (1e-5 of their scale);
+      conv dW   vs oracle on (HIP input activation, d_raw rebuilt from the HIP dz)                       (5e-5);
+      conv dX   the gradient every producer received (dz of the unit below incl. its ReLU mask, the max-pool routing into the
+                skip units, the pooled-gradient buffers, the cropped slice handed to the transposed convolution) vs the
+                oracle's dX of the HIP d_raw                                                             (1e-5);
+      ConvTranspose2d dW / db / dX and the output conv likewise.
+    References: unet.py:7-57 (units), :39-49 (pad / cat), torch autograd's reverse sweep of train_unet.py:374."""
+    from gelslim_depth_amd.train import mse_loss
+    from oracle import unet_numpy as on
+    st = synth.make_state(3, 1, dims, 21, "conditioned")
+    x, tgt = synth.make_batch(1, h, w, 22)
+    m = make_model(dims, st).train()
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    out = m(x=xd)
+    loss = mse_loss(input=out, target=td)
+    loss.backward()
+    torch.cuda.synchronize()
+    eng = m._engine
+    G = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+    npy = lambda t: t.detach().cpu().numpy()          # noqa: E731
+    L_ = len(dims) - 1
+
+    def act(u):          # the unit's activation as every consumer forms it on load: relu(raw * scale + shift)
+        return np.maximum(npy(u.raw) * npy(u.scale)[None, :, None, None] + npy(u.shift)[None, :, None, None], 0).astype(np.float32)
+
+    def close(got, ref, tol, what):
+        scale = float(np.abs(ref).sum()) + 1e-30
+        err = float(np.abs(got.astype(np.float64) - ref).sum()) / scale
+        assert err < tol, f"{what}: relative L1 {err:.3e} >= {tol}"
+
+    def unit_input(u):
+        for lvl, (u0, u1) in enumerate(eng.enc):
+            if u is u0:
+                return x if lvl == 0 else npy(eng.pooled[lvl])
+            if u is u1:
+                return act(u0)
+        for j, (u0, u1) in enumerate(eng.dec):
+            lvl = L_ - 1 - j
+            if u is u1:
+                return act(u0)
+            if u is u0:
+                up_p, _ = on.pad_to(npy(eng.ups[j].out), eng.hs[lvl], eng.ws[lvl])
+                return np.concatenate([act(eng.enc[lvl][1]), up_p], axis=1)
+        raise AssertionError
+
+    d_raw, dx_of = {}, {}
+    for u in eng.units:
+        a_in = unit_input(u)
+        wt = st[u.wname]
+        raw = npy(u.raw)
+        close(raw, on.conv3x3_fwd(a_in, wt), 1e-5, f"{u.wname} forward")
+        mean, invstd = npy(u.mean).astype(np.float64), npy(u.invstd).astype(np.float64)
+        r64 = raw.astype(np.float64)
+        assert np.allclose(mean, r64.mean(axis=(0, 2, 3)), rtol=1e-5, atol=1e-6), u.gname
+        assert np.allclose(invstd, 1.0 / np.sqrt(r64.var(axis=(0, 2, 3)) + 1e-5), rtol=1e-5), u.gname
+        xhat = (r64 - mean[None, :, None, None]) * invstd[None, :, None, None]
+        g = npy(u.g).astype(np.float64)
+        if u.pitched or u.fused_dw:
+            # u.g still holds dz (the apply pass wrote d_raw out of place / the first layer's dW formed it on the fly)
+            cnt = g.shape[0] * g.shape[2] * g.shape[3]
+            dbeta, dgamma = g.sum(axis=(0, 2, 3)), (g * xhat).sum(axis=(0, 2, 3))
+            close(G[u.bname], dbeta, 1e-5 + 1e-6 * float(np.abs(g).sum()) / (float(np.abs(dbeta).sum()) + 1e-30), f"{u.bname} grad")
+            close(G[u.gname], dgamma, 1e-5 + 1e-6 * float(np.abs(g * xhat).sum()) / (float(np.abs(dgamma).sum()) + 1e-30), f"{u.gname} grad")
+            gam = st[u.gname].astype(np.float64)
+            dr = (gam * invstd)[None, :, None, None] * (g - dbeta[None, :, None, None] / cnt - xhat * dgamma[None, :, None, None] / cnt)
+        else:
+            dr = g                # d_raw in place
+            mag = np.abs(dr).mean(axis=(0, 2, 3)) * dr.shape[0] * dr.shape[2] * dr.shape[3] + 1e-30
+            assert float((np.abs(dr.sum(axis=(0, 2, 3))) / mag).max()) < 1e-4 and float((np.abs((dr * xhat).sum(axis=(0, 2, 3))) / mag).max()) < 1e-4
+        d_raw[id(u)] = dr.astype(np.float32)
+        dxr, dwr = on.conv3x3_bwd(a_in, wt, d_raw[id(u)], need_dx=u.need_dgrad)
+        close(G[u.wname], dwr, 5e-5, f"{u.wname} grad")
+        dx_of[id(u)] = dxr
+
+    def masked(u, da):    # dz of unit u from the gradient w.r.t. its activation
+        return np.where(act(u) > 0, da, 0).astype(np.float32)
+
+    def dz_of(u):
+        assert u.pitched or u.fused_dw, "this check reads dz from u.g"
+        return npy(u.g)
+
+    last = eng.dec[-1][1] if L_ > 0 else eng.enc[0][1]
+    dout = 2.0 * (npy(out).astype(np.float64) - tgt) / out.numel()
+    wout = st["outc.conv.weight"].reshape(1, -1, 1, 1).astype(np.float64)
+    if last.pitched:
+        close(dz_of(last), masked(last, dout * wout), 1e-5, "output conv dX + ReLU mask")
+    close(G["outc.conv.bias"], dout.sum(axis=(0, 2, 3)), 1e-5, "outc bias grad")
+    close(G["outc.conv.weight"].reshape(-1), (dout * act(last).astype(np.float64)).sum(axis=(0, 2, 3)), 1e-5, "outc weight grad")
+    for pair in list(eng.enc) + list(eng.dec):      # second unit -> first unit of a DoubleConv
+        u0, u1 = pair
+        if u0.pitched or u0.fused_dw:
+            close(dz_of(u0), masked(u0, dx_of[id(u1)]), 1e-5, f"{u1.wname} dX into {u0.gname}")
+    for lvl in range(1, L_ + 1):                     # first encoder unit of a level -> the pooled gradient
+        close(npy(eng.dpooled[lvl]), dx_of[id(eng.enc[lvl][0])], 1e-5, f"dX into pooled[{lvl}]")
+    for j, up in enumerate(eng.ups):
+        lvl = L_ - 1 - j
+        skip, d0 = eng.enc[lvl][1], eng.dec[j][0]
+        dcat = dx_of[id(d0)]
+        oy, ox = eng._pad_off(lvl)
+        hu, wu = 2 * eng.hs[lvl + 1], 2 * eng.ws[lvl + 1]
+        gup = dcat[:, skip.cout:, oy:oy + hu, ox:ox + wu]
+        close(npy(up.dout), gup, 1e-5, f"dX slice handed to {up.wname}")
+        prev = eng.dec[j - 1][1] if j > 0 else eng.enc[L_][1]
+        dxu, dwu, dbu = on.convT_bwd(act(prev), st[up.wname], npy(up.dout))
+        close(G[up.wname], dwu, 5e-5, f"{up.wname} grad")
+        close(G[up.bname], dbu, 1e-5, f"{up.bname} grad")
+        if prev.pitched:
+            close(dz_of(prev), masked(prev, dxu), 1e-5, f"{up.wname} dX into {prev.gname}")
+        # the skip unit's gradient: its slice of the decoder conv's dX + the max-pool routing of the level below
+        if skip.pitched:
+            _, idx = on.maxpool2_fwd(act(skip))
+            dpool = on.maxpool2_bwd(npy(eng.dpooled[lvl + 1]), idx, act(skip).shape)
+            close(dz_of(skip), masked(skip, dcat[:, :skip.cout] + dpool), 1e-5, f"skip + pool gradient into {skip.gname}")
