@@ -16,6 +16,7 @@ def kname(n):
     n = n.strip()
     if n.startswith('void '):
         n = n[5:]
+    n = n.replace('(anonymous namespace)::', '')
     d = 0
     for i, ch in enumerate(n):
         d += ch == '<'
