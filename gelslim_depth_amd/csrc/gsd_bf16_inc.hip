@@ -82,6 +82,17 @@ struct IncP {
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4), aligned(8)));
 
+#ifndef INC_NT      // 1: a0 / y1 leave as non-temporal stores (diagnostic switch while measuring)
+#define INC_NT 0
+#endif
+__device__ __forceinline__ void inc_store16(u16* p, u32x4 v) {
+#if INC_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4s*>(p));
+#else
+  *reinterpret_cast<u32x4s*>(p) = v;
+#endif
+}
+
 #ifndef INC_ABL     // diagnostic builds only (results are then garbage): 1 no a0 stores, 2 no y1 stores, 4 no statistics,
 #define INC_ABL 0   // 8 no K loop, 16 the rebuild's activation is not staged in LDS
 #endif
@@ -270,8 +281,8 @@ __global__ __launch_bounds__(512) void inc_fused_bf16_kernel(const IncP P) {
         *reinterpret_cast<u32x4*>(Al + G::ACT_PLANE + q * 64 + sw) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         if (!((INC_ABL) & 1) && inimg && r >= 1 && r <= TH && c >= 1 && c <= I_TW) {   // the tile's own pixels: a0 goes to HBM once
           u16* o = P.a0 + ((long long)(n * P.H + h) * P.W + w) * P.a0_pitch + g * 8;
-          *reinterpret_cast<u32x4s*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          *reinterpret_cast<u32x4s*>(o + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+          inc_store16(o, u32x4{pk[0], pk[1], pk[2], pk[3]});
+          inc_store16(o + 32, u32x4{pk[4], pk[5], pk[6], pk[7]});
         }
       }
     };
@@ -369,8 +380,8 @@ __global__ __launch_bounds__(512) void inc_fused_bf16_kernel(const IncP P) {
         }
         if (ok && (!((INC_ABL) & 2) || pk[0] == 0x12345u)) {
           u16* o = y_o0 + t * y_row;
-          *reinterpret_cast<u32x4s*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          *reinterpret_cast<u32x4s*>(o + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+          inc_store16(o, u32x4{pk[0], pk[1], pk[2], pk[3]});
+          inc_store16(o + 32, u32x4{pk[4], pk[5], pk[6], pk[7]});
         }
       }
     };
