@@ -140,6 +140,9 @@ SIGNATURES = {
     "gsd_bf16_inc_conv": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _NHWC, _NHWC, _P, _P]),
     "gsd_bf16_first_bn_bwd_reduce": (_I, [_P, _I, _I, _I, _I, _P, _NHWC, _P, _P, _P, _P, _P, _P]),
     "gsd_bf16_wgrad_first_recompute": (_I, [_P, _I, _I, _I, _I, _P, _NHWC, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "gsd_bf16_conv3x3_c64_supported": (_I, [_I, _I]),
+    "gsd_bf16_conv3x3_c64_partial_rows": (_I, [_I, _I, _I]),
+    "gsd_bf16_conv3x3_c64": (_I, [_NHWC, _P, _NHWC, _P, _BNBWD, _P]),
     "gsd_bf16_bn_apply": (_I, [_NHWC, _P, _P, _NHWC, _I, _P]),
     "gsd_bf16_bn_apply_pool": (_I, [_NHWC, _P, _P, _NHWC, _NHWC, _P]),
     "gsd_bf16_maxpool2": (_I, [_NHWC, _NHWC, _P]),

@@ -52,6 +52,7 @@ class _Unit:
         self.need_dgrad = True
         self.wt_f = self.wt_d = None
         self.scale = self.shift = self.mean = self.invstd = self.c1 = self.c2 = self.sums = None
+        self.fused_rows = 0         # partial rows written by the dX launch whose epilogue did pass 1 of this unit's BatchNorm backward
         self.y = self.g = None      # (N,H,W,Cout) bf16
         self.a = None               # gsd_nhwc view of the activation (own tensor or a slice of a concat buffer)
         self.a_t = None             # tensor backing `a`
@@ -180,6 +181,8 @@ class UNetEngineBF16:
         # gradients are handed to the all-reduce and at the end of backward.  GSD_BF16_SIDE_DW=0: everything on one stream.
         # BatchNorm apply + max-pool of the encoder's skip units in one pass (gsd_bf16_bn_apply_pool); GSD_BF16_APPLY_POOL=0: two
         self.apply_pool = os.environ.get("GSD_BF16_APPLY_POOL", "1") != "0"
+        # 64 -> 64 convolutions (forward and dX) on the weights-resident kernel (gsd_bf16_c64.hip); GSD_BF16_C64=0: the DMA-filled one
+        self.c64 = os.environ.get("GSD_BF16_C64", "1") != "0"
         self.side_dw = train and os.environ.get("GSD_BF16_SIDE_DW", "1") != "0"
         self.side = torch.cuda.Stream(device=dev) if self.side_dw else None
         self.wspace_side = torch.empty((max(max_ws, 64),), **f32) if self.side_dw else None
@@ -277,6 +280,14 @@ class UNetEngineBF16:
             check(lib.gsd_bf16_conv_dense(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), src[2], u.cout, 1, 1, z, z, lh, lw, 0, 0, 0,
                                           None, part, None, st), "conv_dense(first)")
             done()
+        elif self._use_c64(u.cin, u.cout):
+            self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
+            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+            check(lib.gsd_bf16_conv3x3_c64(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), part, None, st), "conv3x3_c64")
+            done()
+            self._finalize_stats(u, lib.gsd_bf16_conv3x3_c64_partial_rows(n, lh, lw), float(n * lh * lw), P, st)
+            self._apply(u, dy, st, pool_to)
+            return
         else:
             self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
             done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
@@ -286,6 +297,9 @@ class UNetEngineBF16:
                 else lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout))
         self._finalize_stats(u, rows, float(n * lh * lw), P, st)
         self._apply(u, dy, st, pool_to)
+
+    def _use_c64(self, k: int, m: int) -> bool:
+        return self.c64 and bool(lib.gsd_bf16_conv3x3_c64_supported(k, m))
 
     def _run_inc_fused(self, u0: _Unit, u1: _Unit, P, st: int, pool_to: Optional[torch.Tensor]) -> None:
         """Train-mode `inc` (unet.py:7-20, :67) without u0's raw output: statistics of conv(x) from a write-free pass, then ONE
@@ -421,7 +435,7 @@ class UNetEngineBF16:
         does not exist: pass 1 and dW recompute it from x (gsd_bf16_first_bn_bwd_reduce, gsd_bf16_wgrad_first_recompute)."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         count = float(n * lh * lw)
-        rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout) if fused else lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
+        rows = (u.fused_rows or lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cout)) if fused else lib.gsd_bf16_bn_bwd_partial_rows(n, lh, lw)
         if recompute:
             fused = True
             rows = lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout)
@@ -577,9 +591,17 @@ class UNetEngineBF16:
         if fuse is not None:
             bw, keep = self._bnbwd(fuse)
         done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
-        check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), u.cout, u.cin,
-                                   self.partials.data_ptr() if bw is not None else None, C.byref(bw) if bw is not None else None, st),
-              "conv3x3 dgrad")
+        part = self.partials.data_ptr() if bw is not None else None
+        if self._use_c64(u.cout, u.cin):
+            check(lib.gsd_bf16_conv3x3_c64(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), part, C.byref(bw) if bw is not None else None, st),
+                  "conv3x3_c64 dgrad")
+            rows = lib.gsd_bf16_conv3x3_c64_partial_rows(n, lh, lw)
+        else:
+            check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), u.cout, u.cin, part,
+                                       C.byref(bw) if bw is not None else None, st), "conv3x3 dgrad")
+            rows = lib.gsd_bf16_conv_partial_rows(n, lh, lw, u.cin)
+        if fuse is not None:
+            fuse.fused_rows = rows
         done()
 
     def backward(self, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
@@ -624,6 +646,7 @@ class UNetEngineBF16:
             check(lib.gsd_bf16_conv_dense(C.byref(gup), up.wt_d.data_ptr(), C.byref(dprev), up.cout, up.cin, 4, 2, ty, tx, hi, wi, 0,
                                           0, 0, None, self.partials.data_ptr(), C.byref(bw), st), "convT dgrad")
             done()
+            prev.fused_rows = lib.gsd_bf16_conv_partial_rows(n, hi, wi, prev.cout)
             prev_fused = prev
             if self.block_done_cb is not None:
                 self._join_side()

@@ -136,6 +136,17 @@ int gsd_bf16_wgrad_first_recompute(const float* x, int N, int C, int H, int W, c
                                    const float* c1, const float* c2, float* dw, float* workspace, int64_t workspace_elems,
                                    void* stream);
 
+/* ---- conv3x3 64 -> 64 channels with the weights resident in LDS -------------------------------------------------------------
+ * The 64-channel 3x3 convolutions of the first level (unet.py:14 for `inc` and `up.3.conv`, forward and dX) as a persistent
+ * kernel that loads its 72 KiB of weights once per CU and fills the whole 64-channel halo of a pixel tile by one LDS-DMA fill
+ * under the previous tile's epilogue: no operand fill and no barrier inside the K loop.  Same products in the same order as
+ * gsd_bf16_conv3x3 (outputs bit-identical); `wt`, `partials` (gsd_bf16_conv3x3_c64_partial_rows rows of 2*gsd_bf16_conv_mpad(64)
+ * floats, one per block; NULL: a plain convolution) and `bw` as there. */
+int gsd_bf16_conv3x3_c64_supported(int K, int M);
+int gsd_bf16_conv3x3_c64_partial_rows(int N, int H, int W);
+int gsd_bf16_conv3x3_c64(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, float* partials, const gsd_bf16_bnbwd* bw,
+                         void* stream);
+
 /* First layer: x (N,C,H,W) fp32 NCHW -> col (N,H,W,round_up(9C,32)) bf16 with col[..,c*9+t] = x[n,c,h+t/3-1,w+t%3-1]
  * (zero padded), so that conv3x3(x) is a 1x1 convolution of col (gsd_bf16_conv_dense). unet.py:11 for `inc`. */
 int gsd_bf16_im2col3x3(const float* x, int N, int C, int H, int W, const gsd_nhwc* col, void* stream);

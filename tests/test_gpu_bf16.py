@@ -690,3 +690,66 @@ def test_inc_block_fused_equals_its_unfused_kernels_bf16(n, c, h, w):
                                                  shift.data_ptr(), mean_f.data_ptr(), invstd_f.data_ptr(), c1.data_ptr(), c2.data_ptr(),
                                                  dw.data_ptr(), ws.data_ptr(), need, L.stream_ptr()), "wgrad_first_recompute")
     assert bool(torch.isfinite(dw).all()) and torch.equal(dw, dw_ref)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 19, 70), (1, 8, 64), (3, 21, 27), (2, 33, 130), (1, 5, 3), (2, 40, 427)])
+def test_conv3x3_c64_weights_resident_equals_the_dma_kernel_bf16(n, h, w):
+    """gsd_bf16_conv3x3_c64 (64 -> 64 channels, weights resident in LDS, one halo fill per tile) against gsd_bf16_conv3x3: the same
+    products in the same order -- raw output bit-identical, BatchNorm partial sums equal to the sums of the stored values; with
+    `bw` (fused pass 1 of the BatchNorm + ReLU backward, raw output of the unit below from HBM) dz bit-identical and the two sums
+    equal to those of the DMA kernel; without partials a plain convolution.  Input and output as channel slices of wider buffers."""
+    L = _lib()
+    m = 64
+    g = torch.Generator().manual_seed(3 * n + h + w)
+    assert L.lib.gsd_bf16_conv3x3_c64_supported(64, 64) == 1 and L.lib.gsd_bf16_conv3x3_c64_supported(128, 64) == 0
+    a = bf16r(torch.randn((n, m, h, w), generator=g))
+    wt = torch.randn((m, m, 3, 3), generator=g) * 0.05
+    a_buf = to_nhwc(a, c_total=m + 32, c_off=32)              # the input is a channel slice of a wider buffer
+    w_d = wt.cuda()
+    mp = L.lib.gsd_bf16_conv_mpad(m)
+    rows_d, rows_c = L.lib.gsd_bf16_conv_partial_rows(n, h, w, m), L.lib.gsd_bf16_conv3x3_c64_partial_rows(n, h, w)
+    din = L.make_nhwc(a_buf, 32, m)
+    for mode in (0, 1):                                       # forward image, dX image
+        img = torch.zeros(L.lib.gsd_bf16_weight_image_size(mode, m, m), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib.gsd_bf16_weight_image(mode, w_d.data_ptr(), m, m, img.data_ptr(), L.stream_ptr()), "wimg")
+        ref = torch.full((n, h, w, m + 16), 7.0, dtype=torch.bfloat16, device="cuda")
+        got = torch.full((n, h, w, m + 16), 7.0, dtype=torch.bfloat16, device="cuda")
+        pr, pg = torch.zeros((rows_d, 2 * mp), device="cuda"), torch.full((rows_c, 2 * mp), float("nan"), device="cuda")
+        L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(ref, 16, m)), m, m, pr.data_ptr(), None,
+                                       L.stream_ptr()), "conv3x3")
+        L.check(L.lib.gsd_bf16_conv3x3_c64(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(got, 16, m)), pg.data_ptr(), None,
+                                           L.stream_ptr()), "conv3x3_c64")
+        torch.cuda.synchronize()
+        assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), f"mode {mode}: raw output (and the untouched channels)"
+        yv = got[..., 16:].double()
+        sg = pg.double().sum(0)
+        np.testing.assert_allclose(sg[:m].cpu().numpy(), yv.sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(sg[mp:mp + m].cpu().numpy(), (yv * yv).sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # ---- fused BatchNorm + ReLU backward pass 1, raw output of the unit below from HBM
+    yb = bf16r(torch.randn((n, m, h, w), generator=g))
+    yb_buf = to_nhwc(yb)
+    vec = [(torch.rand(m, generator=g) + 0.5).cuda(), (torch.randn(m, generator=g) * 0.3).cuda(), (torch.randn(m, generator=g) * 0.1).cuda(),
+           (torch.rand(m, generator=g) + 0.5).cuda()]      # scale shift mean invstd
+    yv_ = L.make_nhwc(yb_buf)
+    bw = L.gsd_bf16_bnbwd()
+    bw.y = C.pointer(yv_)
+    bw.scale, bw.shift, bw.mean, bw.invstd = [v.data_ptr() for v in vec]
+    ref = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    got = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+    pr, pg = torch.zeros((rows_d, 2 * mp), device="cuda"), torch.full((rows_c, 2 * mp), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(ref)), m, m, pr.data_ptr(), C.byref(bw), L.stream_ptr()),
+            "conv3x3 bw")
+    L.check(L.lib.gsd_bf16_conv3x3_c64(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(got)), pg.data_ptr(), C.byref(bw), L.stream_ptr()),
+            "conv3x3_c64 bw")
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), "dz"
+    sr, sg = pr.double().sum(0), pg.double().sum(0)
+    mag = float(ref.double().abs().sum(dim=(0, 1, 2)).max()) + 1e-9
+    assert float((sr[:m] - sg[:m]).abs().max()) <= 1e-5 * mag and float((sr[mp:mp + m] - sg[mp:mp + m]).abs().max()) <= 2e-5 * mag
+    # ---- a plain convolution (partials == NULL): what inc's second dX runs when the first raw output was never stored
+    ref = torch.zeros((n, h, w, m), dtype=torch.bfloat16, device="cuda")
+    got = torch.full((n, h, w, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(ref)), m, m, None, None, L.stream_ptr()), "plain")
+    L.check(L.lib.gsd_bf16_conv3x3_c64(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(got)), None, None, L.stream_ptr()), "plain c64")
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16))

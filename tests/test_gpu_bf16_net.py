@@ -303,3 +303,17 @@ def test_bf16_fused_inc_block_tracks_the_unfused_step(dims, n, h, w, monkeypatch
         assert rel_l1(b1[k].cpu().numpy(), b0[k].cpu().numpy()) < 2e-3, k
     assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
     assert not _model([32, 64], synth.make_state(3, 1, [32, 64], 1, "conditioned"), "bf16")._engine.__dict__.get("fused_inc", False)
+
+
+@pytest.mark.parametrize("dims,n,h,w", [([64, 128], 3, 37, 53), ([64, 128, 256], 2, 40, 130)])
+def test_bf16_c64_kernel_tracks_the_dma_kernel_step(dims, n, h, w, monkeypatch):
+    """GSD_BF16_C64 (default on): the 64 -> 64 convolutions of the first level (forward and dX) on the weights-resident kernel.
+    Its outputs are bit-identical to the DMA-filled kernel's (tests/test_gpu_bf16.py); the BatchNorm partial sums come in another
+    order, so at network level the step agrees like two orders of one sum."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_C64": "0"}, steps=1, n=n, h=h, w=w)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_C64": "1"}, steps=1, n=n, h=h, w=w)
+    assert not e0.c64 and e1.c64
+    assert abs(l0[0] - l1[0]) <= 1e-4 * abs(l0[0])
+    for k in b0:
+        assert rel_l1(b1[k].cpu().numpy(), b0[k].cpu().numpy()) < 2e-3, k
+    assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
