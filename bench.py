@@ -240,7 +240,10 @@ class Leg:
             extra = {"traffic": traffic, "traffic_source": traffic_src, "traffic_vs_algorithmic": round(traffic / by, 3),
                      "traffic_TBps": round(traffic / (avg * 1e-3) / 1e12, 3)}
         return {**extra, "bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
-                + ("first conv straight from x + 64->64 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
+                + ("statistics-only first conv + fused kernel (rebuilds relu(bn(conv(x))) per halo tile, weights-resident 64->64 "
+                   "conv) + BN finalize x2 + BN-apply with the max-pool (gsd_bf16_inc.hip)"
+                   if (self.dtype == "bf16" and getattr(self.model._engine, "fused_inc", False)) else
+                   "first conv straight from x + 64->64 conv + BN statistics + 2 BN-apply launches" if self.dtype == "bf16"
                    else "direct conv + Winograd conv + BN statistics launches"),
                 "achieved": round(tbs, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),
                 "algorithmic_bytes": int(by), "avg_ms": round(avg, 4), "launches_timed": len(ms),
