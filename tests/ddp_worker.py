@@ -45,6 +45,8 @@ def main():
     from gelslim_depth_amd.train import TrainStep
     full = len(sys.argv) > 4 and sys.argv[4] == "full"     # BASELINE's network and resolution: the REAL bucket sizes (0.15-57 MB)
     dims = [64, 128, 256, 512, 1024] if full else ([16, 32, 64] if precision == "fp32" else [32, 64, 128])
+    if len(sys.argv) > 5:                                   # explicit layer dimensions, e.g. "64,128": the fused `inc` block and the
+        dims = [int(v) for v in sys.argv[5].split(",")]     # weights-resident 64 -> 64 kernel of the bf16 engine
     # every rank starts from DIFFERENT weights: the rank-0 broadcast must fix that
     st = synth.make_state(3, 1, dims, 5 + 100 * rank, "conditioned")
     x, t = synth.make_batch(4, 320, 427, 6) if full else synth.make_batch(4, 37, 53, 6)            # global batch 4 -> 2 per rank

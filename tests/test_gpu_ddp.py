@@ -17,10 +17,12 @@ from gelslim_depth_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_two_ranks(tmp_path, mode, precision="fp32", size="small"):
+def run_two_ranks(tmp_path, mode, precision="fp32", size="small", dims=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(REPO, "tests", "ddp_worker.py"), str(tmp_path), mode, precision, size]
+    if dims is not None:
+        cmd.append(",".join(str(d) for d in dims))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = [dict(np.load(os.path.join(tmp_path, f"rank{i}.npz"))) for i in range(2)]
@@ -210,3 +212,43 @@ def test_two_rank_validation_pass_is_the_single_process_value(tmp_path):
         assert abs(float(res[0][f"val{n}"]) - one) <= 2e-6 * abs(one), (n, float(res[0][f"val{n}"]), one)
         for r in range(2):
             assert tuple(res[r][f"shape{n}"]) == (2, 37, 53), "evaluation keeps the per-rank train shape"
+
+
+@pytest.mark.parametrize("mode", ["local_bn", "sync_bn"])
+def test_two_rank_bf16_with_the_fused_inc_block(tmp_path, mode):
+    """The bf16 engine's round-4 kernels under data parallelism (layer_dimensions starting at 64: the `inc` double convolution
+    without its first raw output, its recomputing backward, the weights-resident 64 -> 64 kernel).  local BatchNorm: the
+    all-reduced arena equals, bit for bit, the sum of two single-process steps on the shards.  SyncBN: the statistics-only pass and
+    the fused kernel's partial sums go through the all-reduce like any other layer's; the result tracks one process on the whole
+    batch."""
+    import torch
+    from gelslim_depth_amd.models.unet import UNet
+    from gelslim_depth_amd.train import TrainStep
+    dims = [64, 128]
+    res = run_two_ranks(tmp_path, mode, "bf16", "small", dims=dims)
+    st0 = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, t = synth.make_batch(4, 37, 53, 6)
+    assert np.array_equal(res[0]["g_sum"], res[1]["g_sum"]) and np.array_equal(res[0]["p1"], res[1]["p1"])
+
+    def single(xs, ts):
+        m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision="bf16")
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in st0.items()}, strict=True)
+        m = m.to("cuda").train()
+        step = TrainStep(m)
+        loss = float(step(torch.from_numpy(xs).cuda(), torch.from_numpy(ts).cuda()))
+        assert m._engine.fused_inc and m._engine.c64
+        return loss, step.g_flat.cpu().numpy(), m
+    if mode == "local_bn":
+        shards = [single(x[2 * r:2 * r + 2], t[2 * r:2 * r + 2]) for r in range(2)]
+        for r in range(2):
+            assert abs(shards[r][0] - float(res[r]["loss"])) <= 1e-6 * abs(shards[r][0])
+        assert np.array_equal(res[0]["g_sum"], shards[0][1] + shards[1][1])
+    else:
+        loss, g1, m = single(x, t)
+        g2 = res[0]["g_sum"] / 2.0
+        assert abs(0.5 * (float(res[0]["loss"]) + float(res[1]["loss"])) - loss) <= 2e-3 * abs(loss)
+        cos = float(g1.astype(np.float64) @ g2.astype(np.float64) / np.sqrt((g1.astype(np.float64) ** 2).sum() * (g2.astype(np.float64) ** 2).sum()))
+        assert cos > 0.99, cos
+        for k, v in m.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert rel_l1(res[0]["buf/" + k], v.cpu().numpy()) < 1e-3, k
