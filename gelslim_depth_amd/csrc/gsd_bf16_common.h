@@ -38,6 +38,24 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned v) {
   return __builtin_bit_cast(unsigned, r);
 }
 
+// Whole-line stores of a 16-pixel x 64-channel MFMA result (bf16 NHWC, 128 B a pixel).  The MFMA leaves lane (g = lane>>4,
+// j = lane&15) with channels 8g..8g+7 (`lo`) and 32+8g.. (`hi`) of pixel j: stored as they lie, every instruction writes sixteen
+// 64-byte HALF lines, and two half-line writes of a 128-byte line reach HBM at about half the rate of whole-line ones (a plain
+// fill of 1.12 GB: 6.9 TB/s; gsd_bf16_conv3x3_first storing 560 MB that way: 3.35 TB/s).  One DPP rotate by 8 lanes inside each
+// row of 16, written only to half of the row (bank_mask), hands lanes j >= 8 the `hi` piece of pixel j-8 and lanes j < 8 the `lo`
+// piece of pixel j+8: instruction A then writes pixels 0..7 of the tile as whole 128-byte lines, instruction B pixels 8..15.
+//   lane's pixel inside the tile: A: j & 7, B: 8 + (j & 7); channel offset of its 16 bytes: (j < 8 ? 0 : 32) + 8g  (both: gsd_line_*)
+__device__ __forceinline__ void gsd_line_pieces(const unsigned (&lo)[4], const unsigned (&hi)[4], u32x4& a, u32x4& b) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // row_ror:8 = 0x128; bank_mask 0xC: only lanes 8..15 of each row take the rotated value, 0x3: only lanes 0..7
+    a[i] = (unsigned)__builtin_amdgcn_update_dpp((int)lo[i], (int)hi[i], 0x128, 0xf, 0xC, false);
+    b[i] = (unsigned)__builtin_amdgcn_update_dpp((int)hi[i], (int)lo[i], 0x128, 0xf, 0x3, false);
+  }
+}
+__device__ __forceinline__ int gsd_line_pixel(int j) { return j & 7; }                       // (+ 8 for instruction B)
+__device__ __forceinline__ int gsd_line_channel(int g, int j) { return (j < 8 ? 0 : 32) + 8 * g; }
+
 struct NhwcD {
   u16* p;
   long long pitch;

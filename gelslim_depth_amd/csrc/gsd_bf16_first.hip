@@ -185,10 +185,18 @@ __global__ __launch_bounds__(256, FM == FM_BWD ? 2 : 3) void conv_first_bf16_ker
             s1[m][3] += q3; s2[m][3] = fmaf(q3, q3, s2[m][3]);
           }
         }
-        if ((FM == FM_STORE || FM == FM_EVAL) && w < P.W) {
-          u16* o = P.out + (((long long)n * P.H + h) * P.W + w) * P.out_pitch + ch0;
-          *reinterpret_cast<u32x4s*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-          if (MT == 4) *reinterpret_cast<u32x4s*>(o + 32) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        if (FM == FM_STORE || FM == FM_EVAL) {
+          if (MT == 4) {   // whole 128-byte lines per instruction (gsd_line_pieces): pixels 0..7 of the step, then 8..15
+            u32x4 la, lb;
+            gsd_line_pieces({pk[0], pk[1], pk[2], pk[3]}, {pk[4], pk[5], pk[6], pk[7]}, la, lb);
+            const int wa = w0 + t * 16 + gsd_line_pixel(j);
+            u16* o = P.out + (((long long)n * P.H + h) * P.W + wa) * P.out_pitch + gsd_line_channel(g, j);
+            if (wa < P.W) *reinterpret_cast<u32x4s*>(o) = la;
+            if (wa + 8 < P.W) *reinterpret_cast<u32x4s*>(o + 8 * P.out_pitch) = lb;
+          } else if (w < P.W) {
+            u16* o = P.out + (((long long)n * P.H + h) * P.W + w) * P.out_pitch + ch0;
+            *reinterpret_cast<u32x4s*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          }
         }
       }
     }
