@@ -122,6 +122,7 @@ SIGNATURES = {
     # ---- include/gsd_bf16.h
     "gsd_bf16_conv_mpad": (_I, [_I]),
     "gsd_bf16_conv_partial_rows": (_I, [_I, _I, _I, _I]),
+    "gsd_bf16_conv_dense_partial_rows": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "gsd_bf16_conv3x3": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _BNBWD, _P]),
     "gsd_bf16_conv_dense": (_I, [_NHWC, _P, _NHWC, _I, _I, _I, _I, _IP, _IP, _I, _I, _I, _I, _I, _P, _P, _BNBWD, _P]),
     "gsd_bf16_conv3x3_bnrelu": (_I, [_NHWC, _P, _NHWC, _I, _I, _P, _P, _P]),

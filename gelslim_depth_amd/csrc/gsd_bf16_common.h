@@ -26,8 +26,11 @@ __device__ __forceinline__ u16 f32_to_bf16(float v) {
   const __bf16 h = (__bf16)v;
   return __builtin_bit_cast(u16, h);
 }
+// two values in ONE v_cvt_pk_bf16_f32 (the vector convert; two scalar converts cost two of them plus a shift and an or -- same bits)
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // ReLU of two packed bf16 values: as 16-bit integers a bf16 is negative exactly when its sign bit is set, so a packed signed
@@ -77,3 +80,11 @@ static inline int gsd_check_nhwc(const gsd_nhwc* t, const char* what) {
               what);
   return 0;
 }
+
+// gsd_bf16_ctgemm.hip: the large-tile kernel behind gsd_bf16_conv_dense for the transposed convolutions' forward and dX
+bool gsd_ctgemm_shape(int N, int H, int W, int K, int M, int ntaps, int stride, int scatter_cs);
+bool gsd_ctgemm_operands(const gsd_nhwc* in, const gsd_nhwc* out, const gsd_bf16_bnbwd* bw, int ntaps, const int* ty, const int* tx, int H,
+                         int W);
+int gsd_ctgemm_partial_rows(int N, int H, int W, int M);
+int gsd_ctgemm_launch(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, const int* ty, const int* tx, int H,
+                      int W, int scatter_cs, int oy, int ox, const float* bias, float* partials, const gsd_bf16_bnbwd* bw, void* stream);

@@ -688,6 +688,21 @@ static int conv_dense_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* o
   } else {
     GSD_REQUIRE(out->C == M && H <= out->H && W <= out->W, GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: out must hold (H,W,M)");
   }
+  if (bw != nullptr) {
+    if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv_dense bw.y")) return e;
+    GSD_REQUIRE(scatter_cs == 0 && bias == nullptr && bw->scale && bw->shift && bw->mean && bw->invstd && partials, GSD_ERR_BAD_ARG,
+                "gsd_bf16_conv_dense: fused BatchNorm backward needs plain output, coefficients and partials");
+    GSD_REQUIRE(bw->y->N == out->N && bw->y->H == out->H && bw->y->W == out->W && out->H == H && out->W == W && bw->y->C == M &&
+                    (bw->y->pitch & 3) == 0,
+                GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: bw.y must have out's geometry (and out the GEMM's pixel grid)");
+  }
+  if (ep_scale == nullptr && (partials == nullptr) == (bw == nullptr) && gsd_ctgemm_shape(in->N, H, W, K, M, ntaps, stride, scatter_cs)) {
+    // the transposed convolutions' forward and dX: the large-tile kernel (gsd_bf16_ctgemm.hip)
+    if (gsd_ctgemm_operands(in, out, bw, ntaps, ty, tx, H, W))
+      return gsd_ctgemm_launch(in, wt, out, K, M, ntaps, ty, tx, H, W, scatter_cs, oy, ox, bias, partials, bw, stream);
+    GSD_REQUIRE(partials == nullptr, GSD_ERR_UNSUPPORTED,
+                "gsd_bf16_conv_dense: taps that leave the buffer with fused statistics (gsd_bf16_conv_dense_partial_rows counted the large-tile kernel's rows)");
+  }
   const Plan pl = make_plan(H, W, M);
   GConvP P;
   P.in = (const u16*)in->ptr; P.in_pitch = in->pitch; P.Hin = in->H; P.Win = in->W;
@@ -704,12 +719,6 @@ static int conv_dense_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* o
   P.ep_scale = ep_scale; P.ep_shift = ep_shift;
   P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
   if (bw != nullptr) {
-    if (int e = gsd_check_nhwc(bw->y, "gsd_bf16_conv_dense bw.y")) return e;
-    GSD_REQUIRE(scatter_cs == 0 && bias == nullptr && bw->scale && bw->shift && bw->mean && bw->invstd && partials, GSD_ERR_BAD_ARG,
-                "gsd_bf16_conv_dense: fused BatchNorm backward needs plain output, coefficients and partials");
-    GSD_REQUIRE(bw->y->N == out->N && bw->y->H == out->H && bw->y->W == out->W && out->H == H && out->W == W && bw->y->C == M &&
-                    (bw->y->pitch & 3) == 0,
-                GSD_ERR_BAD_ARG, "gsd_bf16_conv_dense: bw.y must have out's geometry (and out the GEMM's pixel grid)");
     P.bw_y = (const u16*)bw->y->ptr; P.bw_pitch = bw->y->pitch;
     P.bw_scale = bw->scale; P.bw_shift = bw->shift; P.bw_mean = bw->mean; P.bw_invstd = bw->invstd;
   }
@@ -719,6 +728,11 @@ static int conv_dense_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* o
   const size_t lds = (size_t)2 * nsub * pl.BM * 64 + (size_t)2 * nsub * pl.NPX * 96 + (size_t)(4 * pl.BM + 512) * sizeof(float);
   if (pl.wide) return launch<1, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
   return launch<1, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv_dense");
+}
+
+extern "C" int gsd_bf16_conv_dense_partial_rows(int N, int H, int W, int K, int M, int ntaps, int stride) {
+  if (gsd_ctgemm_shape(N, H, W, K, M, ntaps, stride, 0)) return gsd_ctgemm_partial_rows(N, H, W, M);
+  return gsd_bf16_conv_partial_rows(N, H, W, M);
 }
 
 extern "C" int gsd_bf16_conv3x3(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, float* partials,

@@ -171,6 +171,9 @@ class UNetEngineBF16:
                 up.wt_f = torch.empty((lib.gsd_bf16_weight_image_size(3, up.cout, up.cin),), **bf)
                 up.wt_d = torch.empty((lib.gsd_bf16_weight_image_size(4, up.cout, up.cin),), **bf)
             if train:
+                # the transposed convolution's dX carries pass 1 of the BatchNorm backward of the unit below it
+                max_part = max(max_part, lib.gsd_bf16_conv_dense_partial_rows(n, hs[li], ws[li], up.cout, up.cin, 4, 2) * 2 *
+                               lib.gsd_bf16_conv_mpad(up.cin))
                 max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(4, n, hs[li], ws[li], up.cin, up.cout))
                 max_ws = max(max_ws, lib.gsd_bf16_channel_sums_workspace(n, 2 * hs[li], 2 * ws[li], up.cout))
         self.partials = torch.empty((max_part,), **f32)
@@ -646,7 +649,7 @@ class UNetEngineBF16:
             check(lib.gsd_bf16_conv_dense(C.byref(gup), up.wt_d.data_ptr(), C.byref(dprev), up.cout, up.cin, 4, 2, ty, tx, hi, wi, 0,
                                           0, 0, None, self.partials.data_ptr(), C.byref(bw), st), "convT dgrad")
             done()
-            prev.fused_rows = lib.gsd_bf16_conv_partial_rows(n, hi, wi, prev.cout)
+            prev.fused_rows = lib.gsd_bf16_conv_dense_partial_rows(n, hi, wi, up.cout, up.cin, 4, 2)
             prev_fused = prev
             if self.block_done_cb is not None:
                 self._join_side()

@@ -67,6 +67,11 @@ int gsd_bf16_conv1x1_bnrelu(const gsd_nhwc* in, const void* wt, const gsd_nhwc* 
 int gsd_bf16_conv_dense(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out, int K, int M, int ntaps, int stride,
                         const int* ty, const int* tx, int H, int W, int scatter_cs, int oy, int ox, const float* bias,
                         float* partials, const gsd_bf16_bnbwd* bw, void* stream);
+/* BatchNorm partial rows a gsd_bf16_conv_dense launch of this shape writes (plain output, scatter_cs == 0): the transposed
+ * convolutions' shapes (4 taps at stride 2, K % 64 == 0, M == 128 or M % 256 == 0) run on a large-tile kernel with its own
+ * row count (csrc/gsd_bf16_ctgemm.hip; GSD_BF16_CTGEMM=0 keeps them on the general kernel), everything else writes
+ * gsd_bf16_conv_partial_rows(N, H, W, M) rows. */
+int gsd_bf16_conv_dense_partial_rows(int N, int H, int W, int K, int M, int ntaps, int stride);
 
 /* ---- weight images (fp32 master -> bf16 GEMM layout [T][mpad(M)][round_up(K,32)], zero padded) ---------------------
  * mode 0 conv3x3 forward  from (Cout,Cin,3,3):  [t][co][ci]

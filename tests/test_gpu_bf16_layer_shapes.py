@@ -182,3 +182,101 @@ def test_bf16_convT_at_network_shape(case, n):
     ws, db = torch.empty((nws,), device="cuda"), torch.zeros((cout,), device="cuda")
     L.check(L.lib.gsd_bf16_channel_sums(C.byref(dgy), oy, ox, 2 * h, 2 * w, db.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()), "db")
     assert float((db.cpu().double() - bz.grad).abs().max()) <= 2e-5 * float(bz.grad.abs().max()) + 1e-9, f"{name} db"
+
+
+def _convT_both_kernels(L, fn):
+    """fn() under GSD_BF16_CTGEMM=1 (the large-tile kernel, csrc/gsd_bf16_ctgemm.hip) and =0 (gconv_bf16_kernel<1,..>)."""
+    import os
+    old = os.environ.get("GSD_BF16_CTGEMM")
+    out = []
+    try:
+        for v in ("1", "0"):
+            os.environ["GSD_BF16_CTGEMM"] = v
+            out.append(fn())
+    finally:
+        if old is None:
+            os.environ.pop("GSD_BF16_CTGEMM", None)
+        else:
+            os.environ["GSD_BF16_CTGEMM"] = old
+    return out
+
+
+CT_CASES = [(CONVT[0], 2), (CONVT[1], 3), (CONVT[2], 2), (CONVT[3], 1), (CONVT[3], 2), (CONVT[0], 32), (CONVT[2], 8)]
+
+
+@pytest.mark.parametrize("case,n", CT_CASES, ids=[f"{c[0]}-N{n}" for c, n in CT_CASES])
+def test_bf16_convT_large_tile_kernel_equals_the_general_kernel(case, n):
+    """The transposed convolutions' forward and dX on the large-tile kernel (256 x 256 / 128 x 256 tiles, eight waves) against the
+    DMA-filled general kernel they ran on before: same operands, same k order through the same MFMA -> bit-identical outputs
+    (scattered forward with bias; plain dX; dX with the fused BatchNorm-backward pass 1, whose sums agree to fp32 rounding)."""
+    L = _lib()
+    name, lvl, cin = case
+    cout, h, w = cin // 2, HS[lvl], WS[lvl]
+    H2, W2 = HS[lvl - 1], WS[lvl - 1]
+    oy, ox = (H2 - 2 * h) // 2, (W2 - 2 * w) // 2
+    g = torch.Generator().manual_seed(7 * cin + n)
+    x = bf16r(torch.randn((n, cin, h, w), generator=g))
+    w_d = (torch.randn((cin, cout, 2, 2), generator=g) / cin ** 0.5).cuda()
+    bias_d = torch.randn((cout,), generator=g).cuda()
+    xin = to_nhwc(x)
+    z = L.int_array([0])
+    img_f, img_d = image(L, 3, w_d, cout, cin), image(L, 4, w_d, cout, cin)
+
+    def fwd():
+        cat = torch.zeros((n, H2, W2, 2 * cout), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib.gsd_bf16_conv_dense(C.byref(L.make_nhwc(xin)), img_f.data_ptr(), C.byref(L.make_nhwc(cat, cout, cout)), cin, 4 * cout,
+                                          1, 1, z, z, h, w, cout, oy, ox, bias_d.data_ptr(), None, None, L.stream_ptr()), "convT")
+        torch.cuda.synchronize()
+        return cat
+    a, b = _convT_both_kernels(L, fwd)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"{name} forward"
+    assert float(a[:, oy:oy + 2 * h, ox:ox + 2 * w, cout:].float().abs().max()) > 0
+    del a, b
+
+    gcat = torch.zeros((n, H2, W2, 2 * cout), dtype=torch.bfloat16)
+    gcat[:, oy:oy + 2 * h, ox:ox + 2 * w, cout:] = bf16r(torch.randn((n, 2 * h, 2 * w, cout), generator=g)).to(torch.bfloat16)
+    gcat = gcat.cuda()
+    ty, tx = L.int_array([oy, oy, oy + 1, oy + 1]), L.int_array([ox, ox + 1, ox, ox + 1])
+    dgy = L.make_nhwc(gcat, cout, cout)
+
+    def dx_plain():
+        dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib.gsd_bf16_conv_dense(C.byref(dgy), img_d.data_ptr(), C.byref(L.make_nhwc(dx)), cout, cin, 4, 2, ty, tx, h, w, 0, 0, 0,
+                                          None, None, None, L.stream_ptr()), "convT dX")
+        torch.cuda.synchronize()
+        return dx
+    a, b = _convT_both_kernels(L, dx_plain)
+    assert not bool(torch.isnan(a.float()).any())
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"{name} dX"
+    del a, b
+
+    # fused pass 1 of the BatchNorm+ReLU backward of the unit below: dz = dX where relu(bn(y)) > 0, sums of dz and dz * xhat
+    y = bf16r(torch.randn((n, h, w, cin), generator=g)).to(torch.bfloat16).cuda()
+    coef = [t.cuda() for t in (torch.rand((cin,), generator=g) + 0.5, 0.3 * torch.randn((cin,), generator=g),
+                               0.2 * torch.randn((cin,), generator=g), torch.rand((cin,), generator=g) + 0.5)]
+    dyv = L.make_nhwc(y)
+    mp = L.lib.gsd_bf16_conv_mpad(cin)
+
+    def dx_fused():
+        rows = L.lib.gsd_bf16_conv_dense_partial_rows(n, h, w, cout, cin, 4, 2)
+        assert rows > 0
+        dz = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+        part = torch.full((rows, 2 * mp), float("nan"), device="cuda")
+        bw = L.gsd_bf16_bnbwd()
+        bw.y = C.pointer(dyv)
+        bw.scale, bw.shift, bw.mean, bw.invstd = (t.data_ptr() for t in coef)
+        L.check(L.lib.gsd_bf16_conv_dense(C.byref(dgy), img_d.data_ptr(), C.byref(L.make_nhwc(dz)), cout, cin, 4, 2, ty, tx, h, w, 0, 0, 0,
+                                          None, part.data_ptr(), C.byref(bw), L.stream_ptr()), "convT dX fused")
+        torch.cuda.synchronize()
+        return dz, part.double().sum(dim=0).cpu()
+    (za, sa), (zb, sb) = _convT_both_kernels(L, dx_fused)
+    assert torch.equal(za.view(torch.int16), zb.view(torch.int16)), f"{name} fused dz"
+    assert bool(torch.isfinite(sa[:cin]).all()) and bool(torch.isfinite(sa[mp:mp + cin]).all())
+    # reference sums in fp64 from the stored dz
+    zf, yf = za.double().cpu(), y.double().cpu()
+    xhat = (yf - coef[2].double().cpu()) * coef[3].double().cpu()
+    r1, r2 = zf.sum(dim=(0, 1, 2)), (zf * xhat).sum(dim=(0, 1, 2))
+    scale1, scale2 = float(zf.abs().sum(dim=(0, 1, 2)).max()), float((zf * xhat).abs().sum(dim=(0, 1, 2)).max())
+    for s_ in (sa, sb):
+        assert float((s_[:cin] - r1).abs().max()) <= 2e-5 * scale1, f"{name} sum dz"
+        assert float((s_[mp:mp + cin] - r2).abs().max()) <= 2e-5 * scale2, f"{name} sum dz*xhat"
