@@ -59,6 +59,17 @@ __device__ __forceinline__ void gsd_line_pieces(const unsigned (&lo)[4], const u
 __device__ __forceinline__ int gsd_line_pixel(int j) { return j & 7; }                       // (+ 8 for instruction B)
 __device__ __forceinline__ int gsd_line_channel(int g, int j) { return (j < 8 ? 0 : 32) + 8 * g; }
 
+// One LDS-DMA instruction (global_load_lds_dwordx4: lane i's 16 bytes to lds + 16 i) that the COMPILER does not see.  For kernels
+// that read LDS through an intrinsic without a memory operand (ds_read_b64_tr_b16) while a fill of the other image is in flight:
+// hipcc then assumes the read may alias every outstanding __builtin_amdgcn_global_load_lds and puts s_waitcnt vmcnt(0) in front
+// of each read -- every fill instruction stalls for its own round trip.  The caller orders fills and reads itself
+// (gsd_dma_barrier: explicit vmcnt(0) + barrier); untracked fills only make the compiler's own vmcnt waits more conservative.
+// `lds` must be wave-uniform (M0 holds the LDS base; the compiler re-loads M0 before every use of its own).
+__device__ __forceinline__ void gsd_dma16_untracked(const void* g, void* lds) {
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds;
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(a), "v"(g));
+}
+
 struct NhwcD {
   u16* p;
   long long pitch;

@@ -230,6 +230,180 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
   }
 }
 
+// ---- dense 4-tap form on a large tile (the transposed convolutions' dW) -------------------------------------------------------
+// With no halo to share, the 128 x (32 x 4 taps) tile above moves 32 KB into LDS for 32 MFMAs per wave (its fills cost as much
+// as its arithmetic: 0.16-0.25 PFLOP/s).  Here: eight waves, tile 256 m x (64 n x 4 taps) (or 128 m when M == 128), stages of 64
+// LINEAR pixels (no 2-D tile padding; the stride-2 gather decodes (n,h,w) per fill row), two LDS images: the next stage's
+// fill flies during this stage's 64 MFMAs per wave.  Same transposed-read layout (rows of 32 B x odd), same slab / reduce.
+struct GWBigP {
+  const u16* a;
+  int a_pitch;
+  const u16* b;
+  int b_pitch, Hb, Wb;
+  float* slabs;
+  int P, H, W;          // pixels of the reduction (N*H*W) and the grid they come from
+  float rW, rHW;
+  int M, Ncols;
+  int ty[4], tx[4];
+  int stages_total, splits, mblocks, nblocks, xcd;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512) void gwgrad_big_bf16_kernel(const GWBigP P) {
+  static_assert(WM * WN == 8, "eight waves");
+  constexpr int BM = WM * 64, NTW = 4 / WN;   // n-tiles per wave: 64 n / WN / 16
+  constexpr int BNC = 64, TT = 4, MT = 4, NPX = 64, KS = 2;
+  constexpr int RSA = BM * 2 + 32, RSB = BNC * 2 + 32;     // 32 B x odd
+  constexpr int ABYTES = NPX * RSA, BBYTES = TT * NPX * RSB;
+  constexpr int NA = (ABYTES + 8191) / 8192, NB = (BBYTES + 8191) / 8192;   // DMA instructions per wave (8 waves x 1 KiB)
+  constexpr int IMG = ((ABYTES + 1023) / 1024 + (BBYTES + 1023) / 1024) * 1024;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+
+  const int per_split = P.mblocks * P.nblocks;
+  const int lid = P.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BM, n0 = nb * BNC;
+  const int s_begin = (int)((long long)split * P.stages_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.stages_total / P.splits);
+
+  // ---- DMA bookkeeping: instruction k of this wave fills the 1 KiB piece k*8 + wave of an image; -1: nothing to move (row pad) --
+  int arow[NA], aoffc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const int o = (k * 8 + wave) * 1024 + lane * 16;
+    const int row = o / RSA, piece = (o - row * RSA) >> 4;
+    const bool ok = row < NPX && piece < BM / 8;
+    arow[k] = ok ? row : -1;
+    aoffc[k] = row * P.a_pitch + m0 + piece * 8;
+  }
+  // B rows are a stride-2 gather: element offset of pixel p's 2 x 2 block = ((n*Hb + 2h)*Wb + 2w)*pitch.  Decoding (n,h,w) per fill
+  // instruction costs more vector issue than the stage's MFMAs leave free, so one wave decodes a stage's 64 pixels ONCE into an
+  // LDS table (two stages ahead of its use, two slots) and a fill instruction adds its lane-constant part: tap, columns, piece.
+  int* sTab = reinterpret_cast<int*>(smem + 2 * IMG);   // [2][64]
+  int bpx[NB], bofc[NB];   // table index of the row's pixel (-1: nothing to move), and (ty*Wb + tx)*pitch + n0 + piece*8
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int o = (k * 8 + wave) * 1024 + lane * 16;
+    const int row = o / RSB, piece = (o - row * RSB) >> 4;
+    const bool ok = row < TT * NPX && piece < BNC / 8;
+    const int t = ok ? row / NPX : 0;
+    bpx[k] = ok ? row % NPX : -1;
+    bofc[k] = (P.ty[t] * P.Wb + P.tx[t]) * P.b_pitch + n0 + piece * 8;
+  }
+  auto decode_stage = [&](int stage) {   // one wave: lane = pixel of the stage
+    const int p = min(stage * NPX + lane, P.P - 1);   // beyond the grid A is zero: any valid B row does
+    const int HW = P.H * P.W;
+    int n = (int)((float)p * P.rHW);
+    int r = p - n * HW;
+    if (r < 0) { --n; r += HW; } else if (r >= HW) { ++n; r -= HW; }
+    int h = (int)((float)r * P.rW);
+    int w = r - h * P.W;
+    if (w < 0) { --h; w += P.W; } else if (w >= P.W) { ++h; w -= P.W; }
+    sTab[(stage & 1) * 64 + lane] = ((n * P.Hb + 2 * h) * P.Wb + 2 * w) * P.b_pitch;
+  };
+  constexpr int AOFF = 0, BOFF = ((ABYTES + 1023) / 1024) * 1024;
+  auto dma_a = [&](int k, int stage, int buf) {
+    if (arow[k] < 0) return;
+    const int p0 = stage * NPX;
+    const void* s = (const void*)gsd_zero16w;
+    if (p0 + arow[k] < P.P) s = (const void*)(P.a + (long long)p0 * P.a_pitch + aoffc[k]);
+    gsd_dma16_untracked(s, smem + buf * IMG + AOFF + (k * 8 + wave) * 1024);   // (untracked: see gsd_bf16_common.h)
+  };
+  auto dma_b = [&](int k, int toff, int buf) {   // toff: the table entry of the row's pixel
+    if (bpx[k] < 0) return;
+    gsd_dma16_untracked((const void*)(P.b + toff + bofc[k]), smem + buf * IMG + BOFF + (k * 8 + wave) * 1024);
+  };
+  auto table = [&](int k, int stage) { return bpx[k] >= 0 ? sTab[(stage & 1) * 64 + bpx[k]] : 0; };
+
+  const int a_rd = (4 * g + q) * RSA + (wm * 64 + 4 * p4) * 2;            // + ks*32*RSA + m*32 (+ 16*RSA)
+  const int b_rd = BOFF + (4 * g + q) * RSB + (wn * NTW * 16 + 4 * p4) * 2;   // + (t*NPX + ks*32)*RSB + nt*32 (+ 16*RSB)
+
+  f32x4 acc[MT][TT * NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < TT * NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (s_begin < s_end) {
+    if (wave == 0) decode_stage(s_begin);
+    if (wave == 1 && s_begin + 1 < s_end) decode_stage(s_begin + 1);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NA; ++k) dma_a(k, s_begin, 0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) dma_b(k, table(k, s_begin), 0);
+  }
+  for (int stage = s_begin; stage < s_end; ++stage) {
+    const int buf = (stage - s_begin) & 1;
+    gsd_dma_barrier();   // this stage has landed, every wave has left the other image, the table of stage + 1 is published
+    const unsigned char* Im = smem + buf * IMG;
+    const int fst = stage + 1 < s_end ? stage + 1 : stage;   // after the last stage: a fill nobody reads (no branch)
+    int toff[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) toff[k] = table(k, fst);
+    if (wave == 0 && stage + 2 < s_end) decode_stage(stage + 2);   // into the slot whose readers (the fills of `stage`) are done
+    auto read_a = [&](int ks, u32x4* a) {
+      const unsigned char* ap = Im + a_rd + ks * 32 * RSA;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const u32x2 lo = tr_read_b64(ap + m * 32), hi = tr_read_b64(ap + m * 32 + 16 * RSA);
+        a[m] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+    };
+    auto read_b = [&](int st) {   // st = (ks, t, nt)
+      const int ks = st / (TT * NTW), tn = st - ks * (TT * NTW), t = tn / NTW, nt = tn - t * NTW;
+      const unsigned char* bp = Im + b_rd + (t * NPX + ks * 32) * RSB + nt * 32;
+      const u32x2 lo = tr_read_b64(bp), hi = tr_read_b64(bp + 16 * RSB);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    constexpr int NST = KS * TT * NTW;          // steps of 4 MFMAs
+    constexpr int NSL = NA + NB;                // DMA slots of the next stage's fill
+    static_assert(NST >= NSL, "a fill slot per step at most");
+    constexpr int GAP = NST / NSL;
+    u32x4 a[2][MT], b[3];
+    read_a(0, a[0]);
+    b[0] = read_b(0);
+    b[1] = read_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int ks = st / (TT * NTW), tn = st - ks * (TT * NTW);
+      if (st + 2 < NST) b[(st + 2) % 3] = read_b(st + 2);
+      if (tn == TT * NTW - 2 && ks + 1 < KS) read_a(ks + 1, a[(ks + 1) & 1]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][tn] = mfma_bf16(a[ks & 1][m], b[st % 3], acc[m][tn]);
+      if (st % GAP == GAP - 1) {   // one slot of the next stage's fill
+        const int sl = st / GAP;
+        if (sl < NA) dma_a(sl, fst, buf ^ 1);
+        else if (sl < NSL) dma_b(sl - NA, toff[sl - NA], buf ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  gsd_dma_barrier();   // the last (unread) fill must have landed before the block gives its LDS back
+
+  // ---- slab store: slab[split][t][m][n] ------------------------------------------------------------------------------
+#pragma unroll
+  for (int tn = 0; tn < TT * NTW; ++tn) {
+    const int t = tn / NTW, nt = tn - t * NTW;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int mr = m0 + wm * 64 + m * 16 + g * 4 + e;
+        const int col = n0 + wn * NTW * 16 + nt * 16 + li;
+        if (mr < P.M && col < P.Ncols) P.slabs[(((size_t)split * TT + t) * P.M + mr) * P.Ncols + col] = acc[m][tn][e];
+      }
+  }
+}
+
 // out[(m * NcOut + n) * T + t] = sum over splits of slab[split][t][m][n]   (n < NcOut <= Ncols)
 __global__ void gwgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int splits, int T, int M, int Ncols,
                                      int NcOut) {
@@ -306,9 +480,57 @@ int launch_w(const GWgradP& P, int grid, size_t lds, hipStream_t st, const char*
 
 }  // namespace
 
+namespace {
+
+struct BigPlan {
+  bool ok;
+  int BM, mblocks, nblocks, stages_total, splits;
+  int64_t slab_elems;
+};
+
+// the large-tile form takes 4 dense taps with M % 128 == 0 and Ncols % 64 == 0 (GSD_BF16_WGRAD_BIG=0: never)
+BigPlan make_bigplan(int ntaps, int N, int H, int W, int M, int Ncols) {
+  BigPlan p;
+  p.ok = false;
+  p.slab_elems = 0;
+  const long long P = (long long)N * H * W;
+  if (ntaps != 4 || M % 128 != 0 || Ncols % 64 != 0 || P >= (1 << 24) || gsd_env_int("GSD_BF16_WGRAD_BIG", 1) == 0) return p;
+  p.BM = M % 256 == 0 ? 256 : 128;
+  p.mblocks = M / p.BM;
+  p.nblocks = Ncols / 64;
+  p.stages_total = (int)((P + 63) / 64);
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  int splits = cus / (p.mblocks * p.nblocks);   // one block per CU (its two LDS images fill the CU)
+  if (splits < 1) splits = 1;
+  if (splits > p.stages_total) splits = p.stages_total;
+  p.splits = splits;
+  p.slab_elems = (int64_t)splits * 4 * M * Ncols;
+  p.ok = true;
+  return p;
+}
+
+template <int WM, int WN>
+int launch_big(const GWBigP& P, int grid, hipStream_t st) {
+  constexpr int BM = WM * 64;
+  constexpr size_t img = ((size_t)(64 * (BM * 2 + 32) + 1023) / 1024 + (size_t)(4 * 64 * (64 * 2 + 32) + 1023) / 1024) * 1024;
+  static gsd_attr_once big_lds;
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gwgrad_big_bf16_kernel<WM, WN>)); e != hipSuccess) {
+    gsd_set_error("gsd_bf16_wgrad (large tile): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
+  }
+  GSD_REQUIRE(2 * img + 512 <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_bf16_wgrad (large tile): LDS %zu B too large", 2 * img + 512);
+  hipLaunchKernelGGL((gwgrad_big_bf16_kernel<WM, WN>), dim3(grid), dim3(512), 2 * img + 512, st, P);
+  GSD_LAUNCH_CHECK("gsd_bf16_wgrad (large tile)");
+  return GSD_OK;
+}
+
+}  // namespace
+
 extern "C" int64_t gsd_bf16_wgrad_workspace(int ntaps, int N, int H, int W, int M, int Ncols) {
   if (ntaps < 1 || ntaps > 9 || N <= 0 || H <= 0 || W <= 0 || M <= 0 || Ncols <= 0) return 0;
-  return make_wplan(ntaps == 9, ntaps, N, H, W, M, Ncols).slab_elems;
+  const int64_t a = make_wplan(ntaps == 9, ntaps, N, H, W, M, Ncols).slab_elems, b = make_bigplan(ntaps, N, H, W, M, Ncols).slab_elems;
+  return a > b ? a : b;   // (the large-tile form also needs stride 2 and in-buffer taps: whichever form runs, this is enough)
 }
 
 extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, int stride, const int* ty, const int* tx,
@@ -328,6 +550,33 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
       GSD_REQUIRE(ty[t] == t / 3 - 1 && tx[t] == t % 3 - 1, GSD_ERR_UNSUPPORTED, "gsd_bf16_wgrad: 9 taps must be the 3x3 p1 stencil");
   }
   const int M = a->C, Ncols = b->C;
+  const BigPlan bp = make_bigplan(ntaps, a->N, a->H, a->W, M, Ncols);
+  if (bp.ok && stride == 2 && (long long)a->N * a->H * a->W * a->pitch < 2147483647LL && (long long)b->N * b->H * b->W * b->pitch < 2147483647LL) {
+    bool inside = true;   // the large-tile form gathers without a zero line: every tap of every pixel must be in b's buffer
+    for (int t = 0; t < 4; ++t) inside = inside && ty[t] >= 0 && tx[t] >= 0 && 2 * (a->H - 1) + ty[t] < b->H && 2 * (a->W - 1) + tx[t] < b->W;
+    if (inside) {
+      GSD_REQUIRE(workspace_elems >= bp.slab_elems, GSD_ERR_WORKSPACE, "gsd_bf16_wgrad: workspace %lld < %lld elements",
+                  (long long)workspace_elems, (long long)bp.slab_elems);
+      GWBigP Q;
+      Q.a = (const u16*)a->ptr; Q.a_pitch = (int)a->pitch;
+      Q.b = (const u16*)b->ptr; Q.b_pitch = (int)b->pitch; Q.Hb = b->H; Q.Wb = b->W;
+      Q.slabs = workspace;
+      Q.P = a->N * a->H * a->W; Q.H = a->H; Q.W = a->W;
+      Q.rW = 1.0f / (float)a->W; Q.rHW = 1.0f / (float)(a->H * a->W);
+      Q.M = M; Q.Ncols = Ncols;
+      for (int t = 0; t < 4; ++t) { Q.ty[t] = ty[t]; Q.tx[t] = tx[t]; }
+      Q.stages_total = bp.stages_total; Q.splits = bp.splits; Q.mblocks = bp.mblocks; Q.nblocks = bp.nblocks;
+      Q.xcd = gsd_env_int("GSD_BF16_XCD", 1) != 0 ? 1 : 0;
+      const int grid = bp.splits * bp.mblocks * bp.nblocks;
+      const int rc = bp.BM == 256 ? launch_big<4, 2>(Q, grid, (hipStream_t)stream) : launch_big<2, 4>(Q, grid, (hipStream_t)stream);
+      if (rc) return rc;
+      const long long per = (long long)4 * M * Ncols;
+      const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+      hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, bp.splits, 4, M, Ncols, ncols_out);
+      GSD_LAUNCH_CHECK("gsd_bf16_wgrad reduce");
+      return GSD_OK;
+    }
+  }
   const WPlan pl = make_wplan(halo, ntaps, a->N, a->H, a->W, M, Ncols);
   GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_bf16_wgrad: workspace %lld < %lld elements",
               (long long)workspace_elems, (long long)pl.slab_elems);

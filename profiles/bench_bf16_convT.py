@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The four ConvTranspose2d(k2, s2) of the decoder at batch N in the bf16 engine's form: forward (scatter + bias), dX with the fused
-BatchNorm-backward pass 1, dW -- each under GSD_BF16_CTGEMM=0 (general DMA-filled kernel) and =1 (large-tile kernel)."""
+BatchNorm-backward pass 1, dW -- each under GSD_BF16_CTGEMM / GSD_BF16_WGRAD_BIG = 0 (general DMA-filled kernels) and = 1 (large-tile kernels)."""
 import ctypes as C
 import os
 import sys
@@ -72,7 +72,7 @@ for lvl, cin in LEVELS:
     line = f"up level {lvl}: {cin:4d} -> {cout:3d} @ {h}x{w}:"
     for what, fn in (("fwd", fwd), ("dX+bn", dx), ("dW", dwf)):
         for v in ("0", "1"):
-            os.environ["GSD_BF16_CTGEMM"] = v
+            os.environ["GSD_BF16_CTGEMM"] = os.environ["GSD_BF16_WGRAD_BIG"] = v
             ms = timed(fn)
             tot[(what, v)] = tot.get((what, v), 0.0) + ms
             line += f"  {what}[{v}] {ms:.3f} ms ({fl / ms / 1e9:.0f} TF)"
