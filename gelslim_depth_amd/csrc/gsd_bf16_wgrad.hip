@@ -405,19 +405,57 @@ __global__ __launch_bounds__(512) void gwgrad_big_bf16_kernel(const GWBigP P) {
 }
 
 // out[(m * NcOut + n) * T + t] = sum over splits of slab[split][t][m][n]   (n < NcOut <= Ncols)
-__global__ void gwgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int splits, int T, int M, int Ncols,
-                                     int NcOut) {
+// SG > 1: the splits of an element are summed by SG threads (split k goes to thread k % SG, each adds its own in ascending order,
+// the SG partial sums are added in ascending order): a fixed order, so still bitwise reproducible.  With hundreds of splits of
+// a small dW (64 x 64 x 9: 36,864 elements, 512 splits) one thread per element is 144 blocks each walking 512 dependent loads.
+template <int SG>
+__global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int splits, int T, int M,
+                                                            int Ncols, int NcOut) {
+  constexpr int EPB = 256 / SG;   // elements per block
+  __shared__ float part[SG][EPB];
   const long long per = (long long)T * M * Ncols;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(e % Ncols);
-    const long long r2 = e / Ncols;
-    const int m = (int)(r2 % M);
-    const int t = (int)(r2 / M);
-    if (n < NcOut) {
-      float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * per + e];
-      out[((size_t)m * NcOut + n) * T + t] = s;
+  const int el = threadIdx.x % EPB, sg = threadIdx.x / EPB;
+  for (long long e0 = (long long)blockIdx.x * EPB; e0 < per; e0 += (long long)gridDim.x * EPB) {
+    const long long e = e0 + el;
+    float s = 0.f;
+    if (e < per) {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four loads in flight; combined in a fixed order
+      int k = sg;
+      for (; k + 3 * SG < splits; k += 4 * SG) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += slabs[(size_t)(k + u * SG) * per + e];
+      }
+      for (; k < splits; k += SG) s4[0] += slabs[(size_t)k * per + e];
+      s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
+    if (SG > 1) {
+      part[sg][el] = s;
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int g = 1; g < SG; ++g) s += part[g][el];
+      }
+    }
+    if (sg == 0 && e < per) {
+      const int n = (int)(e % Ncols);
+      const long long r2 = e / Ncols;
+      const int m = (int)(r2 % M);
+      const int t = (int)(r2 / M);
+      if (n < NcOut) out[((size_t)m * NcOut + n) * T + t] = s;
+    }
+    if (SG > 1) __syncthreads();
+  }
+}
+
+// the reduce launch: many splits of a small dW -> 8 threads per element
+static void launch_reduce(const float* slabs, float* out, int splits, int T, int M, int Ncols, int NcOut, hipStream_t st) {
+  const long long per = (long long)T * M * Ncols;
+  if (splits >= 32 && per <= (1 << 20)) {
+    const int grid = (int)(ceil_div64(per, 32) < 8192 ? ceil_div64(per, 32) : 8192);
+    hipLaunchKernelGGL(gwgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, st, slabs, out, splits, T, M, Ncols, NcOut);
+  } else {
+    const int grid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
+    hipLaunchKernelGGL(gwgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, slabs, out, splits, T, M, Ncols, NcOut);
   }
 }
 
@@ -570,9 +608,7 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
       const int grid = bp.splits * bp.mblocks * bp.nblocks;
       const int rc = bp.BM == 256 ? launch_big<4, 2>(Q, grid, (hipStream_t)stream) : launch_big<2, 4>(Q, grid, (hipStream_t)stream);
       if (rc) return rc;
-      const long long per = (long long)4 * M * Ncols;
-      const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-      hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, bp.splits, 4, M, Ncols, ncols_out);
+      launch_reduce(workspace, dw, bp.splits, 4, M, Ncols, ncols_out, (hipStream_t)stream);
       GSD_LAUNCH_CHECK("gsd_bf16_wgrad reduce");
       return GSD_OK;
     }
@@ -599,10 +635,7 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
   else if (ntaps == 4) rc = pl.wide ? launch_w<0, 4, 1, 4>(P, grid, pl.lds, st, "gsd_bf16_wgrad") : launch_w<0, 4, 2, 2>(P, grid, pl.lds, st, "gsd_bf16_wgrad");
   else rc = pl.wide ? launch_w<0, 1, 1, 4>(P, grid, pl.lds, st, "gsd_bf16_wgrad") : launch_w<0, 1, 2, 2>(P, grid, pl.lds, st, "gsd_bf16_wgrad");
   if (rc) return rc;
-  const long long per = (long long)ntaps * M * Ncols;
-  const int rgrid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
-  hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, ntaps, M, Ncols,
-                     ncols_out);
+  launch_reduce(workspace, dw, pl.splits, ntaps, M, Ncols, ncols_out, (hipStream_t)stream);
   GSD_LAUNCH_CHECK("gsd_bf16_wgrad reduce");
   return GSD_OK;
 }

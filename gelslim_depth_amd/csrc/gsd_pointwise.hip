@@ -329,12 +329,26 @@ __device__ __forceinline__ bool rf_block_sums(const float* __restrict__ part, in
   const int c = blockIdx.x * RF_CH + (threadIdx.x & (RF_CH - 1)), rl = threadIdx.x / RF_CH;
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += RF_LANES) {
+  if (c < C) {
+    int r = rl;
+    for (; r + 3 * RF_LANES < rows; r += 4 * RF_LANES) {   // four rows' loads in flight (thousands of rows from the stand-alone reduce kernels); same order of additions
+      float f[4][NV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) f[u][i] = off[i] >= 0 ? part[(size_t)(r + u * RF_LANES) * ld + off[i] + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (off[i] >= 0) v[i] += (double)f[u][i];
+    }
+    for (; r < rows; r += RF_LANES) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
         if (off[i] >= 0) v[i] += (double)part[(size_t)r * ld + off[i] + c];
     }
+  }
   __shared__ double red[NV][RF_LANES / 4][RF_CH];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
