@@ -62,33 +62,64 @@ __global__ void weight_image_kernel(int mode, const float* __restrict__ w, int C
 // every image of a step in one launch (blockIdx.y = job): as 43 separate launches between the convolutions they are latency,
 // 10 us each
 constexpr int WJOBS = 32;
-constexpr int WCHUNK = 16384;   // elements per block: a job gets blocks in proportion to its size
+constexpr int WPAIRS = 2048;   // (row, k) pairs per block: a job gets blocks in proportion to its size
 struct WJob { const float* w; u16* out; int mode, Cout, Cin, first_block; WImg d; };
 struct WJobs { WJob j[WJOBS]; int n; };
+// A thread owns one (row m, column k) of an image, k fastest, and walks its taps: the fp32 source of a pair's taps is ONE contiguous
+// run (9 floats of a 3x3 kernel, 4 of a 2x2 one) and every tap's store is coalesced over k -- an element-major walk reads
+// 4 bytes at a stride of 36 and pays three 64-bit divisions per element.  ConvT forward (mode 3, m = (q, co)): the pair is
+// (co, k) and its four q rows, when the image has no padded rows.
+static inline __host__ __device__ int wimg_pairs(int mode, int Cout, const WImg& d) {
+  return (mode == 3 && d.Mp == 4 * Cout) ? Cout * d.Kp : d.Mp * d.Kp;
+}
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // the flat parameter arena aligns tensors to 4 bytes only
 __global__ __launch_bounds__(256) void weight_images_kernel(WJobs jobs) {
   int q = 0;
   while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].first_block) ++q;   // (<= 32 jobs: a linear search)
   const WJob& J = jobs.j[q];
-  const long long base = (long long)((int)blockIdx.x - J.first_block) * WCHUNK;
-  const long long total = (long long)J.d.T * J.d.Mp * J.d.Kp;
-  const long long end = base + WCHUNK < total ? base + WCHUNK : total;
-  WImg d = J.d;
-  // the element loop of weight_image_elements over [base, end)
-  for (long long e = base + threadIdx.x; e < end; e += 256) {
-    const int k = (int)(e % d.Kp);
-    const int m = (int)((e / d.Kp) % d.Mp);
-    const int t = (int)(e / ((long long)d.Kp * d.Mp));
-    float v = 0.f;
-    if (m < d.M && k < d.K) {
-      switch (J.mode) {
-        case 0: v = J.w[((size_t)m * J.Cin + k) * 9 + t]; break;
-        case 1: v = J.w[((size_t)k * J.Cin + m) * 9 + (8 - t)]; break;
-        case 2: v = J.w[(size_t)m * J.Cin * 9 + k]; break;
-        case 3: { const int qq = m / J.Cout, co = m - qq * J.Cout; v = J.w[((size_t)k * J.Cout + co) * 4 + qq]; break; }
-        default: v = J.w[((size_t)m * J.Cout + k) * 4 + t]; break;
+  const WImg d = J.d;
+  const bool quad = J.mode == 3 && d.Mp == 4 * J.Cout;
+  const int pairs = quad ? J.Cout * d.Kp : d.Mp * d.Kp;
+  const int base = ((int)blockIdx.x - J.first_block) * WPAIRS;
+  const int end = base + WPAIRS < pairs ? base + WPAIRS : pairs;
+  const size_t plane = (size_t)d.Mp * d.Kp;
+  for (int pe = base + threadIdx.x; pe < end; pe += 256) {
+    const int m = pe / d.Kp, k = pe - m * d.Kp;
+    if (quad) {   // m = co
+      f4u v = f4u{0.f, 0.f, 0.f, 0.f};
+      if (k < d.K) v = *reinterpret_cast<const f4u*>(J.w + ((size_t)k * J.Cout + m) * 4);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) J.out[(size_t)(qq * J.Cout + m) * d.Kp + k] = f32_to_bf16(v[qq]);
+      continue;
+    }
+    const bool in = m < d.M && k < d.K;
+    switch (J.mode) {
+      case 0: {
+        const float* src = J.w + ((size_t)m * J.Cin + k) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) J.out[t * plane + pe] = f32_to_bf16(in ? src[t] : 0.f);
+        break;
+      }
+      case 1: {
+        const float* src = J.w + ((size_t)k * J.Cin + m) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) J.out[t * plane + pe] = f32_to_bf16(in ? src[8 - t] : 0.f);
+        break;
+      }
+      case 2: J.out[pe] = f32_to_bf16(in ? J.w[(size_t)m * J.Cin * 9 + k] : 0.f); break;
+      case 3: {
+        const int qq = m / J.Cout, co = m - qq * J.Cout;
+        J.out[pe] = f32_to_bf16(in ? J.w[((size_t)k * J.Cout + co) * 4 + qq] : 0.f);
+        break;
+      }
+      default: {
+        f4u v = f4u{0.f, 0.f, 0.f, 0.f};
+        if (in) v = *reinterpret_cast<const f4u*>(J.w + ((size_t)m * J.Cout + k) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) J.out[t * plane + pe] = f32_to_bf16(v[t]);
+        break;
       }
     }
-    J.out[e] = f32_to_bf16(v);
   }
 }
 
@@ -512,7 +543,7 @@ __global__ __launch_bounds__(256) void channel_sums_stage2(const float* __restri
   if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-int pick_pixb(int N, int HW, int target_blocks = 2048) {
+int pick_pixb(int N, int HW, int target_blocks = 1024) {   // (2048 until round 4: half the partial rows for the finalize launch behind it, same pass time)
   long long pixb = ((long long)N * HW + target_blocks - 1) / target_blocks;
   pixb = (pixb + 31) / 32 * 32;
   return (int)(pixb < 32 ? 32 : pixb);
@@ -557,7 +588,8 @@ extern "C" int gsd_bf16_weight_images(const gsd_bf16_wimg_job* jobs, int n, void
       const gsd_bf16_wimg_job& q = jobs[base + i];
       const WImg d = wimg_dims(q.mode, q.Cout, q.Cin);
       a.j[i] = WJob{q.w, (u16*)q.out, q.mode, q.Cout, q.Cin, (int)blocks, d};
-      blocks += ceil_div64((long long)d.T * d.Mp * d.Kp, WCHUNK);
+      GSD_REQUIRE((long long)d.Mp * d.Kp < 2147483647LL, GSD_ERR_UNSUPPORTED, "gsd_bf16_weight_images: image %d too large", base + i);
+      blocks += ceil_div(wimg_pairs(q.mode, q.Cout, d), WPAIRS);
     }
     GSD_REQUIRE(blocks < 2147483647LL, GSD_ERR_UNSUPPORTED, "gsd_bf16_weight_images: images too large");
     hipLaunchKernelGGL(weight_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -136,7 +136,7 @@ def test_weight_images_batched_equal_one_by_one():
     L = _lib()
     g = torch.Generator().manual_seed(99)
     shapes = [(0, 64, 3), (0, 64, 64), (1, 64, 64), (2, 64, 3), (3, 32, 64), (4, 32, 64), (0, 128, 96), (1, 128, 96), (0, 48, 160),
-              (3, 64, 128)] * 4
+              (3, 64, 128), (3, 24, 64), (4, 24, 40)] * 3 + [(0, 64, 3), (1, 512, 256), (3, 256, 512), (4, 256, 512)]
     jobs = (L.gsd_bf16_wimg_job * len(shapes))()
     keep, one_by_one = [], []
     for i, (mode, cout, cin) in enumerate(shapes):
