@@ -148,6 +148,7 @@ SIGNATURES = {
     "gsd_bf16_bn_apply_pool": (_I, [_NHWC, _P, _P, _NHWC, _NHWC, _P]),
     "gsd_bf16_maxpool2": (_I, [_NHWC, _NHWC, _P]),
     "gsd_bf16_conv1x1_out": (_I, [_NHWC, _P, _P, _I, _P, _P]),
+    "gsd_bf16_bn_relu_conv1x1_out": (_I, [_NHWC, _P, _P, _P, _P, _I, _P, _P]),
     "gsd_bf16_bn_bwd_partial_rows": (_I, [_I, _I, _I]),
     "gsd_bf16_bn_bwd_reduce": (_I, [_I, _NHWC, _P, _P, _P, _P, _NHWC, _NHWC, _NHWC, _P, _P, _NHWC, _P, _P]),
     "gsd_bf16_bn_bwd_apply": (_I, [_NHWC, _NHWC, _P, _P, _P, _P, _P, _P]),

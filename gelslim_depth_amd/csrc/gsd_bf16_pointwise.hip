@@ -239,8 +239,12 @@ __global__ __launch_bounds__(256) void maxpool2_bf16_kernel(NhwcD a, NhwcD o) {
 constexpr int OUTC_MAXK = 4;
 // 8 lanes per pixel, each 16-byte pieces c8, c8+8, ... of the pixel's channels (a wave reads 8 pixels x 128 B contiguous
 // per pass for C = 64); the 8 partial dot products are combined with DPP-free xor shuffles inside the 8-lane group.
+// BN (template): `a` is the RAW output of the last unit and scale / shift its BatchNorm coefficients -- the activation
+// bf16(relu(y * scale + shift)), exactly what gsd_bf16_bn_apply would have stored, is formed in registers and never written.
+template <bool BN>
 __global__ __launch_bounds__(256) void conv1x1_out_bf16_kernel(NhwcD a, const float* __restrict__ w, const float* __restrict__ b,
-                                                               int K, float* __restrict__ out) {
+                                                               int K, float* __restrict__ out, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift) {
   const long long HW = (long long)a.H * a.W;
   const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -253,6 +257,10 @@ __global__ __launch_bounds__(256) void conv1x1_out_bf16_kernel(NhwcD a, const fl
     for (int c = sub * 8; c < a.C; c += 64) {
       float f[8];
       unpack8(ld16(src + c), f);
+      if (BN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(f[i], scale[c + i], shift[c + i]), 0.f)));
+      }
 #pragma unroll
       for (int k = 0; k < OUTC_MAXK; ++k)
         if (k < K) {
@@ -655,9 +663,20 @@ extern "C" int gsd_bf16_conv1x1_out(const gsd_nhwc* a, const float* w, const flo
   if (int e = check_c8(a, "gsd_bf16_conv1x1_out a")) return e;
   GSD_REQUIRE(w && out && K >= 1 && K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED, "gsd_bf16_conv1x1_out: n_classes must be in [1,%d]",
               OUTC_MAXK);
-  hipLaunchKernelGGL(conv1x1_out_bf16_kernel, dim3((unsigned)ceil_div64(npix_of(a) * 8, 256)), dim3(256), 0, (hipStream_t)stream,
-                     to_nhwc(*a), w, bias, K, out);
+  hipLaunchKernelGGL(conv1x1_out_bf16_kernel<false>, dim3((unsigned)ceil_div64(npix_of(a) * 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     to_nhwc(*a), w, bias, K, out, nullptr, nullptr);
   GSD_LAUNCH_CHECK("gsd_bf16_conv1x1_out");
+  return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_relu_conv1x1_out(const gsd_nhwc* y, const float* scale, const float* shift, const float* w, const float* bias,
+                                            int K, float* out, void* stream) {
+  if (int e = check_c8(y, "gsd_bf16_bn_relu_conv1x1_out y")) return e;
+  GSD_REQUIRE(scale && shift && w && out && K >= 1 && K <= OUTC_MAXK, GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_bn_relu_conv1x1_out: null argument or n_classes outside [1,%d]", OUTC_MAXK);
+  hipLaunchKernelGGL(conv1x1_out_bf16_kernel<true>, dim3((unsigned)ceil_div64(npix_of(y) * 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     to_nhwc(*y), w, bias, K, out, scale, shift);
+  GSD_LAUNCH_CHECK("gsd_bf16_bn_relu_conv1x1_out");
   return GSD_OK;
 }
 

@@ -186,6 +186,9 @@ class UNetEngineBF16:
         self.apply_pool = os.environ.get("GSD_BF16_APPLY_POOL", "1") != "0"
         # 64 -> 64 convolutions (forward and dX) on the weights-resident kernel (gsd_bf16_c64.hip); GSD_BF16_C64=0: the DMA-filled one
         self.c64 = os.environ.get("GSD_BF16_C64", "1") != "0"
+        # train mode: the last unit's BatchNorm + ReLU rides in the 1x1 output convolution (gsd_bf16_bn_relu_conv1x1_out): its
+        # activation has no other reader (the backward recomputes it from the raw output) and is never written.  GSD_BF16_FUSED_OUT=0: apply + conv
+        self.fused_out = os.environ.get("GSD_BF16_FUSED_OUT", "1") != "0"
         self.side_dw = train and os.environ.get("GSD_BF16_SIDE_DW", "1") != "0"
         self.side = torch.cuda.Stream(device=dev) if self.side_dw else None
         self.wspace_side = torch.empty((max(max_ws, 64),), **f32) if self.side_dw else None
@@ -347,7 +350,13 @@ class UNetEngineBF16:
                   "bn_finalize")
         self._nbt.append(P[u.nbtname])   # int64 counters: one libgsd launch for all of them at the end of the forward
 
+    def _last_unit(self) -> _Unit:
+        return self.dec[-1][1] if self.L > 0 else self.enc[0][1]
+
     def _apply(self, u: _Unit, dy, st: int, pool_to: Optional[torch.Tensor]) -> None:
+        """train mode: a = relu(bn(y)) (+ the max-pool of a skip unit in the same pass)."""
+        if self.fused_out and u is self._last_unit():
+            return      # forward() folds it into the output convolution
         if pool_to is not None:
             dp = L.make_nhwc(pool_to)
             check(lib.gsd_bf16_bn_apply_pool(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), C.byref(dp), st),
@@ -416,8 +425,13 @@ class UNetEngineBF16:
             self._nbt = []
         if out is None:
             out = torch.empty((n, self.n_classes, h, w), device=x.device, dtype=torch.float32)
-        check(lib.gsd_bf16_conv1x1_out(C.byref(cur.a), P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(),
-                                       self.n_classes, out.data_ptr(), st), "conv1x1_out")
+        if train and self.fused_out:
+            check(lib.gsd_bf16_bn_relu_conv1x1_out(C.byref(L.make_nhwc(cur.y)), cur.scale.data_ptr(), cur.shift.data_ptr(),
+                                                   P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(), self.n_classes,
+                                                   out.data_ptr(), st), "bn_relu_conv1x1_out")
+        else:
+            check(lib.gsd_bf16_conv1x1_out(C.byref(cur.a), P["outc.conv.weight"].data_ptr(), P["outc.conv.bias"].data_ptr(),
+                                           self.n_classes, out.data_ptr(), st), "conv1x1_out")
         return out
 
     # ------------------------------------------------------------------ backward

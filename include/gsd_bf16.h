@@ -172,6 +172,11 @@ int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream);
 
 /* OutConv: out (N,K,H,W) fp32 NCHW = conv1x1(a; w (K,C), bias) (unet.py:54), K <= 4. */
 int gsd_bf16_conv1x1_out(const gsd_nhwc* a, const float* w, const float* bias, int K, float* out, void* stream);
+/* The same with the last unit's BatchNorm + ReLU folded in (train mode): y is that unit's RAW output, scale / shift its batch
+ * coefficients; the activation bf16(relu(y*scale+shift)) -- bit for bit what gsd_bf16_bn_apply stores -- is formed in registers
+ * and never written (its only other reader, the backward's gsd_bf16_bn_bwd_reduce mode 2, recomputes it from y too). */
+int gsd_bf16_bn_relu_conv1x1_out(const gsd_nhwc* y, const float* scale, const float* shift, const float* w, const float* bias, int K,
+                                 float* out, void* stream);
 
 /* BatchNorm+ReLU backward, pass 1 (+ the adjoining max-pool / output-conv backward), as gsd_bn_bwd_reduce in gsd.h:
  *   da = g                                  (mode 0)

@@ -109,6 +109,14 @@ def test_bf16_step_layerwise_and_vs_emulation(dims, n, h, w):
         assert torch.allclose(u.mean.cpu().double(), mean, rtol=1e-4, atol=1e-5), u.gname
         assert torch.allclose(u.invstd.cpu().double(), 1.0 / torch.sqrt(var + 1e-5), rtol=1e-4), u.gname
         a_ref = torch.relu(y * u.scale.cpu()[None, :, None, None] + u.shift.cpu()[None, :, None, None])
+        if bool(getattr(eng, "fused_out", False)) and u is eng._last_unit():
+            # the last unit's activation is formed inside the output convolution (gsd_bf16_bn_relu_conv1x1_out) and never stored:
+            # store it here with the apply kernel it replaces, for the checks below that read it
+            import ctypes as C
+            from gelslim_depth_amd import _lib as GL
+            GL.check(GL.lib.gsd_bf16_bn_apply(C.byref(GL.make_nhwc(u.y)), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1,
+                                              GL.stream_ptr()), "bn_apply")
+            torch.cuda.synchronize()
         _ulp_close(_nchw(u.a_t, u.a_off, u.cout), a_ref, f"{u.gname} apply")
         # backward: u.g holds dy (gradient w.r.t. the raw conv output) after the step
         dy = _nchw(u.g)
@@ -316,4 +324,29 @@ def test_bf16_c64_kernel_tracks_the_dma_kernel_step(dims, n, h, w, monkeypatch):
     assert abs(l0[0] - l1[0]) <= 1e-4 * abs(l0[0])
     for k in b0:
         assert rel_l1(b1[k].cpu().numpy(), b0[k].cpu().numpy()) < 2e-3, k
+    assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
+
+
+@pytest.mark.parametrize("dims", [[32, 64, 128], [64]])
+def test_bf16_output_conv_with_the_last_batchnorm_folded_in_changes_nothing(dims, monkeypatch):
+    """GSD_BF16_FUSED_OUT (default on): the last unit's BatchNorm + ReLU is formed inside the 1x1 output convolution instead of
+    being stored by an apply pass: the same bf16 activation values enter the same dot products, so two train steps agree bit for
+    bit (loss, gradients, parameters, BatchNorm buffers)."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FUSED_OUT": "0"})
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_FUSED_OUT": "1"})
+    assert not e0.fused_out and e1.fused_out
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
+
+
+@pytest.mark.parametrize("dims,n,h,w", [([64, 128, 256], 2, 40, 132), ([64, 128, 256, 512], 1, 64, 88)])
+def test_bf16_large_tile_transposed_convolutions_track_the_general_kernels(dims, n, h, w, monkeypatch):
+    """GSD_BF16_CTGEMM / GSD_BF16_WGRAD_BIG (default on): the transposed convolutions' forward, dX (with the fused BatchNorm pass 1)
+    and dW on the large-tile kernels.  Forward and dX outputs are bit-identical to the general kernels' (op tests); the BatchNorm
+    sums of the fused pass and the split-K order of dW differ, so at network level the step agrees like two orders of one sum."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_CTGEMM": "0", "GSD_BF16_WGRAD_BIG": "0"}, steps=1, n=n, h=h, w=w)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_CTGEMM": "1", "GSD_BF16_WGRAD_BIG": "1"}, steps=1, n=n, h=h, w=w)
+    assert abs(l0[0] - l1[0]) <= 1e-6 * abs(l0[0])          # the forward is bit-identical
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k                # ... and so are the running statistics it leaves
     assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
