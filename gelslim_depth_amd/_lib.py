@@ -146,6 +146,8 @@ SIGNATURES = {
     "gsd_bf16_conv3x3_c64": (_I, [_NHWC, _P, _NHWC, _P, _BNBWD, _P]),
     "gsd_bf16_bn_apply": (_I, [_NHWC, _P, _P, _NHWC, _I, _P]),
     "gsd_bf16_bn_apply_pool": (_I, [_NHWC, _P, _P, _NHWC, _NHWC, _P]),
+    "gsd_bf16_bn_apply_pool_idx": (_I, [_NHWC, _P, _P, _NHWC, _NHWC, _P, _P]),
+    "gsd_bf16_bn_bwd_reduce_pool_idx": (_I, [_NHWC, _P, _P, _P, _P, _NHWC, _P, _NHWC, _NHWC, _P, _P]),
     "gsd_bf16_maxpool2": (_I, [_NHWC, _NHWC, _P]),
     "gsd_bf16_conv1x1_out": (_I, [_NHWC, _P, _P, _I, _P, _P]),
     "gsd_bf16_bn_relu_conv1x1_out": (_I, [_NHWC, _P, _P, _P, _P, _I, _P, _P]),

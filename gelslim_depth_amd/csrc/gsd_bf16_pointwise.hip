@@ -177,8 +177,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(NhwcD y, const float* __r
 // writes their four activations (into the concat buffer's skip slice) and, where the window is whole (floor mode drops an
 // odd last row / column), their maximum.  Rounding to bf16 is monotonic, so max of the rounded activations == rounded max:
 // bit-identical to gsd_bf16_bn_apply + gsd_bf16_maxpool2.
+// idx (or null): one u16 per (window, 8-channel group), [N][H/2][W/2][C/8]: two bits per channel = which of the window's four
+// activations the pool took -- the first maximum in (0,0),(0,1),(1,0),(1,1) order of the STORED bf16 values, what the backward
+// (bn_bwd_reduce_pool_bf16_kernel) otherwise finds by re-reading the four activations (4 x 16 B per thread instead of 2 B).
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(NhwcD y, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            NhwcD a, NhwcD o, int wh, int ww) {
+                                                            NhwcD a, NhwcD o, int wh, int ww, u16* __restrict__ idx) {
   const int groups = y.C >> 3;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)y.N * wh * ww * groups) return;
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(NhwcD y, const float
   raw[2] = row2 ? ld16(y.p + (pix + y.W) * y.pitch + gk * 8) : raw[0];
   raw[3] = (row2 && col2) ? ld16(y.p + (pix + y.W + 1) * y.pitch + gk * 8) : raw[0];
   float m[8];
+  uint4 pk[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float f[8];
@@ -209,9 +213,29 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(NhwcD y, const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) m[i] = q == 0 ? f[i] : fmaxf(m[i], f[i]);
     const bool ok = (q == 0) || (q == 1 && col2) || (q == 2 && row2) || (q == 3 && row2 && col2);
-    if (ok) st16(a.p + (pix + (q >> 1) * y.W + (q & 1)) * a.pitch + gk * 8, pack8(f));
+    pk[q] = pack8(f);
+    if (ok) st16(a.p + (pix + (q >> 1) * y.W + (q & 1)) * a.pitch + gk * 8, pk[q]);
   }
-  if (row2 && col2) st16(o.p + (((long long)n * o.H + hp) * o.W + wp) * o.pitch + gk * 8, pack8(m));
+  if (row2 && col2) {
+    st16(o.p + (((long long)n * o.H + hp) * o.W + wp) * o.pitch + gk * 8, pack8(m));
+    if (idx != nullptr) {
+      // activations are >= 0: their bf16 bit patterns order like the values, so the arg-max is taken on the 16-bit integers
+      const unsigned w0[4] = {pk[0].x, pk[0].y, pk[0].z, pk[0].w}, w1[4] = {pk[1].x, pk[1].y, pk[1].z, pk[1].w};
+      const unsigned w2[4] = {pk[2].x, pk[2].y, pk[2].z, pk[2].w}, w3[4] = {pk[3].x, pk[3].y, pk[3].z, pk[3].w};
+      unsigned code = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sh_ = (i & 1) * 16, wd = i >> 1;
+        unsigned best = (w0[wd] >> sh_) & 0xffffu, bi = 0;
+        const unsigned v1 = (w1[wd] >> sh_) & 0xffffu, v2 = (w2[wd] >> sh_) & 0xffffu, v3 = (w3[wd] >> sh_) & 0xffffu;
+        if (v1 > best) { best = v1; bi = 1; }
+        if (v2 > best) { best = v2; bi = 2; }
+        if (v3 > best) { best = v3; bi = 3; }
+        code |= bi << (2 * i);
+      }
+      idx[(((long long)n * o.H + hp) * o.W + wp) * groups + gk] = (u16)code;
+    }
+  }
 }
 
 // ---- MaxPool2d(2), floor mode (unet.py:26) --------------------------------------------------------------------------
@@ -286,6 +310,7 @@ __global__ __launch_bounds__(256) void conv1x1_out_bf16_kernel(NhwcD a, const fl
 // ---- BatchNorm + ReLU (+ max-pool / output conv) backward, pass 1 ---------------------------------------------------
 struct BnBwdB {
   NhwcD y, g, a, dpool, dz;
+  const u16* idx;   // pool mode: the forward's arg-max codes instead of `a` (or null)
   const float* scale; const float* shift; const float* mean; const float* invstd;
   const float* dout; const float* wout;
   float* partials;
@@ -430,24 +455,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_bf16_kernel(const BnBw
     };
     for (int p = chunk * P.pixb + pl; p < p_end && pl < ppi; p += ppi) {
       const int hp = p / Wp, wp = p - hp * Wp;
-      const u16* wb = P.a.p + (((long long)n * P.a.H + 2 * hp) * P.a.W + 2 * wp) * P.a.pitch + gk * 8;
-      float a0[8], a1[8], a2[8], a3[8], dp[8], r0[8], r1[8], r2[8], r3[8];
-      unpack8(ld16(wb), a0);
-      unpack8(ld16(wb + P.a.pitch), a1);
-      unpack8(ld16(wb + (long long)P.a.W * P.a.pitch), a2);
-      unpack8(ld16(wb + (long long)(P.a.W + 1) * P.a.pitch), a3);
+      float dp[8], r0[8], r1[8], r2[8], r3[8];
       unpack8(ld16(P.dpool.p + (((long long)n * Hp + hp) * Wp + wp) * P.dpool.pitch + gk * 8), dp);
+      if (P.idx != nullptr) {   // the forward (gsd_bf16_bn_apply_pool_idx) left the arg-max: 2 bytes instead of the window's 64
+        const unsigned code = P.idx[(((long long)n * Hp + hp) * Wp + wp) * groups + gk];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {   // first maximum in (0,0),(0,1),(1,0),(1,1) order wins
-        float best = a0[i];
-        int bi = 0;
-        if (a1[i] > best) { best = a1[i]; bi = 1; }
-        if (a2[i] > best) { best = a2[i]; bi = 2; }
-        if (a3[i] > best) { best = a3[i]; bi = 3; }
-        r0[i] = bi == 0 ? dp[i] : 0.f;
-        r1[i] = bi == 1 ? dp[i] : 0.f;
-        r2[i] = bi == 2 ? dp[i] : 0.f;
-        r3[i] = bi == 3 ? dp[i] : 0.f;
+        for (int i = 0; i < 8; ++i) {
+          const unsigned bi = (code >> (2 * i)) & 3u;
+          r0[i] = bi == 0 ? dp[i] : 0.f;
+          r1[i] = bi == 1 ? dp[i] : 0.f;
+          r2[i] = bi == 2 ? dp[i] : 0.f;
+          r3[i] = bi == 3 ? dp[i] : 0.f;
+        }
+      } else {
+        const u16* wb = P.a.p + (((long long)n * P.a.H + 2 * hp) * P.a.W + 2 * wp) * P.a.pitch + gk * 8;
+        float a0[8], a1[8], a2[8], a3[8];
+        unpack8(ld16(wb), a0);
+        unpack8(ld16(wb + P.a.pitch), a1);
+        unpack8(ld16(wb + (long long)P.a.W * P.a.pitch), a2);
+        unpack8(ld16(wb + (long long)(P.a.W + 1) * P.a.pitch), a3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // first maximum in (0,0),(0,1),(1,0),(1,1) order wins
+          float best = a0[i];
+          int bi = 0;
+          if (a1[i] > best) { best = a1[i]; bi = 1; }
+          if (a2[i] > best) { best = a2[i]; bi = 2; }
+          if (a3[i] > best) { best = a3[i]; bi = 3; }
+          r0[i] = bi == 0 ? dp[i] : 0.f;
+          r1[i] = bi == 1 ? dp[i] : 0.f;
+          r2[i] = bi == 2 ? dp[i] : 0.f;
+          r3[i] = bi == 3 ? dp[i] : 0.f;
+        }
       }
       one_pixel(2 * hp, 2 * wp, r0);
       one_pixel(2 * hp, 2 * wp + 1, r1);
@@ -631,8 +669,8 @@ extern "C" int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const fl
   return GSD_OK;
 }
 
-extern "C" int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
-                                      const gsd_nhwc* pooled, void* stream) {
+extern "C" int gsd_bf16_bn_apply_pool_idx(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
+                                          const gsd_nhwc* pooled, void* idx, void* stream) {
   if (int e = check_c8(y, "gsd_bf16_bn_apply_pool y")) return e;
   if (int e = check_c8(a, "gsd_bf16_bn_apply_pool a")) return e;
   if (int e = check_c8(pooled, "gsd_bf16_bn_apply_pool pooled")) return e;
@@ -642,9 +680,14 @@ extern "C" int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, con
   const int wh = (y->H + 1) / 2, ww = (y->W + 1) / 2;
   const long long total = (long long)y->N * wh * ww * (y->C / 8);
   hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
-                     scale, shift, to_nhwc(*a), to_nhwc(*pooled), wh, ww);
+                     scale, shift, to_nhwc(*a), to_nhwc(*pooled), wh, ww, (u16*)idx);
   GSD_LAUNCH_CHECK("gsd_bf16_bn_apply_pool");
   return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
+                                      const gsd_nhwc* pooled, void* stream) {
+  return gsd_bf16_bn_apply_pool_idx(y, scale, shift, a, pooled, nullptr, stream);
 }
 
 extern "C" int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream) {
@@ -685,9 +728,9 @@ extern "C" int gsd_bf16_bn_bwd_partial_rows(int N, int H, int W) {
   return N * ceil_div(H * W, pick_pixb(N, H * W));
 }
 
-extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
-                                      const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const gsd_nhwc* dpool,
-                                      const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream) {
+static int bn_bwd_reduce_impl(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const void* pool_idx, const gsd_nhwc* dpool,
+                              const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream) {
   if (int e = check_c8(y, "gsd_bf16_bn_bwd_reduce y")) return e;
   if (int e = check_c8(dz, "gsd_bf16_bn_bwd_reduce dz")) return e;
   GSD_REQUIRE(mode >= 0 && mode <= 2 && scale && shift && mean && invstd && partials && same_extent(y, dz), GSD_ERR_BAD_ARG,
@@ -705,12 +748,18 @@ extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* 
   } else {
     GSD_REQUIRE(dout && wout, GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: mode OUTC needs dout, wout (n_classes == 1)");
   }
+  P.idx = nullptr;
   if (mode == 1) {
-    if (int e = check_c8(a, "gsd_bf16_bn_bwd_reduce a")) return e;
     if (int e = check_c8(dpool, "gsd_bf16_bn_bwd_reduce dpool")) return e;
-    GSD_REQUIRE(same_extent(y, a) && dpool->N == y->N && dpool->C == y->C && dpool->H == y->H / 2 && dpool->W == y->W / 2,
-                GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: mode POOL needs a (N,H,W,C) and dpool (N,H/2,W/2,C)");
-    P.a = to_nhwc(*a);
+    GSD_REQUIRE(dpool->N == y->N && dpool->C == y->C && dpool->H == y->H / 2 && dpool->W == y->W / 2, GSD_ERR_BAD_ARG,
+                "gsd_bf16_bn_bwd_reduce: mode POOL needs dpool (N,H/2,W/2,C)");
+    if (pool_idx != nullptr) {
+      P.idx = (const u16*)pool_idx;
+    } else {
+      if (int e = check_c8(a, "gsd_bf16_bn_bwd_reduce a")) return e;
+      GSD_REQUIRE(same_extent(y, a), GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce: mode POOL needs a (N,H,W,C)");
+      P.a = to_nhwc(*a);
+    }
     P.dpool = to_nhwc(*dpool);
   }
   P.scale = scale; P.shift = shift; P.mean = mean; P.invstd = invstd;
@@ -727,6 +776,19 @@ extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* 
   } else hipLaunchKernelGGL((bn_bwd_reduce_bf16_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, P);
   GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_reduce");
   return GSD_OK;
+}
+
+extern "C" int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const gsd_nhwc* dpool,
+                                      const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream) {
+  return bn_bwd_reduce_impl(mode, y, scale, shift, mean, invstd, g, a, nullptr, dpool, dout, wout, dz, partials, stream);
+}
+
+extern "C" int gsd_bf16_bn_bwd_reduce_pool_idx(const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                                               const float* invstd, const gsd_nhwc* g, const void* pool_idx, const gsd_nhwc* dpool,
+                                               const gsd_nhwc* dz, float* partials, void* stream) {
+  GSD_REQUIRE(pool_idx != nullptr, GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_reduce_pool_idx: null index");
+  return bn_bwd_reduce_impl(1, y, scale, shift, mean, invstd, g, nullptr, pool_idx, dpool, nullptr, nullptr, dz, partials, stream);
 }
 
 extern "C" int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* scale, const float* mean,

@@ -184,6 +184,11 @@ class UNetEngineBF16:
         # gradients are handed to the all-reduce and at the end of backward.  GSD_BF16_SIDE_DW=0: everything on one stream.
         # BatchNorm apply + max-pool of the encoder's skip units in one pass (gsd_bf16_bn_apply_pool); GSD_BF16_APPLY_POOL=0: two
         self.apply_pool = os.environ.get("GSD_BF16_APPLY_POOL", "1") != "0"
+        # ... and that pass leaves the pool's arg-max (2 bits per element) for the backward, which then does not re-read the
+        # window's activations (gsd_bf16_bn_apply_pool_idx / gsd_bf16_bn_bwd_reduce_pool_idx); GSD_BF16_POOL_IDX=0: it does
+        self.pool_index = train and self.apply_pool and os.environ.get("GSD_BF16_POOL_IDX", "1") != "0"
+        self.pool_idx = [None] + [torch.empty((n, hs[l], ws[l], self.dims[l - 1] // 8), device=dev, dtype=torch.int16)
+                                  if self.pool_index else None for l in range(1, self.L + 1)]
         # 64 -> 64 convolutions (forward and dX) on the weights-resident kernel (gsd_bf16_c64.hip); GSD_BF16_C64=0: the DMA-filled one
         self.c64 = os.environ.get("GSD_BF16_C64", "1") != "0"
         # train mode: the last unit's BatchNorm + ReLU rides in the 1x1 output convolution (gsd_bf16_bn_relu_conv1x1_out): its
@@ -359,8 +364,9 @@ class UNetEngineBF16:
             return      # forward() folds it into the output convolution
         if pool_to is not None:
             dp = L.make_nhwc(pool_to)
-            check(lib.gsd_bf16_bn_apply_pool(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), C.byref(dp), st),
-                  "bn_apply_pool")
+            idx = self.pool_idx[u.level + 1] if self.pool_index else None
+            check(lib.gsd_bf16_bn_apply_pool_idx(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), C.byref(dp),
+                                                 L.ptr(idx), st), "bn_apply_pool")
         else:
             check(lib.gsd_bf16_bn_apply(C.byref(dy), u.scale.data_ptr(), u.shift.data_ptr(), C.byref(u.a), 1, st), "bn_apply")
 
@@ -672,7 +678,14 @@ class UNetEngineBF16:
             u0, u1 = self.enc[lvl]
             if lvl < self.L:
                 gskip = L.make_nhwc(self.gcat[lvl], 0, u1.cout)
-                self._reduce(1, u1, st, g=gskip, dpool=self.dpooled[lvl + 1])
+                if self.pool_index:
+                    dyv, dzv, dpv = L.make_nhwc(u1.y), L.make_nhwc(u1.g), L.make_nhwc(self.dpooled[lvl + 1])
+                    check(lib.gsd_bf16_bn_bwd_reduce_pool_idx(C.byref(dyv), u1.scale.data_ptr(), u1.shift.data_ptr(), u1.mean.data_ptr(),
+                                                              u1.invstd.data_ptr(), C.byref(gskip), self.pool_idx[lvl + 1].data_ptr(),
+                                                              C.byref(dpv), C.byref(dzv), self.partials.data_ptr(), st),
+                          "bn_bwd_reduce_pool_idx")
+                else:
+                    self._reduce(1, u1, st, g=gskip, dpool=self.dpooled[lvl + 1])
             self._tail(u1, G, st, dwout, fused=prev_fused is u1)
             dwout = None
             inc = lvl == 0 and self.fused_inc      # u0's raw output was never stored: no pass 1 in the dX epilogue

@@ -166,6 +166,12 @@ int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const float* shift,
  * followed by gsd_bf16_maxpool2. */
 int gsd_bf16_bn_apply_pool(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
                            const gsd_nhwc* pooled, void* stream);
+/* ... and, for the backward, which of its window's four activations each pooled value is: idx = (N, H/2, W/2, C/8) uint16, two
+ * bits per channel (channel c of a group in bits 2c..2c+1; 0..3 = (0,0),(0,1),(1,0),(1,1), the first maximum of the stored
+ * values).  gsd_bf16_bn_bwd_reduce_pool_idx then routes the pooled gradient from 2 bytes per (window, 8 channels) instead
+ * of re-reading the window's four activations (64 bytes).  idx == NULL: gsd_bf16_bn_apply_pool. */
+int gsd_bf16_bn_apply_pool_idx(const gsd_nhwc* y, const float* scale, const float* shift, const gsd_nhwc* a,
+                               const gsd_nhwc* pooled, void* idx, void* stream);
 
 /* MaxPool2d(2), floor mode (unet.py:26). */
 int gsd_bf16_maxpool2(const gsd_nhwc* a, const gsd_nhwc* pooled, void* stream);
@@ -189,6 +195,10 @@ int gsd_bf16_bn_bwd_partial_rows(int N, int H, int W);
 int gsd_bf16_bn_bwd_reduce(int mode, const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
                            const float* invstd, const gsd_nhwc* g, const gsd_nhwc* a, const gsd_nhwc* dpool,
                            const float* dout, const float* wout, const gsd_nhwc* dz, float* partials, void* stream);
+/* mode 1 with the arg-max codes of gsd_bf16_bn_apply_pool_idx instead of the activations; same dz, same sums. */
+int gsd_bf16_bn_bwd_reduce_pool_idx(const gsd_nhwc* y, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, const gsd_nhwc* g, const void* pool_idx, const gsd_nhwc* dpool,
+                                    const gsd_nhwc* dz, float* partials, void* stream);
 /* pass 2, in place: dz <- scale * (dz - c1 - xhat * c2), the gradient w.r.t. the raw convolution output. */
 int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* scale, const float* mean, const float* invstd,
                           const float* c1, const float* c2, void* stream);

@@ -356,6 +356,68 @@ def test_bn_apply_pool_is_apply_then_pool_bf16(h, w):
     assert torch.equal(from_nhwc(res[1][1], 0, c), F.max_pool2d(from_nhwc(res[1][0], 0, c), 2))
 
 
+@pytest.mark.parametrize("h,w", [(13, 18), (12, 17), (9, 11), (8, 10), (2, 2)])
+def test_pool_argmax_index_routes_like_the_stored_activations_bf16(h, w):
+    """gsd_bf16_bn_apply_pool_idx leaves, beside the activation and its max-pool, two bits per pooled element saying which of the
+    window's four stored activations it is (first maximum wins; ties made on purpose here: a quarter of the raw values are equal
+    and many activations are 0).  gsd_bf16_bn_bwd_reduce_pool_idx routing the pooled gradient by those codes == mode 1 of
+    gsd_bf16_bn_bwd_reduce re-reading the activations: same dz, same partial sums, bit for bit; and the codes are the arg-max."""
+    L = _lib()
+    g = torch.Generator().manual_seed(70 + h)
+    n, c = 3, 48
+    y = bf16r(torch.round(torch.randn((n, c, h, w), generator=g) * 4) / 4)          # coarse values: ties inside windows
+    gamma, beta = torch.rand((c,), generator=g) + 0.5, 0.3 * torch.randn((c,), generator=g)
+    mean, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    dev = [t.float().cuda() for t in (scale, shift, mean, invstd)]
+    ybuf = to_nhwc(y)
+    a = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device="cuda")
+    a2 = torch.zeros_like(a)
+    pooled = torch.zeros((n, h // 2, w // 2, c), dtype=torch.bfloat16, device="cuda")
+    pooled2 = torch.zeros_like(pooled)
+    idx = torch.full((n, h // 2, w // 2, c // 8), -1, dtype=torch.int16, device="cuda")
+    dy_ = L.make_nhwc(ybuf)
+    L.check(L.lib.gsd_bf16_bn_apply_pool_idx(C.byref(dy_), dev[0].data_ptr(), dev[1].data_ptr(), C.byref(L.make_nhwc(a)),
+                                             C.byref(L.make_nhwc(pooled)), idx.data_ptr(), L.stream_ptr()), "apply_pool_idx")
+    L.check(L.lib.gsd_bf16_bn_apply_pool(C.byref(dy_), dev[0].data_ptr(), dev[1].data_ptr(), C.byref(L.make_nhwc(a2)),
+                                         C.byref(L.make_nhwc(pooled2)), L.stream_ptr()), "apply_pool")
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2) and torch.equal(pooled, pooled2)
+    # the codes against a host arg-max over the stored activations (first maximum in (0,0),(0,1),(1,0),(1,1) order)
+    af = a.float().cpu()[:, :h // 2 * 2, :w // 2 * 2]
+    win = torch.stack([af[:, 0::2, 0::2], af[:, 0::2, 1::2], af[:, 1::2, 0::2], af[:, 1::2, 1::2]], dim=0)     # (4, n, hp, wp, c)
+    ref_bi = torch.zeros(win.shape[1:], dtype=torch.int64)
+    best = win[0].clone()
+    for q in range(1, 4):
+        better = win[q] > best
+        ref_bi[better] = q
+        best = torch.where(better, win[q], best)
+    codes = idx.cpu().to(torch.int32) & 0xffff
+    got_bi = torch.stack([(codes >> (2 * i)) & 3 for i in range(8)], dim=-1).reshape(n, h // 2, w // 2, c).to(torch.int64)
+    assert torch.equal(got_bi, ref_bi)
+    # backward: the two routings
+    gsk = bf16r(torch.randn((n, h, w, c), generator=g)).to(torch.bfloat16).cuda()
+    dpool = bf16r(torch.randn((n, h // 2, w // 2, c), generator=g)).to(torch.bfloat16).cuda()
+    rows = L.lib.gsd_bf16_bn_bwd_partial_rows(n, h, w)
+    res = []
+    for use_idx in (False, True):
+        dz = torch.full((n, h, w, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+        part = torch.full((rows, 3 * c), float("nan"), device="cuda")
+        args = (C.byref(dy_), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), C.byref(L.make_nhwc(gsk)))
+        if use_idx:
+            L.check(L.lib.gsd_bf16_bn_bwd_reduce_pool_idx(*args, idx.data_ptr(), C.byref(L.make_nhwc(dpool)), C.byref(L.make_nhwc(dz)),
+                                                          part.data_ptr(), L.stream_ptr()), "reduce_pool_idx")
+        else:
+            L.check(L.lib.gsd_bf16_bn_bwd_reduce(1, *args, C.byref(L.make_nhwc(a)), C.byref(L.make_nhwc(dpool)), None, None,
+                                                 C.byref(L.make_nhwc(dz)), part.data_ptr(), L.stream_ptr()), "reduce_pool")
+        torch.cuda.synchronize()
+        res.append((dz.clone(), part[:, :2 * c].clone()))
+    assert not bool(torch.isnan(res[1][0].float()).any())
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+    assert torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("mode,h,w", [(0, 13, 18), (1, 13, 18), (1, 12, 17), (1, 9, 11), (1, 8, 10), (2, 13, 18)])
 def test_bn_bwd_bf16(mode, h, w):
     """Pass 1 (mask, pooled-gradient routing, output-conv gradient, per-channel sums) and pass 2 against torch fp64."""

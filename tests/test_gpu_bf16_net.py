@@ -350,3 +350,14 @@ def test_bf16_large_tile_transposed_convolutions_track_the_general_kernels(dims,
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k                # ... and so are the running statistics it leaves
     assert _cos(g1.cpu().numpy(), g0.cpu().numpy()) > 0.98
+
+
+def test_bf16_pool_argmax_index_changes_nothing(monkeypatch):
+    """GSD_BF16_POOL_IDX (default on): the apply + pool pass leaves the pool's arg-max codes and the backward routes the pooled
+    gradient by them instead of re-reading the activations: the same routing, so two train steps agree bit for bit."""
+    dims = [32, 64, 128]
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_POOL_IDX": "0"})
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_POOL_IDX": "1"})
+    assert not e0.pool_index and e1.pool_index
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
