@@ -156,6 +156,8 @@ SIGNATURES = {
     "gsd_bf16_bn_bwd_apply": (_I, [_NHWC, _NHWC, _P, _P, _P, _P, _P, _P]),
     "gsd_bf16_channel_sums_workspace": (_L, [_I, _I, _I, _I]),
     "gsd_bf16_channel_sums": (_I, [_NHWC, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "gsd_bf16_convT_bias_grad_workspace": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "gsd_bf16_convT_bias_grad": (_I, [_P, _I, _I, _I, _NHWC, _I, _I, _I, _I, _P, _P, _L, _P]),
     "gsd_bf16_wgrad_workspace": (_L, [_I, _I, _I, _I, _I, _I]),
     "gsd_bf16_wgrad": (_I, [_NHWC, _NHWC, _I, _I, _IP, _IP, _P, _I, _P, _L, _P]),
 }

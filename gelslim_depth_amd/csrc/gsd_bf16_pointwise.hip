@@ -589,6 +589,23 @@ __global__ __launch_bounds__(256) void channel_sums_stage2(const float* __restri
   if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ConvTranspose2d bias gradient from what the decoder's dX launch left: out[c] = sum over the partial rows of column col0 + c
+// (per-channel sums of the WHOLE gradient plane, from that launch's statistics epilogue) minus the workspace rows (stage-1 sums
+// over the F.pad strips outside the transposed convolution's window).  Block = 64 channels x 4 row lanes, fp64, fixed order.
+__global__ __launch_bounds__(256) void convT_bias_combine_kernel(const float* __restrict__ part, int rows, int ld, int col0,
+                                                                 const float* __restrict__ ws, int wrows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s = 0.0;
+  if (c < C) {
+    for (int r = rl; r < rows; r += 4) s += (double)part[(size_t)r * ld + col0 + c];
+    for (int r = rl; r < wrows; r += 4) s -= (double)ws[(size_t)r * C + c];
+  }
+  __shared__ double red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 int pick_pixb(int N, int HW, int target_blocks = 1024) {   // (2048 until round 4: half the partial rows for the finalize launch behind it, same pass time)
   long long pixb = ((long long)N * HW + target_blocks - 1) / target_blocks;
   pixb = (pixb + 31) / 32 * 32;
@@ -823,5 +840,57 @@ extern "C" int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, 
   hipLaunchKernelGGL(channel_sums_stage2, dim3(ceil_div(t->C, 64)), dim3(256), 0, (hipStream_t)stream, workspace, t->N * chunks,
                      t->C, out);
   GSD_LAUNCH_CHECK("gsd_bf16_channel_sums stage2");
+  return GSD_OK;
+}
+
+namespace {
+// the (up to four) rectangles of an (H, W) plane outside the window [oy, oy+hh) x [ox, ox+ww): {y0, x0, rows, cols}
+int pad_rects(int H, int W, int oy, int ox, int hh, int ww, int (&r)[4][4]) {
+  int n = 0;
+  auto add = [&](int y0, int x0, int rh, int rw) {
+    if (rh > 0 && rw > 0) { r[n][0] = y0; r[n][1] = x0; r[n][2] = rh; r[n][3] = rw; ++n; }
+  };
+  add(0, 0, oy, W);
+  add(oy + hh, 0, H - oy - hh, W);
+  add(oy, 0, hh, ox);
+  add(oy, ox + ww, hh, W - ox - ww);
+  return n;
+}
+}  // namespace
+
+extern "C" int64_t gsd_bf16_convT_bias_grad_workspace(int N, int H, int W, int oy, int ox, int hh, int ww, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || oy < 0 || ox < 0 || hh <= 0 || ww <= 0 || oy + hh > H || ox + ww > W) return 0;
+  int r[4][4];
+  const int n = pad_rects(H, W, oy, ox, hh, ww, r);
+  int64_t tot = 0;
+  for (int i = 0; i < n; ++i) tot += (int64_t)N * ceil_div(r[i][2] * r[i][3], pick_pixb(N, r[i][2] * r[i][3], 512)) * C;
+  return tot > 0 ? tot : 1;
+}
+
+extern "C" int gsd_bf16_convT_bias_grad(const float* partials, int rows, int ld, int col0, const gsd_nhwc* g, int oy, int ox, int hh,
+                                        int ww, float* out, float* workspace, int64_t workspace_elems, void* stream) {
+  if (int e = check_c8(g, "gsd_bf16_convT_bias_grad g")) return e;
+  GSD_REQUIRE(partials && out && workspace && rows > 0 && ld > 0 && col0 >= 0 && col0 + g->C <= ld, GSD_ERR_BAD_ARG,
+              "gsd_bf16_convT_bias_grad: bad partial-row layout (rows %d, ld %d, col0 %d, C %d)", rows, ld, col0, g->C);
+  GSD_REQUIRE(oy >= 0 && ox >= 0 && hh > 0 && ww > 0 && oy + hh <= g->H && ox + ww <= g->W, GSD_ERR_BAD_ARG,
+              "gsd_bf16_convT_bias_grad: window (%d,%d)+(%d,%d) outside (%d,%d)", oy, ox, hh, ww, g->H, g->W);
+  GSD_REQUIRE(g->N <= 65535 && (g->C <= 2048 || g->C % 2048 == 0), GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_convT_bias_grad: N must be <= 65535 and C <= 2048 or a multiple of 2048");
+  GSD_REQUIRE(workspace_elems >= gsd_bf16_convT_bias_grad_workspace(g->N, g->H, g->W, oy, ox, hh, ww, g->C), GSD_ERR_WORKSPACE,
+              "gsd_bf16_convT_bias_grad: workspace too small");
+  int r[4][4];
+  const int n = pad_rects(g->H, g->W, oy, ox, hh, ww, r);
+  int wrows = 0;
+  for (int i = 0; i < n; ++i) {
+    const int area = r[i][2] * r[i][3];
+    const int pixb = pick_pixb(g->N, area, 512), chunks = ceil_div(area, pixb);
+    hipLaunchKernelGGL(channel_sums_stage1, dim3(chunks, g->N), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)stream, to_nhwc(*g),
+                       r[i][0], r[i][1], r[i][2], r[i][3], pixb, chunks, workspace + (size_t)wrows * g->C);
+    GSD_LAUNCH_CHECK("gsd_bf16_convT_bias_grad strips");
+    wrows += g->N * chunks;
+  }
+  hipLaunchKernelGGL(convT_bias_combine_kernel, dim3(ceil_div(g->C, 64)), dim3(256), 0, (hipStream_t)stream, partials, rows, ld, col0,
+                     workspace, wrows, g->C, out);
+  GSD_LAUNCH_CHECK("gsd_bf16_convT_bias_grad");
   return GSD_OK;
 }

@@ -176,6 +176,8 @@ class UNetEngineBF16:
                                lib.gsd_bf16_conv_mpad(up.cin))
                 max_ws = max(max_ws, lib.gsd_bf16_wgrad_workspace(4, n, hs[li], ws[li], up.cin, up.cout))
                 max_ws = max(max_ws, lib.gsd_bf16_channel_sums_workspace(n, 2 * hs[li], 2 * ws[li], up.cout))
+                oy_, ox_ = self._pad_off(li - 1)
+                max_ws = max(max_ws, lib.gsd_bf16_convT_bias_grad_workspace(n, hs[li - 1], ws[li - 1], oy_, ox_, 2 * hs[li], 2 * ws[li], up.cout))
         self.partials = torch.empty((max_part,), **f32)
         self.wspace = torch.empty((max(max_ws, 64),), **f32) if train else None
         # weight gradients on a SIDE stream: dW(u) only needs d_raw(u) and the unit's input, nothing downstream of it waits for
@@ -194,6 +196,12 @@ class UNetEngineBF16:
         # train mode: the last unit's BatchNorm + ReLU rides in the 1x1 output convolution (gsd_bf16_bn_relu_conv1x1_out): its
         # activation has no other reader (the backward recomputes it from the raw output) and is never written.  GSD_BF16_FUSED_OUT=0: apply + conv
         self.fused_out = os.environ.get("GSD_BF16_FUSED_OUT", "1") != "0"
+        # the transposed convolutions' bias gradient from the statistics rows of the dX launch that writes the gradient slice (the
+        # decoder's first convolution) instead of a pass over the slice (gsd_bf16_convT_bias_grad); GSD_BF16_DB_FROM_DX=0: gsd_bf16_channel_sums
+        self.db_from_dx = train and os.environ.get("GSD_BF16_DB_FROM_DX", "1") != "0"
+        self.db_part = [torch.empty((lib.gsd_bf16_conv_partial_rows(n, hs[l], ws[l], self.cat[l].shape[3]) * 2 *
+                                     lib.gsd_bf16_conv_mpad(self.cat[l].shape[3]),), **f32) if self.db_from_dx else None
+                        for l in range(self.L)]
         self.side_dw = train and os.environ.get("GSD_BF16_SIDE_DW", "1") != "0"
         self.side = torch.cuda.Stream(device=dev) if self.side_dw else None
         self.wspace_side = torch.empty((max(max_ws, 64),), **f32) if self.side_dw else None
@@ -604,9 +612,11 @@ class UNetEngineBF16:
                                                   tgt.invstd.data_ptr())
         return bw, yv
 
-    def _dgrad(self, u: _Unit, P, dst: torch.Tensor, st: int, fuse: Optional[_Unit] = None) -> None:
+    def _dgrad(self, u: _Unit, P, dst: torch.Tensor, st: int, fuse: Optional[_Unit] = None, stats_to: Optional[torch.Tensor] = None
+               ) -> None:
         """dX of unit u (u.g holds dy) into the plain tensor dst (N,H,W,u.cin); with `fuse` (the unit whose activation is
-        u's input, dst == fuse.g) the epilogue also does pass 1 of that unit's BatchNorm+ReLU backward."""
+        u's input, dst == fuse.g) the epilogue also does pass 1 of that unit's BatchNorm+ReLU backward; with `stats_to` (and no
+        fuse) it leaves the per-channel sums of what it stores there (gsd_bf16_conv_partial_rows rows of 2*mpad(u.cin))."""
         n, lh, lw = u.y.shape[0], self.hs[u.level], self.ws[u.level]
         self._wimage(1, P[u.wname], u.cout, u.cin, u.wt_d, st)
         din, dout = L.make_nhwc(u.g), L.make_nhwc(dst)
@@ -614,7 +624,7 @@ class UNetEngineBF16:
         if fuse is not None:
             bw, keep = self._bnbwd(fuse)
         done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
-        part = self.partials.data_ptr() if bw is not None else None
+        part = self.partials.data_ptr() if bw is not None else (stats_to.data_ptr() if stats_to is not None else None)
         if self._use_c64(u.cout, u.cin):
             check(lib.gsd_bf16_conv3x3_c64(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), part, C.byref(bw) if bw is not None else None, st),
                   "conv3x3_c64 dgrad")
@@ -647,20 +657,26 @@ class UNetEngineBF16:
             dwout = None
             self._dgrad(u1, P, u0.g, st, fuse=u0)
             self._tail(u0, G, st, fused=True)
-            self._dgrad(u0, P, self.gcat[lvl], st)
+            self._dgrad(u0, P, self.gcat[lvl], st, stats_to=self.db_part[lvl] if self.db_from_dx else None)
             prev = self.dec[j - 1][1] if j > 0 else self.enc[self.L][1]
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
             oy, ox = self._pad_off(lvl)
             gup = L.make_nhwc(self.gcat[lvl], self.dims[lvl], up.cout)
             ty, tx = L.int_array([oy, oy, oy + 1, oy + 1]), L.int_array([ox, ox + 1, ox, ox + 1])
-            def launch(sst, ws, up=up, prev=prev, gup=gup, ty=ty, tx=tx, hi=hi, wi=wi, oy=oy, ox=ox):
+            def launch(sst, ws, up=up, prev=prev, gup=gup, ty=ty, tx=tx, hi=hi, wi=wi, oy=oy, ox=ox, lvl=lvl):
                 done = self._log("bf16_wgrad", 2.0 * 4 * up.cout * up.cin * n * hi * wi)
                 check(lib.gsd_bf16_wgrad(C.byref(prev.a), C.byref(gup), 4, 2, ty, tx, G[up.wname].data_ptr(), up.cout, ws.data_ptr(),
                                          ws.numel(), sst), "convT wgrad")
                 done()
                 # (the bias gradient -- per-channel sums of the same gradient slice -- is off the critical path too)
-                check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), ws.data_ptr(), ws.numel(),
-                                                sst), "convT bias grad")
+                if self.db_from_dx:      # from the statistics rows the dX launch above left: no pass over the slice
+                    ctot = self.cat[lvl].shape[3]
+                    check(lib.gsd_bf16_convT_bias_grad(self.db_part[lvl].data_ptr(), lib.gsd_bf16_conv_partial_rows(n, self.hs[lvl], self.ws[lvl], ctot),
+                                                       2 * lib.gsd_bf16_conv_mpad(ctot), ctot - up.cout, C.byref(gup), oy, ox, 2 * hi, 2 * wi,
+                                                       G[up.bname].data_ptr(), ws.data_ptr(), ws.numel(), sst), "convT bias grad")
+                else:
+                    check(lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, 2 * hi, 2 * wi, G[up.bname].data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), sst), "convT bias grad")
             self._on_side(launch)
             self._wimage(4, P[up.wname], up.cout, up.cin, up.wt_d, st)
             dprev = L.make_nhwc(prev.g)

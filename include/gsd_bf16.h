@@ -208,6 +208,14 @@ int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, const float* sc
 int64_t gsd_bf16_channel_sums_workspace(int N, int hh, int ww, int C);
 int gsd_bf16_channel_sums(const gsd_nhwc* t, int y0, int x0, int hh, int ww, float* out, float* workspace,
                           int64_t workspace_elems, void* stream);
+/* The same bias gradient without a pass over the gradient slice: the dX launch that WROTE the slice (the decoder's first
+ * convolution, gsd_bf16_conv3x3 with `partials` and no `bw`) left per-channel sums of the whole plane in its statistics rows
+ * (`rows` rows of `ld` floats; the slice's channel c is column col0 + c); what lies outside the transposed convolution's window
+ * -- the F.pad border, (oy,ox)+(hh,ww) inside g's (H,W) -- is summed from g (thin strips) and subtracted.
+ * out[c] = sum_rows partials[r][col0+c] - sum_{n, (y,x) outside the window} g[n,y,x,c]. */
+int64_t gsd_bf16_convT_bias_grad_workspace(int N, int H, int W, int oy, int ox, int hh, int ww, int C);
+int gsd_bf16_convT_bias_grad(const float* partials, int rows, int ld, int col0, const gsd_nhwc* g, int oy, int ox, int hh, int ww,
+                             float* out, float* workspace, int64_t workspace_elems, void* stream);
 
 /* ---- weight gradients --------------------------------------------------------------------------------------------
  *   D[t][m][n] = sum_{n_img,h,w} a[n_img,h,w,m] * b[n_img, stride*h+ty[t], stride*w+tx[t], n]   (zeros outside b)

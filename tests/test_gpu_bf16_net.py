@@ -361,3 +361,19 @@ def test_bf16_pool_argmax_index_changes_nothing(monkeypatch):
     assert not e0.pool_index and e1.pool_index
     assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
     assert all(torch.equal(b0[k], b1[k]) for k in b0)
+
+
+@pytest.mark.parametrize("dims,n,h,w", [([32, 64, 128], 3, 37, 53), ([64, 128, 256], 2, 40, 130)])
+def test_bf16_transposed_conv_bias_gradient_from_the_dx_statistics(dims, n, h, w, monkeypatch):
+    """GSD_BF16_DB_FROM_DX (default on): the ConvTranspose2d bias gradient is assembled from the statistics rows of the dX launch that
+    wrote the gradient slice, minus the F.pad strips (gsd_bf16_convT_bias_grad), instead of a pass over the slice
+    (gsd_bf16_channel_sums).  Everything else of the step is untouched (bit-equal); the bias gradients are two summation orders of
+    the same bf16 values (odd sizes here: every level has a pad strip)."""
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_DB_FROM_DX": "0"}, steps=1, n=n, h=h, w=w)
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_DB_FROM_DX": "1"}, steps=1, n=n, h=h, w=w)
+    assert not e0.db_from_dx and e1.db_from_dx
+    assert l0 == l1 and all(torch.equal(b0[k], b1[k]) for k in b0)
+    d = (g0 - g1).abs()
+    assert int((d > 0).sum()) <= sum(dims)                       # only bias-gradient entries may differ
+    scale = float(g0.abs().max())
+    assert float(d.max()) <= 1e-4 * scale + 1e-9
