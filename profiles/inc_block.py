@@ -3,7 +3,12 @@ engine, as a one-level network (layer_dimensions=[64]: inc + the 1x1 output conv
 `--pmc WRITE_SIZE` (profiles/r03_profile.sh) the per-kernel counters of THIS process are the block's real HBM traffic
 (profiles/make_inc_traffic.py sums them, leaving out the output conv); alone it prints the block's time from HIP events.
 usage (GPU box): PYTHONPATH=. python profiles/inc_block.py [fp32|bf16] [batch] [iterations]"""
+import os
 import sys
+
+# a one-level network's `inc` is also its LAST unit, whose BatchNorm + ReLU the bf16 engine would fold into the output convolution
+# (GSD_BF16_FUSED_OUT) -- outside the measured region.  The block under test must produce its activation, as it does in the real net:
+os.environ["GSD_BF16_FUSED_OUT"] = "0"
 
 import torch
 
