@@ -591,19 +591,24 @@ __global__ __launch_bounds__(256) void channel_sums_stage2(const float* __restri
 
 // ConvTranspose2d bias gradient from what the decoder's dX launch left: out[c] = sum over the partial rows of column col0 + c
 // (per-channel sums of the WHOLE gradient plane, from that launch's statistics epilogue) minus the workspace rows (stage-1 sums
-// over the F.pad strips outside the transposed convolution's window).  Block = 64 channels x 4 row lanes, fp64, fixed order.
-__global__ __launch_bounds__(256) void convT_bias_combine_kernel(const float* __restrict__ part, int rows, int ld, int col0,
-                                                                 const float* __restrict__ ws, int wrows, int C, float* __restrict__ out) {
+// over the F.pad strips outside the transposed convolution's window).  Block = 64 channels x 16 row lanes, fp64, fixed order.
+__global__ __launch_bounds__(1024) void convT_bias_combine_kernel(const float* __restrict__ part, int rows, int ld, int col0,
+                                                                  const float* __restrict__ ws, int wrows, int C, float* __restrict__ out) {
+  constexpr int RL = 16;   // row lanes: a few hundred rows, one block per 64 channels -- the walk is a chain of dependent loads
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   double s = 0.0;
   if (c < C) {
-    for (int r = rl; r < rows; r += 4) s += (double)part[(size_t)r * ld + col0 + c];
-    for (int r = rl; r < wrows; r += 4) s -= (double)ws[(size_t)r * C + c];
+    for (int r = rl; r < rows; r += RL) s += (double)part[(size_t)r * ld + col0 + c];
+    for (int r = rl; r < wrows; r += RL) s -= (double)ws[(size_t)r * C + c];
   }
-  __shared__ double red[4][64];
+  __shared__ double red[RL][64];
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < C) out[c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && c < C) {
+    double t = 0.0;
+    for (int i = 0; i < RL; ++i) t += red[i][threadIdx.x];
+    out[c] = (float)t;
+  }
 }
 
 int pick_pixb(int N, int HW, int target_blocks = 1024) {   // (2048 until round 4: half the partial rows for the finalize launch behind it, same pass time)
@@ -889,7 +894,7 @@ extern "C" int gsd_bf16_convT_bias_grad(const float* partials, int rows, int ld,
     GSD_LAUNCH_CHECK("gsd_bf16_convT_bias_grad strips");
     wrows += g->N * chunks;
   }
-  hipLaunchKernelGGL(convT_bias_combine_kernel, dim3(ceil_div(g->C, 64)), dim3(256), 0, (hipStream_t)stream, partials, rows, ld, col0,
+  hipLaunchKernelGGL(convT_bias_combine_kernel, dim3(ceil_div(g->C, 64)), dim3(1024), 0, (hipStream_t)stream, partials, rows, ld, col0,
                      workspace, wrows, g->C, out);
   GSD_LAUNCH_CHECK("gsd_bf16_convT_bias_grad");
   return GSD_OK;
