@@ -42,6 +42,8 @@ struct GConvP {
   int ntaps, stride;
   int ty[9], tx[9];
   int TH, TW, tiles_y, tiles_x, HC, HP;
+  int buf;         // MODE 0: fills through buffer descriptors (image and weight image below 2 GiB)
+  unsigned img_bytes, wt_bytes;
   int Cs, oy, ox;  // scatter (Cs > 0): m = q*Cs + co -> out pixel (2h + (q>>1) + oy, 2w + (q&1) + ox), channel co
   const float* bias;
   float* partials;
@@ -78,6 +80,13 @@ __device__ __forceinline__ void gconv_dma_piece(const void* g, unsigned char* bu
   __builtin_amdgcn_global_load_lds(g, buf + pc * 1024, 16, 0, 0);
 #endif
 }
+// BUF (template, MODE 0): fills go through buffer descriptors (buffer_load_dwordx4 ... lds): one 32-bit offset per piece, the image /
+// weight base and the channel chunk in the scalar offset, and an out-of-image or pad piece is an offset beyond num_records -- the
+// hardware writes ZEROS for it (profiles/ubench/buffer_lds_oob.hip).  BUF = 0: per-lane 64-bit addresses, a zero line and a branch
+// per piece (the form until round 4; still used when an image or the weight image exceeds 2 GiB, and by GSD_BF16_CONV_BUF=0).
+__device__ __forceinline__ void gconv_dma_piece_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned char* buf, int pc) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, voff, soff, 0, 0);
+}
 #ifndef GCONV_STAMP   // diagnostic builds only: every block leaves (shader cycles, 100-MHz ticks) of its K-loop life in a buffer of
 #define GCONV_STAMP 0 // its own -> the clock the chip holds under this kernel (profiles/bench_bf16_conv.py, GSD_DIAG_STAMPS=1)
 #endif
@@ -87,8 +96,9 @@ extern "C" int gsd_diag_gconv_stamps(unsigned long long* host, int nblocks) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(gconv_stamp_buf), sizeof(unsigned long long) * 2 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : 1;
 }
 #endif
-template <int MODE, int WM, int WN>
+template <int MODE, int WM, int WN, int BUF = 0>
 __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
+  static_assert(!BUF || MODE == 0, "buffer-addressed fills: the 3x3 form");
   constexpr int BM = WM * 64, NPX = WN * 128;
   constexpr int MT = 4, NT = 8;
   // k-steps per barrier: MODE 0 the 3 taps of a kernel row; MODE 1 NSUB consecutive 32-channel sub-chunks of one tap
@@ -209,10 +219,12 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
         if (MODE == 0) {
           const int hi = h0 - 1 + y, wi = w0 - 1 + x;
           v = ((unsigned)hi < (unsigned)P.Hin && (unsigned)wi < (unsigned)P.Win) ? (int)((hi * P.Win + wi) * P.in_pitch) + slot * 8 : -1;
+          if (BUF) v = v >= 0 ? v * 2 : (int)0x80000000u;   // byte offset inside the image, or beyond it: zeros
         } else {
           v = (h0 + y < P.H && w0 + x < P.W) ? xpk[k] : -1;
         }
       }
+      if (BUF && v == -2) v = (int)0x80000000u;   // pad / slack pieces: zeros as well
       xoff[k] = v;
     }
   };
@@ -229,6 +241,18 @@ __global__ __launch_bounds__(256) void gconv_bf16_kernel(const GConvP P) {
       const int nch = (P.K >> 5) / NSUB;      // iterations per tap
       tap0 = it / nch;
       chunk = (it - tap0 * nch) * NSUB;       // first 32-channel chunk of the iteration
+    }
+    if (BUF) {
+      // descriptors are rebuilt here from uniform values (scalar ALU): the weight image, and image n of the activations
+      if (slot < NWI) {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.wt, 0, P.wt_bytes, 0x00020000);
+        gconv_dma_piece_buf(rw, (unsigned)woff[slot] * 2u, (unsigned)((tap0 * P.Mpad * P.K + chunk * 32) * 2), Wl + (git & 1) * WBUF, piece(slot, NWI));
+      } else {
+        const int k = slot - NWI;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.in + (long long)n * P.Hin * P.Win * P.in_pitch), 0, P.img_bytes, 0x00020000);
+        gconv_dma_piece_buf(rx, (unsigned)xoff[k], (unsigned)(chunk * 64), Xl + ((git / 3) & 1) * XBUF, piece(k, MAXX));
+      }
+      return;
     }
     if (slot < NWI) {
       const u16* wsrc = P.wt + (long long)tap0 * P.Mpad * P.K + chunk * 32;
@@ -597,20 +621,20 @@ long launch_grid(long items, int mblocks) {
   return grid > items ? items : grid;
 }
 
-template <int MODE, int WM, int WN>
+template <int MODE, int WM, int WN, int BUF = 0>
 int launch(GConvP& P, long items, size_t lds, hipStream_t st, const char* what) {
   GSD_REQUIRE(items > 0 && items < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: %ld work items out of range", what, items);
   P.nitems = (int)items;
   const long grid = launch_grid(items, P.mblocks);
   P.xcd = (gsd_env_int("GSD_BF16_XCD", 1) != 0 && grid % 8 == 0 && (grid / 8) % P.mblocks == 0) ? 1 : 0;
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN>)); e != hipSuccess) {
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&gconv_bf16_kernel<MODE, WM, WN, BUF>)); e != hipSuccess) {
     gsd_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(grid > 0 && grid < 2147483647L, GSD_ERR_UNSUPPORTED, "%s: grid %ld out of range", what, grid);
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "%s: LDS %zu B too large", what, lds);
-  hipLaunchKernelGGL((gconv_bf16_kernel<MODE, WM, WN>), dim3((unsigned)grid), dim3(256), lds, st, P);
+  hipLaunchKernelGGL((gconv_bf16_kernel<MODE, WM, WN, BUF>), dim3((unsigned)grid), dim3(256), lds, st, P);
   GSD_LAUNCH_CHECK(what);
   return GSD_OK;
 }
@@ -647,6 +671,12 @@ static int conv3x3_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out,
   for (int t = 0; t < 9; ++t) { P.ty[t] = t / 3 - 1; P.tx[t] = t % 3 - 1; }
   P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HC = pl.HC; P.HP = pl.HP;
   P.Cs = 0; P.oy = P.ox = 0;
+  {
+    const long long ib = (long long)in->H * in->W * in->pitch * 2, wb = (long long)9 * pl.Mpad * K * 2;
+    P.buf = (ib < (1LL << 31) && wb < (1LL << 31) && gsd_env_int("GSD_BF16_CONV_BUF", 1) != 0) ? 1 : 0;
+    P.img_bytes = (unsigned)ib;
+    P.wt_bytes = (unsigned)wb;
+  }
   P.bias = nullptr;
   P.partials = partials;
   P.ep_scale = ep_scale; P.ep_shift = ep_shift;
@@ -662,6 +692,10 @@ static int conv3x3_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* out,
   }
   const long grid = (long)P.N * pl.tiles_y * pl.tiles_x * pl.mblocks;
   const size_t lds = (size_t)2 * 3 * pl.BM * 64 + (size_t)2 * (pl.wide ? 16 : 10) * 4096 + (size_t)(4 * pl.BM + 512) * sizeof(float);
+  if (P.buf) {
+    if (pl.wide) return launch<0, 1, 4, 1>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
+    return launch<0, 2, 2, 1>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
+  }
   if (pl.wide) return launch<0, 1, 4>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
   return launch<0, 2, 2>(P, grid, lds, (hipStream_t)stream, "gsd_bf16_conv3x3");
 }
@@ -714,6 +748,7 @@ static int conv_dense_impl(const gsd_nhwc* in, const void* wt, const gsd_nhwc* o
   for (int t = 0; t < 9; ++t) { P.ty[t] = t < ntaps ? ty[t] : 0; P.tx[t] = t < ntaps ? tx[t] : 0; }
   P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HC = 0; P.HP = 0;
   P.Cs = scatter_cs; P.oy = oy; P.ox = ox;
+  P.buf = 0; P.img_bytes = P.wt_bytes = 0;
   P.bias = bias;
   P.partials = partials;
   P.ep_scale = ep_scale; P.ep_shift = ep_shift;
