@@ -37,6 +37,7 @@ struct GWgradP {
   int ty[9], tx[9];
   int TH, TW, tiles_y, tiles_x, HC, HP, KS, NPIX;
   int stages_total, splits, mblocks, nblocks, xcd;
+  unsigned a_img_bytes, b_img_bytes;   // one image of each operand (buffer descriptors; below 2 GiB)
 };
 
 __device__ __forceinline__ u32x2 tr_read_b64(const unsigned char* p) {
@@ -126,42 +127,43 @@ __global__ __launch_bounds__(256, 2) void gwgrad_bf16_kernel(const GWgradP P) {
     const int trem = stage - n * tpi;
     const int tyi = trem / P.tiles_x;
     const int h0 = tyi * P.TH, w0 = (trem - tyi * P.tiles_x) * P.TW;
-    const u16* a_img = P.a + (long long)n * P.H * P.W * P.a_pitch + m0;
-    const u16* b_img = P.b + (long long)n * P.Hb * P.Wb * P.b_pitch + n0;
+    // Fills through buffer descriptors (buffer_load_dwordx4 ... lds): one 32-bit byte offset per piece from the image's base, and a
+    // piece with nothing to fetch (outside the image, a channel beyond M / Ncols) is an offset beyond num_records --
+    // the hardware writes zeros for it (profiles/ubench/buffer_lds_oob.hip): no zero line, no 64-bit address, no branch per piece.
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(P.a + (long long)n * P.H * P.W * P.a_pitch), 0, P.a_img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(P.b + (long long)n * P.Hb * P.Wb * P.b_pitch), 0, P.b_img_bytes, 0x00020000);
     __syncthreads();   // every wave has finished reading the previous stage's images
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
-      if (apk[k] != -1) {
-        const void* s = (const void*)gsd_zero16w;
-        if (apk[k] >= 0) {
-          const int h = h0 + (apk[k] >> 20), w = w0 + ((apk[k] >> 8) & 0xfff);
-          if (h < P.H && w < P.W) s = (const void*)(a_img + (long long)(h * P.W + w) * P.a_pitch + (apk[k] & 0xff) * 8);
-        }
-        __builtin_amdgcn_global_load_lds(s, Al + (k * 4 + wave) * 1024, 16, 0, 0);
+      unsigned v = 0x80000000u;
+      if (apk[k] >= 0) {
+        const int h = h0 + (apk[k] >> 20), w = w0 + ((apk[k] >> 8) & 0xfff);
+        if (h < P.H && w < P.W) v = (unsigned)(((h * P.W + w) * (int)P.a_pitch + m0 + (apk[k] & 0xff) * 8) * 2);
       }
+      if (apk[k] != -1)   // (-1: this lane's 16 bytes are row padding or lie behind the image -- inside the B image: not touched)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(Al + (k * 4 + wave) * 1024), 16, v, 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < MAXB; ++k) {
-      if (bpk[k] != -1) {
-        const void* s = (const void*)gsd_zero16w;
-        if (bpk[k] >= 0) {
-          int hi, wi;
-          bool ok = true;
-          if (HALO) {
-            hi = h0 - 1 + ((bpk[k] >> 20) & 0xff);
-            wi = w0 - 1 + ((bpk[k] >> 8) & 0xfff);
-          } else {
-            const int t = (bpk[k] >> 28) & 7;
-            const int h = h0 + ((bpk[k] >> 20) & 0xff), w = w0 + ((bpk[k] >> 8) & 0xfff);
-            ok = h < P.H && w < P.W;      // the pixel itself is outside the reduction grid: A is zero there anyway
-            hi = P.stride * h + P.ty[t];
-            wi = P.stride * w + P.tx[t];
-          }
-          if (ok && (unsigned)hi < (unsigned)P.Hb && (unsigned)wi < (unsigned)P.Wb)
-            s = (const void*)(b_img + (long long)(hi * P.Wb + wi) * P.b_pitch + (bpk[k] & 0xff) * 8);
+      unsigned v = 0x80000000u;
+      if (bpk[k] >= 0) {
+        int hi, wi;
+        bool ok = true;
+        if (HALO) {
+          hi = h0 - 1 + ((bpk[k] >> 20) & 0xff);
+          wi = w0 - 1 + ((bpk[k] >> 8) & 0xfff);
+        } else {
+          const int t = (bpk[k] >> 28) & 7;
+          const int h = h0 + ((bpk[k] >> 20) & 0xff), w = w0 + ((bpk[k] >> 8) & 0xfff);
+          ok = h < P.H && w < P.W;      // the pixel itself is outside the reduction grid: A is zero there anyway
+          hi = P.stride * h + P.ty[t];
+          wi = P.stride * w + P.tx[t];
         }
-        __builtin_amdgcn_global_load_lds(s, Bl + (k * 4 + wave) * 1024, 16, 0, 0);
+        if (ok && (unsigned)hi < (unsigned)P.Hb && (unsigned)wi < (unsigned)P.Wb)
+          v = (unsigned)(((hi * P.Wb + wi) * (int)P.b_pitch + n0 + (bpk[k] & 0xff) * 8) * 2);
       }
+      if (bpk[k] != -1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(Bl + (k * 4 + wave) * 1024), 16, v, 0, 0, 0);
     }
     gsd_dma_barrier();   // vmcnt(0) + barrier: both images have landed
     // One flat, fully unrolled sequence of KS*TT steps (4 MFMAs each).  The B operand of step s+2 and, two steps before a
@@ -628,6 +630,10 @@ extern "C" int gsd_bf16_wgrad(const gsd_nhwc* a, const gsd_nhwc* b, int ntaps, i
   P.NPIX = pl.NPIX; P.KS = pl.NPIX / 32;
   P.stages_total = pl.stages_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   P.xcd = gsd_env_int("GSD_BF16_XCD", 1) != 0 ? 1 : 0;
+  GSD_REQUIRE((long long)a->H * a->W * a->pitch < (1LL << 30) && (long long)b->H * b->W * b->pitch < (1LL << 30), GSD_ERR_UNSUPPORTED,
+              "gsd_bf16_wgrad: one image of an operand exceeds 2 GiB");
+  P.a_img_bytes = (unsigned)((long long)a->H * a->W * a->pitch * 2);
+  P.b_img_bytes = (unsigned)((long long)b->H * b->W * b->pitch * 2);
   const int grid = pl.splits * pl.mblocks * pl.nblocks;
   int rc;
   hipStream_t st = (hipStream_t)stream;
