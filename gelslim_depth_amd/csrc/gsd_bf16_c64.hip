@@ -27,7 +27,6 @@
 
 #include <type_traits>
 
-__device__ const uint4 gsd_zero16_c64[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
 namespace {
 
@@ -67,6 +66,7 @@ struct C64P {
   const float *bw_scale, *bw_shift, *bw_mean, *bw_invstd;
   int N, H, W, Mpad;
   int tiles_y, tiles_x, ntiles;
+  unsigned img_bytes;   // one input image (buffer descriptor of the halo fills; below 2 GiB)
 };
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4), aligned(8)));
@@ -134,17 +134,19 @@ __global__ __launch_bounds__(512) void conv64_bf16_kernel(const C64P P) {
   auto fill = [&](int tile) {
     int n, h0, w0;
     decode(tile, n, h0, w0);
-    const u16* img = P.in + (long long)n * P.H * P.W * P.in_pitch;
+    // through a buffer descriptor of image n: a 32-bit byte offset per piece, zeros for everything outside the image from the range
+    // check (an offset beyond num_records) -- no zero line, no 64-bit address, no branch (profiles/ubench/buffer_lds_oob.hip)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.in + (long long)n * P.H * P.W * P.in_pitch), 0, P.img_bytes, 0x00020000);
 #pragma unroll
     for (int k = 0; k < C_NF_W; ++k) {
       if (k * NW + wave < C_NFILL) {   // wave-uniform
-        const void* sp = (const void*)gsd_zero16_c64;
+        unsigned v = 0x80000000u;
         const int hi = h0 - 1 + (xpk[k] >> 20), wi = w0 - 1 + ((xpk[k] >> 8) & 0xfff);
         if (xpk[k] >= 0 && (unsigned)hi < (unsigned)P.H && (unsigned)wi < (unsigned)P.W)
-          sp = (const void*)(img + (long long)(hi * P.W + wi) * P.in_pitch + (xpk[k] & 0xff));
+          v = (unsigned)(((hi * P.W + wi) * (int)P.in_pitch + (xpk[k] & 0xff)) * 2);
         // (the image ends in the middle of the last instruction: its surplus lanes are switched off, nothing lies behind it)
         if ((k * NW + wave + 1) * 64 <= C_SLOTS || xpk[k] >= 0)
-          __builtin_amdgcn_global_load_lds(sp, Al + (k * NW + wave) * 1024, 16, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(Al + (k * NW + wave) * 1024), 16, v, 0, 0, 0);
       }
     }
   };
@@ -358,6 +360,8 @@ int c64_common(C64P& P, const gsd_nhwc* in, const void* wt, const gsd_nhwc* out,
   GSD_REQUIRE(in->N == out->N && in->H == out->H && in->W == out->W, GSD_ERR_BAD_ARG, "%s: in/out extents differ", what);
   GSD_REQUIRE((out->pitch & 3) == 0, GSD_ERR_UNSUPPORTED, "%s: out pitch must be a multiple of 4", what);
   P.in = (const u16*)in->ptr; P.in_pitch = in->pitch; P.wt = (const u16*)wt;
+  GSD_REQUIRE((long long)in->H * in->W * in->pitch < (1LL << 30), GSD_ERR_UNSUPPORTED, "gsd_bf16_conv3x3_c64: one input image exceeds 2 GiB");
+  P.img_bytes = (unsigned)((long long)in->H * in->W * in->pitch * 2);
   P.out = (u16*)out->ptr; P.out_pitch = out->pitch; P.partials = partials;
   P.bw_y = nullptr; P.bw_pitch = 0; P.bw_scale = P.bw_shift = P.bw_mean = P.bw_invstd = nullptr;
   P.N = in->N; P.H = in->H; P.W = in->W; P.Mpad = round_up(C_M, 128);
