@@ -377,3 +377,14 @@ def test_bf16_transposed_conv_bias_gradient_from_the_dx_statistics(dims, n, h, w
     assert int((d > 0).sum()) <= sum(dims)                       # only bias-gradient entries may differ
     scale = float(g0.abs().max())
     assert float(d.max()) <= 1e-4 * scale + 1e-9
+
+
+def test_bf16_buffer_descriptor_fills_change_nothing(monkeypatch):
+    """GSD_BF16_CONV_BUF (default on): the 3x3 convolution's halo and weight fills go through buffer descriptors (zero padding from the
+    range check: an out-of-range lane of buffer_load ... lds writes zeros) instead of per-lane 64-bit addresses and a zero line: the
+    same bytes land in LDS, so two train steps agree bit for bit."""
+    dims = [32, 64, 128]
+    e0, l0, g0, p0, b0 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_CONV_BUF": "0"})
+    e1, l1, g1, p1, b1 = _bf16_step_state(dims, monkeypatch, {"GSD_BF16_CONV_BUF": "1"})
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)
