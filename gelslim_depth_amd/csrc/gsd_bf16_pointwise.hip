@@ -337,12 +337,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const BnBwdB P)
       wo[i] = MODE == 2 ? P.wout[gk * 8 + i] : 0.f;
       s1[i] = s2[i] = s3[i] = 0.f;
     }
-    for (int p = chunk * P.pixb + pl; p < p_end && pl < ppi; p += ppi) {
+    // the NEXT pixel's loads go out in front of this pixel's store: dz may alias g, so the compiler keeps loads behind older
+    // stores -- without the prefetch a thread has one load in flight and every pixel is a dependent round trip
+    const int p_first = chunk * P.pixb + pl;
+    const bool any = p_first < p_end && pl < ppi;
+    uint4 y_nx = make_uint4(0, 0, 0, 0), g_nx = make_uint4(0, 0, 0, 0);
+    float d_nx = 0.f;
+    if (any) {
+      const long long pix0 = (long long)n * HW + p_first;
+      y_nx = ld16(P.y.p + pix0 * P.y.pitch + gk * 8);
+      if (MODE == 2) d_nx = P.dout[pix0];
+      else g_nx = ld16(P.g.p + pix0 * P.g.pitch + gk * 8);
+    }
+    for (int p = p_first; p < p_end && pl < ppi; p += ppi) {
       const long long pix = (long long)n * HW + p;
       float yv[8], gv[8];
-      unpack8(ld16(P.y.p + pix * P.y.pitch + gk * 8), yv);
+      const uint4 y_cur = y_nx, g_cur = g_nx;
+      const float d = d_nx;
+      if (p + ppi < p_end) {
+        const long long pixn = pix + ppi;
+        y_nx = ld16(P.y.p + pixn * P.y.pitch + gk * 8);
+        if (MODE == 2) d_nx = P.dout[pixn];
+        else g_nx = ld16(P.g.p + pixn * P.g.pitch + gk * 8);
+      }
+      unpack8(y_cur, yv);
       if (MODE == 2) {
-        const float d = P.dout[pix];
 #pragma unroll
         for (int i = 0; i < 8; ++i) gv[i] = d * wo[i];
 #pragma unroll
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const BnBwdB P)
           s3[i] = fmaf(d, av, s3[i]);
         }
       } else {
-        unpack8(ld16(P.g.p + pix * P.g.pitch + gk * 8), gv);
+        unpack8(g_cur, gv);
       }
       if (MODE == 1) {
         const int h = p / P.y.W, w = p - h * P.y.W;
@@ -433,11 +452,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_bf16_kernel(const BnBw
       sc[i] = P.scale[gk * 8 + i]; sh[i] = P.shift[gk * 8 + i]; mu[i] = P.mean[gk * 8 + i]; is[i] = P.invstd[gk * 8 + i];
       s1[i] = s2[i] = 0.f;
     }
-    auto one_pixel = [&](int h, int w, const float* add) {   // dz of pixel (h, w); add: pooled gradient routed here, or null
-      const long long pix = ((long long)n * H + h) * W + w;
+    // dz of the pixel at `pix` from its raw output and skip gradient (already loaded); add: pooled gradient routed here, or null
+    auto pixel_from = [&](const uint4 yraw, const uint4 graw, long long pix, const float* add) {
       float yv[8], gv[8], dzv[8];
-      unpack8(ld16(P.y.p + pix * P.y.pitch + gk * 8), yv);
-      unpack8(ld16(P.g.p + pix * P.g.pitch + gk * 8), gv);
+      unpack8(yraw, yv);
+      unpack8(graw, gv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float gsum = add != nullptr ? gv[i] + add[i] : gv[i];
@@ -452,6 +471,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_bf16_kernel(const BnBw
         s1[i] += dq[i];
         s2[i] = fmaf(dq[i], (yv[i] - mu[i]) * is[i], s2[i]);
       }
+    };
+    auto one_pixel = [&](int h, int w, const float* add) {
+      const long long pix = ((long long)n * H + h) * W + w;
+      pixel_from(ld16(P.y.p + pix * P.y.pitch + gk * 8), ld16(P.g.p + pix * P.g.pitch + gk * 8), pix, add);
     };
     for (int p = chunk * P.pixb + pl; p < p_end && pl < ppi; p += ppi) {
       const int hp = p / Wp, wp = p - hp * Wp;
@@ -487,10 +510,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_bf16_kernel(const BnBw
           r3[i] = bi == 3 ? dp[i] : 0.f;
         }
       }
-      one_pixel(2 * hp, 2 * wp, r0);
-      one_pixel(2 * hp, 2 * wp + 1, r1);
-      one_pixel(2 * hp + 1, 2 * wp, r2);
-      one_pixel(2 * hp + 1, 2 * wp + 1, r3);
+      {
+        // the window's eight loads go out together, IN FRONT of its four stores: dz may alias g, so the compiler keeps every load
+        // of pixel k + 1 behind the store of pixel k -- four dependent round trips per thread instead of one
+        const long long p00 = ((long long)n * H + 2 * hp) * W + 2 * wp;
+        const long long px[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        uint4 yr[4], gr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          yr[k] = ld16(P.y.p + px[k] * P.y.pitch + gk * 8);
+          gr[k] = ld16(P.g.p + px[k] * P.g.pitch + gk * 8);
+        }
+        pixel_from(yr[0], gr[0], px[0], r0);
+        pixel_from(yr[1], gr[1], px[1], r1);
+        pixel_from(yr[2], gr[2], px[2], r2);
+        pixel_from(yr[3], gr[3], px[3], r3);
+      }
       const bool xcol = wp == Wp - 1 && (W & 1), xrow = hp == Hp - 1 && (H & 1);
       if (xcol) {
         one_pixel(2 * hp, W - 1, nullptr);
