@@ -171,6 +171,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(NhwcD y, const float* __r
   st16(a.p + p * a.pitch + gk * 8, pack8(f));
 }
 
+// The same, UNR pixels per thread (C / 8 divides 256: every network shape): a block's 256 threads are (256 / groups) pixel lanes x
+// groups channel groups, a thread keeps its group's coefficients and walks UNR pixels with all their loads in flight before the
+// first store -- four times the bytes in flight per thread, index arithmetic and coefficient loads paid once instead of per pixel.
+template <int UNR>
+__global__ __launch_bounds__(256) void bn_apply_multi_kernel(NhwcD y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             NhwcD a, int relu, long long npix) {
+  const int groups = y.C >> 3, ppi = 256 / groups;
+  const int pl = threadIdx.x / groups, gk = threadIdx.x - pl * groups;
+  const long long p0 = (long long)blockIdx.x * (ppi * UNR) + pl;
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + gk * 8), s1 = *reinterpret_cast<const f32x4*>(scale + gk * 8 + 4);
+  const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + gk * 8), h1 = *reinterpret_cast<const f32x4*>(shift + gk * 8 + 4);
+  uint4 raw[UNR];
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    const long long p = p0 + (long long)k * ppi;
+    raw[k] = p < npix ? ld16(y.p + p * y.pitch + gk * 8) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    const long long p = p0 + (long long)k * ppi;
+    float f[8];
+    unpack8(raw[k], f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[i] = fmaf(f[i], s0[i], h0[i]);
+      f[4 + i] = fmaf(f[4 + i], s1[i], h1[i]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = fmaxf(f[i], 0.f);
+    }
+    if (p < npix) st16(a.p + p * a.pitch + gk * 8, pack8(f));
+  }
+}
+
 // ---- a = relu(y * scale + shift) AND pooled = MaxPool2d(2)(a) in one pass (unet.py:15-16 followed by :26) ---------------
 // The encoder's second unit feeds a max-pool: the stand-alone pool re-reads the activation the apply pass has just written.
 // Thread = one 2x2 window x 8 channels over the ceil(H/2) x ceil(W/2) window grid: it reads the window's four raw values,
@@ -577,6 +612,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(NhwcD dz, NhwcD 
   st16(dz.p + p * dz.pitch + gk * 8, pack8(d));
 }
 
+// UNR pixels per thread (C / 8 divides 256), as bn_apply_multi_kernel: the 40 coefficient floats of a channel group are loaded
+// once per thread instead of once per pixel, and all of a thread's loads are in flight before its first (aliasing) store.
+template <int UNR>
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16_multi_kernel(NhwcD dz, NhwcD y, const float* __restrict__ scale,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                      const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                      long long npix) {
+  const int groups = y.C >> 3, ppi = 256 / groups;
+  const int pl = threadIdx.x / groups, gk = threadIdx.x - pl * groups;
+  const long long p0 = (long long)blockIdx.x * (ppi * UNR) + pl;
+  float sc[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = gk * 8 + i;
+    sc[i] = scale[c]; mu[i] = mean[c]; is[i] = invstd[c]; k1[i] = c1[c]; k2[i] = c2[c];
+  }
+  uint4 dr[UNR], yr[UNR];
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    const long long p = p0 + (long long)k * ppi;
+    const bool ok = p < npix;
+    dr[k] = ok ? ld16(dz.p + p * dz.pitch + gk * 8) : make_uint4(0, 0, 0, 0);
+    yr[k] = ok ? ld16(y.p + p * y.pitch + gk * 8) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) {
+    const long long p = p0 + (long long)k * ppi;
+    float d[8], yv[8];
+    unpack8(dr[k], d);
+    unpack8(yr[k], yv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (yv[i] - mu[i]) * is[i];
+      d[i] = sc[i] * (d[i] - k1[i] - xh * k2[i]);
+    }
+    if (p < npix) st16(dz.p + p * dz.pitch + gk * 8, pack8(d));
+  }
+}
+
 // ---- per-channel sums over a window of every image (ConvTranspose2d bias gradient) -------------------------------------
 // stage 1: grid (chunks, N), same thread layout as the BatchNorm reduction; stage 2: one thread per channel, fp64
 __global__ __launch_bounds__(256) void channel_sums_stage1(NhwcD t, int y0, int x0, int hh, int ww, int pixb, int chunks,
@@ -722,8 +796,15 @@ extern "C" int gsd_bf16_bn_apply(const gsd_nhwc* y, const float* scale, const fl
   if (int e = check_c8(a, "gsd_bf16_bn_apply a")) return e;
   GSD_REQUIRE(scale && shift && same_extent(y, a), GSD_ERR_BAD_ARG, "gsd_bf16_bn_apply: bad argument");
   const long long np = npix_of(y), total = np * (y->C / 8);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
-                     scale, shift, to_nhwc(*a), relu, np);
+  const int groups = y->C / 8;
+  if (groups <= 256 && 256 % groups == 0 && total >= 256 * 4 * 64) {
+    const long long ppb = (256 / groups) * 4;
+    hipLaunchKernelGGL(bn_apply_multi_kernel<4>, dim3((unsigned)ceil_div64(np, ppb)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y), scale, shift,
+                       to_nhwc(*a), relu, np);
+  } else {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*y),
+                       scale, shift, to_nhwc(*a), relu, np);
+  }
   GSD_LAUNCH_CHECK("gsd_bf16_bn_apply");
   return GSD_OK;
 }
@@ -856,8 +937,15 @@ extern "C" int gsd_bf16_bn_bwd_apply(const gsd_nhwc* dz, const gsd_nhwc* y, cons
   if (int e = check_c8(y, "gsd_bf16_bn_bwd_apply y")) return e;
   GSD_REQUIRE(scale && mean && invstd && c1 && c2 && same_extent(dz, y), GSD_ERR_BAD_ARG, "gsd_bf16_bn_bwd_apply: bad argument");
   const long long np = npix_of(y), total = np * (y->C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  const int groups = y->C / 8;
+  if (groups <= 256 && 256 % groups == 0 && total >= 256 * 4 * 64) {
+    const long long ppb = (256 / groups) * 4;
+    hipLaunchKernelGGL(bn_bwd_apply_bf16_multi_kernel<4>, dim3((unsigned)ceil_div64(np, ppb)), dim3(256), 0, (hipStream_t)stream, to_nhwc(*dz),
+                       to_nhwc(*y), scale, mean, invstd, c1, c2, np);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      to_nhwc(*dz), to_nhwc(*y), scale, mean, invstd, c1, c2, np);
+  }
   GSD_LAUNCH_CHECK("gsd_bf16_bn_bwd_apply");
   return GSD_OK;
 }
