@@ -73,50 +73,76 @@ static inline __host__ __device__ int wimg_pairs(int mode, int Cout, const WImg&
   return (mode == 3 && d.Mp == 4 * Cout) ? Cout * d.Kp : d.Mp * d.Kp;
 }
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // the flat parameter arena aligns tensors to 4 bytes only
+// A thread owns EIGHT consecutive k of one row: every tap's store is then 16 bytes (2-byte stores move 128 B per wave-instruction),
+// and the fp32 source of a (row, k) pair's taps is still one contiguous run.
 __global__ __launch_bounds__(256) void weight_images_kernel(WJobs jobs) {
   int q = 0;
   while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.j[q + 1].first_block) ++q;   // (<= 32 jobs: a linear search)
   const WJob& J = jobs.j[q];
   const WImg d = J.d;
   const bool quad = J.mode == 3 && d.Mp == 4 * J.Cout;
-  const int pairs = quad ? J.Cout * d.Kp : d.Mp * d.Kp;
-  const int base = ((int)blockIdx.x - J.first_block) * WPAIRS;
-  const int end = base + WPAIRS < pairs ? base + WPAIRS : pairs;
+  const int k8n = d.Kp >> 3;                                  // Kp % 32 == 0
+  const int units = (quad ? J.Cout : d.Mp) * k8n;             // (row, 8 k) units of the job
+  const int base = ((int)blockIdx.x - J.first_block) * (WPAIRS / 8);
+  const int end = base + WPAIRS / 8 < units ? base + WPAIRS / 8 : units;
   const size_t plane = (size_t)d.Mp * d.Kp;
-  for (int pe = base + threadIdx.x; pe < end; pe += 256) {
-    const int m = pe / d.Kp, k = pe - m * d.Kp;
-    if (quad) {   // m = co
-      f4u v = f4u{0.f, 0.f, 0.f, 0.f};
-      if (k < d.K) v = *reinterpret_cast<const f4u*>(J.w + ((size_t)k * J.Cout + m) * 4);
+  for (int ue = base + threadIdx.x; ue < end; ue += 256) {
+    const int m = ue / k8n, k0 = (ue - m * k8n) * 8;
+    const size_t o = (size_t)m * d.Kp + k0;
+    if (quad) {   // m = co; rows q * Cout + co
+      float v[4][8];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) J.out[(size_t)(qq * J.Cout + m) * d.Kp + k] = f32_to_bf16(v[qq]);
+      for (int j = 0; j < 8; ++j) {
+        f4u t4 = f4u{0.f, 0.f, 0.f, 0.f};
+        if (k0 + j < d.K) t4 = *reinterpret_cast<const f4u*>(J.w + ((size_t)(k0 + j) * J.Cout + m) * 4);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) v[qq][j] = t4[qq];
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) st16(J.out + (size_t)(qq * J.Cout + m) * d.Kp + k0, pack8(v[qq]));
       continue;
     }
-    const bool in = m < d.M && k < d.K;
     switch (J.mode) {
-      case 0: {
-        const float* src = J.w + ((size_t)m * J.Cin + k) * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) J.out[t * plane + pe] = f32_to_bf16(in ? src[t] : 0.f);
-        break;
-      }
+      case 0:
       case 1: {
-        const float* src = J.w + ((size_t)k * J.Cin + m) * 9;
+        float v[9][8];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) J.out[t * plane + pe] = f32_to_bf16(in ? src[8 - t] : 0.f);
+        for (int j = 0; j < 8; ++j) {
+          const bool in = m < d.M && k0 + j < d.K;
+          const float* src = J.mode == 0 ? J.w + ((size_t)m * J.Cin + k0 + j) * 9 : J.w + ((size_t)(k0 + j) * J.Cin + m) * 9;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) v[t][j] = in ? src[J.mode == 0 ? t : 8 - t] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) st16(J.out + t * plane + o, pack8(v[t]));
         break;
       }
-      case 2: J.out[pe] = f32_to_bf16(in ? J.w[(size_t)m * J.Cin * 9 + k] : 0.f); break;
+      case 2: {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m < d.M && k0 + j < d.K) ? J.w[(size_t)m * J.Cin * 9 + k0 + j] : 0.f;
+        st16(J.out + o, pack8(v));
+        break;
+      }
       case 3: {
+        float v[8];
         const int qq = m / J.Cout, co = m - qq * J.Cout;
-        J.out[pe] = f32_to_bf16(in ? J.w[((size_t)k * J.Cout + co) * 4 + qq] : 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m < d.M && k0 + j < d.K) ? J.w[((size_t)(k0 + j) * J.Cout + co) * 4 + qq] : 0.f;
+        st16(J.out + o, pack8(v));
         break;
       }
       default: {
-        f4u v = f4u{0.f, 0.f, 0.f, 0.f};
-        if (in) v = *reinterpret_cast<const f4u*>(J.w + ((size_t)m * J.Cout + k) * 4);
+        float v[4][8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) J.out[t * plane + pe] = f32_to_bf16(v[t]);
+        for (int j = 0; j < 8; ++j) {
+          f4u t4 = f4u{0.f, 0.f, 0.f, 0.f};
+          if (m < d.M && k0 + j < d.K) t4 = *reinterpret_cast<const f4u*>(J.w + ((size_t)m * J.Cout + k0 + j) * 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t][j] = t4[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st16(J.out + t * plane + o, pack8(v[t]));
         break;
       }
     }
