@@ -748,7 +748,7 @@ __global__ __launch_bounds__(1024) void convT_bias_combine_kernel(const float* _
 
 // pixels per block of the stand-alone reduce kernels: target_blocks = 0 -> GSD_BF16_BN_BLOCKS (tuning) or the default
 int pick_pixb(int N, int HW, int target_blocks = 0) {
-  if (target_blocks <= 0) target_blocks = gsd_env_int("GSD_BF16_BN_BLOCKS", 1024);
+  if (target_blocks <= 0) target_blocks = gsd_env_int("GSD_BF16_BN_BLOCKS", 512);   // (2048 until round 4; 512 / 1024 / 2048 measured 25.9-26.1 / 26.15 / 26.3 ms per step)
   long long pixb = ((long long)N * HW + target_blocks - 1) / target_blocks;
   pixb = (pixb + 31) / 32 * 32;
   return (int)(pixb < 32 ? 32 : pixb);
