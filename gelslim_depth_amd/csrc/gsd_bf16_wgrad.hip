@@ -449,12 +449,46 @@ __global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* __restr
   }
 }
 
+// Large dW (>= 64 k (m, n) pairs): a thread owns one (m, n) and all T taps -- its T results are consecutive in the output
+// ([m][n][t]: a wave writes one contiguous run instead of 4-byte pieces T floats apart), the slab reads stay coalesced over n.
+// Same order of additions per element as gwgrad_reduce_kernel<1>.
+template <int T>
+__global__ __launch_bounds__(256) void gwgrad_reduce_mn_kernel(const float* __restrict__ slabs, float* __restrict__ out, int splits, int M,
+                                                               int Ncols, int NcOut) {
+  const long long mn = (long long)M * Ncols, per = (long long)T * mn;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < mn; e += (long long)gridDim.x * 256) {
+    const int n = (int)(e % Ncols), m = (int)(e / Ncols);
+    float r[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float* sp = slabs + (size_t)t * mn + e;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 3 < splits; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += sp[(size_t)(k + u) * per];
+      }
+      for (; k < splits; ++k) s4[0] += sp[(size_t)k * per];
+      r[t] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    if (n < NcOut) {
+      float* o = out + ((size_t)m * NcOut + n) * T;
+#pragma unroll
+      for (int t = 0; t < T; ++t) o[t] = r[t];
+    }
+  }
+}
+
 // the reduce launch: many splits of a small dW -> 8 threads per element
 static void launch_reduce(const float* slabs, float* out, int splits, int T, int M, int Ncols, int NcOut, hipStream_t st) {
   const long long per = (long long)T * M * Ncols;
   if (splits >= 32 && per <= (1 << 20)) {
     const int grid = (int)(ceil_div64(per, 32) < 8192 ? ceil_div64(per, 32) : 8192);
     hipLaunchKernelGGL(gwgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, st, slabs, out, splits, T, M, Ncols, NcOut);
+  } else if ((long long)M * Ncols >= 65536 && (T == 9 || T == 4)) {
+    const int grid = (int)(ceil_div64((long long)M * Ncols, 256) < 4096 ? ceil_div64((long long)M * Ncols, 256) : 4096);
+    if (T == 9) hipLaunchKernelGGL(gwgrad_reduce_mn_kernel<9>, dim3(grid), dim3(256), 0, st, slabs, out, splits, M, Ncols, NcOut);
+    else hipLaunchKernelGGL(gwgrad_reduce_mn_kernel<4>, dim3(grid), dim3(256), 0, st, slabs, out, splits, M, Ncols, NcOut);
   } else {
     const int grid = (int)(ceil_div64(per, 256) < 4096 ? ceil_div64(per, 256) : 4096);
     hipLaunchKernelGGL(gwgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, st, slabs, out, splits, T, M, Ncols, NcOut);
