@@ -815,3 +815,62 @@ def test_conv3x3_c64_weights_resident_equals_the_dma_kernel_bf16(n, h, w):
     L.check(L.lib.gsd_bf16_conv3x3_c64(C.byref(din), img.data_ptr(), C.byref(L.make_nhwc(got)), None, None, L.stream_ptr()), "plain c64")
     torch.cuda.synchronize()
     assert torch.equal(ref.view(torch.int16), got.view(torch.int16))
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 13, 18, 64), (3, 9, 11, 40), (1, 20, 26, 128)])
+def test_output_conv_with_batchnorm_folded_in_equals_apply_then_conv_bf16(n, h, w, c):
+    """gsd_bf16_bn_relu_conv1x1_out (the last unit's BatchNorm + ReLU formed inside the 1x1 output convolution, unet.py:15-16 then
+    :54) == gsd_bf16_bn_apply followed by gsd_bf16_conv1x1_out, bit for bit, and both match torch fp64 on the bf16 activation."""
+    L = _lib()
+    g = torch.Generator().manual_seed(3 * c + h)
+    y = bf16r(torch.randn((n, c, h, w), generator=g))
+    scale, shift = torch.rand((c,), generator=g) + 0.5, 0.4 * torch.randn((c,), generator=g)
+    wo, bo = torch.randn((1, c), generator=g) / c ** 0.5, torch.randn((1,), generator=g)
+    dev = [t.float().cuda() for t in (scale, shift, wo, bo)]
+    ybuf = to_nhwc(y)
+    a = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device="cuda")
+    out0 = torch.full((n, 1, h, w), float("nan"), device="cuda")
+    out1 = torch.full((n, 1, h, w), float("nan"), device="cuda")
+    dy_ = L.make_nhwc(ybuf)
+    L.check(L.lib.gsd_bf16_bn_apply(C.byref(dy_), dev[0].data_ptr(), dev[1].data_ptr(), C.byref(L.make_nhwc(a)), 1, L.stream_ptr()), "apply")
+    L.check(L.lib.gsd_bf16_conv1x1_out(C.byref(L.make_nhwc(a)), dev[2].data_ptr(), dev[3].data_ptr(), 1, out0.data_ptr(), L.stream_ptr()), "out")
+    L.check(L.lib.gsd_bf16_bn_relu_conv1x1_out(C.byref(dy_), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), 1,
+                                               out1.data_ptr(), L.stream_ptr()), "bn_relu_out")
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1)
+    ref = F.conv2d(from_nhwc(a, 0, c).double(), wo.double()[:, :, None, None], bo.double())
+    assert float((out1.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n,H,W,ctot,cup,oy,ox,hh,ww", [(2, 21, 27, 96, 32, 0, 1, 20, 26), (3, 16, 24, 64, 32, 0, 0, 16, 24),
+                                                        (2, 19, 23, 128, 64, 1, 2, 16, 20)])
+def test_convT_bias_gradient_from_dx_statistics_bf16(n, H, W, ctot, cup, oy, ox, hh, ww):
+    """gsd_bf16_convT_bias_grad: per-channel sums over the transposed convolution's window of the gradient slice, assembled from
+    the statistics rows of a gsd_bf16_conv3x3 launch that wrote the WHOLE concat gradient (sums of what it stored) minus the F.pad
+    strips -- against gsd_bf16_channel_sums over the window and against torch fp64 on the stored bf16 values."""
+    L = _lib()
+    g = torch.Generator().manual_seed(H * 7 + ctot)
+    k = 64
+    x = bf16r(torch.randn((n, k, H, W), generator=g))
+    wt = bf16r(torch.randn((ctot, k, 3, 3), generator=g) / (3.0 * k ** 0.5))
+    xin = to_nhwc(x)
+    img = weight_image(wt.permute(2, 3, 0, 1).reshape(9, ctot, k))
+    gcat = torch.zeros((n, H, W, ctot), dtype=torch.bfloat16, device="cuda")
+    rows = L.lib.gsd_bf16_conv_partial_rows(n, H, W, ctot)
+    mp = L.lib.gsd_bf16_conv_mpad(ctot)
+    part = torch.full((rows, 2 * mp), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_conv3x3(C.byref(L.make_nhwc(xin)), img.data_ptr(), C.byref(L.make_nhwc(gcat)), k, ctot, part.data_ptr(), None,
+                                   L.stream_ptr()), "conv3x3 + statistics")
+    gup = L.make_nhwc(gcat, ctot - cup, cup)
+    nws = max(L.lib.gsd_bf16_convT_bias_grad_workspace(n, H, W, oy, ox, hh, ww, cup), L.lib.gsd_bf16_channel_sums_workspace(n, hh, ww, cup))
+    ws = torch.empty((nws,), device="cuda")
+    db0 = torch.full((cup,), float("nan"), device="cuda")
+    db1 = torch.full((cup,), float("nan"), device="cuda")
+    L.check(L.lib.gsd_bf16_channel_sums(C.byref(gup), oy, ox, hh, ww, db0.data_ptr(), ws.data_ptr(), nws, L.stream_ptr()), "channel_sums")
+    L.check(L.lib.gsd_bf16_convT_bias_grad(part.data_ptr(), rows, 2 * mp, ctot - cup, C.byref(gup), oy, ox, hh, ww, db1.data_ptr(),
+                                           ws.data_ptr(), nws, L.stream_ptr()), "convT_bias_grad")
+    torch.cuda.synchronize()
+    ref = gcat.double().cpu()[:, oy:oy + hh, ox:ox + ww, ctot - cup:].sum(dim=(0, 1, 2))
+    scale = float(gcat.double().cpu()[..., ctot - cup:].abs().sum(dim=(0, 1, 2)).max())
+    for got in (db0, db1):
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * scale + 1e-9
