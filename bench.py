@@ -45,6 +45,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the short extra legs at N=1 (configs[1] inference, configs[3] shares at batch 16 / 8, bf16 at 16 / 32)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the 'val L1 vs ref' leg at N=1 (one eval forward against tests/golden/gfull_b1.npz, outside the timed region)")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -129,6 +131,39 @@ def cpu_baseline(seconds_budget: float = 25.0):
     return {"value": round(b / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} full train steps (fwd+MSE+bwd+Adam) of batch {b} at 3x{H}x{W} fp32, "
                       f"torch CPU operators as the reference executes them, median {med:.2f} s/step"}
+
+
+def parity_vs_reference(dev, dtype):
+    """BASELINE.json's "val L1 vs ref" (the path of /root/reference/test_utils/test_depth_estimation.py:17,61-65: build the
+    model, load weights, eval(), model(x=...)): one eval-mode forward of the full-size net at 1x3x320x427 through the HIP path,
+    against the output the REFERENCE itself produced for the same weights and input on PyTorch-CPU (tests/golden/gfull_b1.npz,
+    made by tests/golden/make_golden.py importing the reference; weights and input are regenerated from the fixture's seed by
+    the build-owned generators).  Runs outside the timed region.  Bound: the north star's 1e-3 relative L1 on fp32 depth;
+    the bf16 mixed-precision form is not the metric's arithmetic and is reported against the 2e-2 its test allows."""
+    import numpy as np
+    import torch
+    from gelslim_depth_amd import synth
+    from gelslim_depth_amd.models.unet import UNet
+    fixture = "gfull_b1.npz"
+    g = np.load(os.path.join(REPO, "tests", "golden", fixture))
+    dims = [int(v) for v in g["meta/dims"]]
+    seed = int(g["meta/seed"])
+    st = synth.make_state(3, 1, dims, seed, "conditioned")
+    x, _ = synth.make_batch(1, H, W, seed + 1)
+    m = UNet(n_channels=3, n_classes=1, layer_dimensions=dims, precision="bf16" if dtype == "bf16" else "fp32")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(x=torch.from_numpy(x).to(dev)).double().cpu().numpy()
+    ref = g["y_eval"].astype(np.float64)
+    rel = float(np.abs(y - ref).sum() / np.abs(ref).sum())
+    bound = 1e-3 if dtype == "f32" else 2e-2
+    del m
+    torch.cuda.empty_cache()
+    return {"rel_l1": float("%.3e" % rel), "bound": bound, "ok": bool(rel <= bound), "fixture": fixture,
+            "what": "eval-mode forward, 1x3x320x427, full-size net: sum|y_hip - y_ref| / sum|y_ref| against the reference's own "
+                    "PyTorch-CPU output (fixture generated by importing the reference, tests/golden/make_golden.py)",
+            "dtype": dtype}
 
 
 class Leg:
@@ -507,9 +542,19 @@ def main():
                     "note": "single-GPU measurements; an upper bound on the multi-GPU speedup, not a scaling measurement"}
         if extra:
             out["extra"] = extra
+        parity_failed = False
+        if world == 1 and not args.no_parity:
+            leg = None
+            torch.cuda.empty_cache()
+            out["parity"] = parity_vs_reference(dev, args.dtype)
+            parity_failed = not out["parity"]["ok"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            print("bench.py: the HIP path's output differs from the reference's by more than the bound: %r" % (out["parity"],),
+                  file=sys.stderr)
+            sys.exit(3)
     if pg is not None:
         torch.distributed.destroy_process_group()
 

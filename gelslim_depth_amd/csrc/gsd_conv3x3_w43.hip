@@ -68,6 +68,8 @@ struct W43Params {
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
   int NP, RPI, NI, RO;   // 16-byte halo pieces (X4): pieces per window row, rows per DMA instruction, instructions per plane, read offset
   int fold;              // tile rows run over the padded flat rows of the whole batch (see w43_row)
+  int nslab;             // K-slab form (SPLIT): the block's channel chunks are slab k's share, its y goes to `slabs`
+  float* slabs;          // [nslab][tile blocks][64 channels][64 Winograd tiles][4 pixels]: un-reduced outputs of the K slabs
   unsigned long long* stamps;   // diagnostic builds only
 };
 
@@ -214,6 +216,138 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
   }
 }
 
+// Epilogue shared by the convolution kernel (y = A^T M of its accumulators) and the K-slab reducer (y = sum of the slabs' tiles): NCHW
+// stores into two destination segments with crop, BatchNorm partial sums, or the fused BatchNorm-backward form.  The lane owns the
+// four pixels (h_t, w0 + 4 tq ..) of image n_t (fold) / n for the 16 output channels m0 + m * 16 + j * 4 + reg.
+template <int WM, class GetY>
+__device__ __forceinline__ void w43_epilogue(const W43Params& P, int n, int pt, int wave, int wm, int mbb, int m0, int j, int l16,
+                                             int n_t, int h_t, int w0, int tq, int vmask, const float* sBw, GetY&& get_y) {
+  constexpr int MT = 4, BM = W43_BM, BMB = WM * BM;
+  // ---- epilogue: y = A^T M, NCHW stores (two destination segments with crop), BatchNorm partial sums ----------------------
+  // per destination: element offset of the tile's first pixel inside a plane, and the mask of its pixels that are stored
+  int off0 = 0, off1 = 0, sm0 = 0, sm1 = 0;
+  {
+    const int h = h_t, w = w0 + 4 * tq;
+    const int fo0 = P.fold ? n_t * (int)P.dst0.ns : 0, fo1 = P.fold ? n_t * (int)P.dst1.ns : 0;
+    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
+    if (h >= 0 && (unsigned)hd < (unsigned)P.dst0.H) {
+      off0 = fo0 + hd * P.dst0.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0 |= 1 << i;
+    }
+    hd = h - P.dst1.oh;
+    wd = w - P.dst1.ow;
+    if (h >= 0 && (unsigned)hd < (unsigned)P.dst1.H) {
+      off1 = fo1 + hd * P.dst1.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1 |= 1 << i;
+    }
+  }
+  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
+  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * 4 + wave) * (2 * P.Mpad) : nullptr;
+
+  if (P.bw_raw == nullptr) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        const bool first = co < P.dst0.C;
+        const int cd = first ? co : co - P.dst0.C;
+        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+        float* const px = (first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs) + (first ? off0 : off1);
+        const int sm = co_ok ? (first ? sm0 : sm1) : 0;
+        float y[4];
+        get_y(m, reg, y);
+        // statistics over the pixels that are STORED (the destination's window: for a cropped second destination -- the
+        // backward of F.pad -- the sums are those of the crop, e.g. the ConvT bias gradient; the same pixels as `vmask` for a
+        // full-size destination)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (sm >> i & 1) {
+            s1 += y[i];
+            s2 = fmaf(y[i], y[i], s2);
+          }
+        }
+        if (sm == 15) {
+          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (sm >> i & 1) px[i] = y[i];
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  } else {
+    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX.
+    // Loads and stores share vmcnt: the raw values of one m-tile (4 rows x 4 pixels) are loaded together in front of its
+    // stores, the coefficients come from LDS.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float xr[4][4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        const float* const rp = P.bw_raw + (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs + off0;
+        if (sm0 == 15) {
+          const f32x4 t = *reinterpret_cast<const f32x4u*>(rp);
+          xr[reg][0] = t[0]; xr[reg][1] = t[1]; xr[reg][2] = t[2]; xr[reg][3] = t[3];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xr[reg][i] = (sm0 >> i & 1) ? rp[i] : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + m * 16 + j * 4 + reg;
+        float* const px = d0 + (long long)co * P.dst0.cs + off0;
+        const int cl = wm * BM + m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BMB + cl], bmu = sBw[2 * BMB + cl], bis = sBw[3 * BMB + cl];
+        const int sm = co < P.Cout ? sm0 : 0;
+        float y[4];
+        get_y(m, reg, y);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = xr[reg][i];
+          const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[i] : 0.f;
+          y[i] = dz;
+          s1 += dz;
+          s2 = fmaf(dz, (x - bmu) * bis, s2);
+        }
+        if (sm == 15) {
+          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (sm >> i & 1) px[i] = y[i];
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  }
+}
+
 // WM = groups of 4 waves per block: 1 -> 64 m x 256 px, two blocks per CU; 2 -> 128 m x 256 px (two 64-channel weight
 // images side by side), 8 waves, one block per CU: the halo DMA -- the expensive part of the data movement -- is then shared
 // by twice the MFMAs (9 instead of 13 DMA instructions per wave and chunk).  Tuning option (GSD_W43_BIG), not the default.
@@ -246,7 +380,12 @@ __device__ __forceinline__ void w43_loader(const W43Params& P, float* smem, int 
 // around the tensor: gsd_src.slack) and the lane that moved it overwrites its outside floats with the padding value once its
 // own fills have landed (vmcnt(0)), in front of the chunk's barrier.  Ablation (fills removed, profiles/build_diag.sh
 // -DW43_ABL): the dword halo fills cost 9.5 % of the kernel's time, the weight fills 3 %, the barrier 2 %.
-template <int WM, int X4M, int NL, bool FAST, bool PLAIN>
+//
+// SPLIT ("K slabs"): a launch whose tile grid covers a fraction of the chip's 512 block slots (the 40 x 53 and 20 x 26 levels at
+// small per-GPU batches: 152-600 blocks of 128-256 chunks each) is cut along the input channels instead: block (tile, slab k)
+// runs chunks [k nchunks / S, (k+1) nchunks / S) and stores its UN-reduced y = A^T M tile to P.slabs; w43_slab_reduce_kernel adds
+// the S slabs in slab order and runs this kernel's epilogue (crop, statistics, fused BatchNorm-backward) on the sums.
+template <int WM, int X4M, int NL, bool FAST, bool PLAIN, bool SPLIT = false>
 #ifndef W43_ABL   // diagnostic builds: 1 no weight fills, 2 no halo fills, 4 no barrier per chunk, 8 no wait for the fills, 16 / 32 halo fills from hot addresses (results are then garbage)
 #define W43_ABL 0
 #endif
@@ -257,6 +396,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   static_assert(NL == 0 || WM == 1, "loader waves serve one 64-channel weight image");
   constexpr bool X4 = X4M == 1, U4 = X4M == 2;
   static_assert(!U4 || (FAST && WM == 1 && NL == 0), "unaligned 16-byte halo pieces: the straight-fill 4-wave form");
+  static_assert(!SPLIT || (FAST && WM == 1 && NL == 0 && !U4), "K slabs: the straight-fill 4-wave form");
   constexpr int MT = 4, BM = W43_BM, WS = BM, WTILE = W43_WTILE, W4 = W43_W4 * WM, NT = 256 * WM + 64 * NL, NWAVE = 4 * WM;
   constexpr int NWI = (W4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -276,7 +416,10 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   // a contiguous range of logical ids (pixel tile major, m-block minor) and its L2 serves the halo once.
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mbb = lid % P.mblocks;              // P.mblocks counts blocks (WM 64-channel groups each)
-  const int pt = lid / P.mblocks;
+  const int slab = SPLIT ? (lid / P.mblocks) % P.nslab : 0;   // SPLIT: pixel tile major, then slab, m-block minor
+  const int pt = SPLIT ? lid / (P.mblocks * P.nslab) : lid / P.mblocks;
+  const int c_lo = SPLIT ? (int)((long long)slab * P.nchunks / P.nslab) : 0;            // this block's channel chunks
+  const int c_hi = SPLIT ? (int)((long long)(slab + 1) * P.nchunks / P.nslab) : P.nchunks;
   const int mb = mbb * WM + wm;
   const int m0 = mb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
@@ -396,14 +539,16 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   long long xl0[NPP];   // first segment's offsets as 64-bit lane values (the address add is then a single instruction)
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) xl0[pp] = xo0[pp];
+  // SPLIT: a slab that lies wholly in the second (concat) segment starts there -- its padding positions, plane pointer and lane offsets
+  const bool s1_start = SPLIT && P.src1.C > 0 && c_lo * 4 > P.src0.C;
   if constexpr (NL == 0 && !U4)
   {
     // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only: the lanes that
     // would otherwise DMA the sentinel there on every fill); visible to the consumers after the first barrier
-    const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
+    const float pad0 = (s1_start ? P.src1.relu : P.src0.relu) ? __builtin_nanf("") : 0.f;
 #pragma unroll
     for (int pp = 0; pp < NPP; ++pp)
-      if (p_on[pp] && xo0[pp] == -1) {
+      if (p_on[pp] && (s1_start ? xo1[pp] : xo0[pp]) == -1) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           if constexpr (X4) {   // the unit's own plane: the other planes' pieces belong to other units
@@ -419,6 +564,14 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   int d_seg = 0, d_left = P.src0.C;
   const float* d_base = P.src0.p + (long long)n * P.src0.ns;
   long long d_cs = P.src0.cs;
+  if constexpr (SPLIT) {   // first channel plane of the slab
+    if (s1_start) {
+      d_base = P.src1.p + (long long)n * P.src1.ns + (long long)(c_lo * 4 - P.src0.C) * P.src1.cs;
+      d_cs = P.src1.cs;
+    } else {
+      d_base += (long long)(c_lo * 4) * P.src0.cs;
+    }
+  }
   const float* d_sent = X4 ? (P.src0.relu ? &gsd_pad16_w43[4] : &gsd_pad16_w43[0]) : (P.src0.relu ? &gsd_pad_w43[1] : &gsd_pad_w43[0]);
   int d_xo[NPP];
 #pragma unroll
@@ -428,13 +581,13 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   // Cin % 4 == 0), so a halo slot is: the lanes that have a pixel move it, the plane pointer advances by one channel.  The
   // switch to the second (concat) segment happens once per block, between two chunks: new plane pointer and lane offsets,
   // and the padding positions of that segment are written into each LDS image the first time it is filled from it.
-  const int f_sw = P.src1.C > 0 ? P.src0.C / 4 : -1;   // first chunk of the second segment
+  const int f_sw = (P.src1.C > 0 && !s1_start) ? P.src0.C / 4 : -1;   // first chunk of the second segment
   int f_xo[NPP];
   long long f_xl[NPP];
 #pragma unroll
   for (int pp = 0; pp < NPP; ++pp) {
-    f_xo[pp] = xo0[pp];
-    f_xl[pp] = xo0[pp];
+    f_xo[pp] = s1_start ? xo1[pp] : xo0[pp];
+    f_xl[pp] = f_xo[pp];
   }
   auto begin_fill = [&](int chunk, int buf) {
     if constexpr (U4) {
@@ -648,13 +801,13 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
 
   const int a_lane = wm * WTILE + l16 * 4;
   if constexpr (NL == 0) {
-    if constexpr (FAST) begin_fill(0, 0);
+    if constexpr (FAST) begin_fill(c_lo, 0);
 #pragma unroll
-    for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, 0, 0);
+    for (int slot = 0; slot < NWI + 4; ++slot) dma_slot(slot, c_lo, 0);
   }
   W43_STAMP(5)   // prologue
-  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
-    const int cur = chunk & 1;
+  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+    const int cur = (chunk - c_lo) & 1;
     if constexpr (U4) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the chunk have landed
       if (u_patch) {   // a block at the left / right image edge: the outside floats of the straddling pieces this lane moved
@@ -687,7 +840,7 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
       sc = sAff[kc], sh = sAff[Kpad + kc];
       lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
     }
-    const bool more = chunk + 1 < P.nchunks;
+    const bool more = chunk + 1 < c_hi;
     const float* Wc = smem + cur * BUF;
 #ifndef W43_PF   // k-steps the weight operand is read ahead of its MFMAs
 #define W43_PF 1
@@ -769,31 +922,6 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
   }
 
   // ---- epilogue: y = A^T M, NCHW stores (two destination segments with crop), BatchNorm partial sums ----------------------
-  // per destination: element offset of the tile's first pixel inside a plane, and the mask of its pixels that are stored
-  int off0 = 0, off1 = 0, sm0 = 0, sm1 = 0;
-  {
-    const int h = h_t, w = w0 + 4 * tq;
-    const int fo0 = P.fold ? n_t * (int)P.dst0.ns : 0, fo1 = P.fold ? n_t * (int)P.dst1.ns : 0;
-    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
-    if (h >= 0 && (unsigned)hd < (unsigned)P.dst0.H) {
-      off0 = fo0 + hd * P.dst0.ws + wd;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0 |= 1 << i;
-    }
-    hd = h - P.dst1.oh;
-    wd = w - P.dst1.ow;
-    if (h >= 0 && (unsigned)hd < (unsigned)P.dst1.H) {
-      off1 = fo1 + hd * P.dst1.ws + wd;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((vmask >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1 |= 1 << i;
-    }
-  }
-  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
-  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
-  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * 4 + wave) * (2 * P.Mpad) : nullptr;
-
   auto out_transform = [&](int m, int reg, float (&y)[4]) {
     const float M0 = acc[m][0][reg], M1 = acc[m][1][reg], M2 = acc[m][2][reg];
     const float M3 = acc[m][3][reg], M4 = acc[m][4][reg], M5 = acc[m][5][reg];
@@ -804,102 +932,19 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
     y[3] = fmaf(8.f, m34, m12) + M5;
   };
 
-  if (P.bw_raw == nullptr) {
+  if constexpr (SPLIT) {
+    // K slab: the un-reduced tile, every lane its 16 B (padding tiles and channels included; the reducer masks)
+    float* const tile = P.slabs + (((size_t)slab * (gridDim.x / P.nslab) + (size_t)pt * P.mblocks + mbb) * BM) * 256 + (wave * 16 + l16) * 4;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + m * 16 + j * 4 + reg;
-        const bool first = co < P.dst0.C;
-        const int cd = first ? co : co - P.dst0.C;
-        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
-        float* const px = (first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs) + (first ? off0 : off1);
-        const int sm = co_ok ? (first ? sm0 : sm1) : 0;
         float y[4];
         out_transform(m, reg, y);
-        // statistics over the pixels that are STORED (the destination's window: for a cropped second destination -- the
-        // backward of F.pad -- the sums are those of the crop, e.g. the ConvT bias gradient; the same pixels as `vmask` for a
-        // full-size destination)
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (sm >> i & 1) {
-            s1 += y[i];
-            s2 = fmaf(y[i], y[i], s2);
-          }
-        }
-        if (sm == 15) {
-          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (sm >> i & 1) px[i] = y[i];
-        }
-        if (prow != nullptr) {
-          s1 = reduce16_to_lane15(s1);
-          s2 = reduce16_to_lane15(s2);
-          if (l16 == 15 && co < P.Mpad) {
-            prow[co] = s1;
-            prow[P.Mpad + co] = s2;
-          }
-        }
+        *reinterpret_cast<f32x4*>(tile + (m * 16 + j * 4 + reg) * 256) = f32x4{y[0], y[1], y[2], y[3]};
       }
-    }
   } else {
-    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX.
-    // Loads and stores share vmcnt: the raw values of one m-tile (4 rows x 4 pixels) are loaded together in front of its
-    // stores, the coefficients come from LDS.
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float xr[4][4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + m * 16 + j * 4 + reg;
-        const float* const rp = P.bw_raw + (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs + off0;
-        if (sm0 == 15) {
-          const f32x4 t = *reinterpret_cast<const f32x4u*>(rp);
-          xr[reg][0] = t[0]; xr[reg][1] = t[1]; xr[reg][2] = t[2]; xr[reg][3] = t[3];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xr[reg][i] = (sm0 >> i & 1) ? rp[i] : 0.f;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + m * 16 + j * 4 + reg;
-        float* const px = d0 + (long long)co * P.dst0.cs + off0;
-        const int cl = wm * BM + m * 16 + j * 4 + reg;
-        const float bsc = sBw[cl], bsh = sBw[BMB + cl], bmu = sBw[2 * BMB + cl], bis = sBw[3 * BMB + cl];
-        const int sm = co < P.Cout ? sm0 : 0;
-        float y[4];
-        out_transform(m, reg, y);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float x = xr[reg][i];
-          const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[i] : 0.f;
-          y[i] = dz;
-          s1 += dz;
-          s2 = fmaf(dz, (x - bmu) * bis, s2);
-        }
-        if (sm == 15) {
-          *reinterpret_cast<f32x4u*>(px) = f32x4{y[0], y[1], y[2], y[3]};
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (sm >> i & 1) px[i] = y[i];
-        }
-        if (prow != nullptr) {
-          s1 = reduce16_to_lane15(s1);
-          s2 = reduce16_to_lane15(s2);
-          if (l16 == 15 && co < P.Mpad) {
-            prow[co] = s1;
-            prow[P.Mpad + co] = s2;
-          }
-        }
-      }
-    }
+    w43_epilogue<WM>(P, n, pt, wave, wm, mbb, m0, j, l16, n_t, h_t, w0, tq, vmask, sBw, out_transform);
   }
 #ifdef GSD_W43_STAMPS
   W43_STAMP(4)   // epilogue
@@ -908,6 +953,62 @@ __global__ __launch_bounds__(256 * WM + 64 * NL, NL > 0 ? 3 : (WM == 1 ? W43_MIN
     for (int i = 0; i < 8; ++i) P.stamps[((size_t)blockIdx.x * NWAVE + wave8) * 8 + i] = st_acc[i];
   }
 #endif
+}
+
+// K-slab reducer: block (pixel tile, m-block) adds the S un-reduced 64 x 256 tiles the SPLIT blocks left in P.slabs, in slab order
+// (run-to-run bitwise), and runs the convolution's epilogue on the sums -- same lane -> (channel, pixel) map, same destinations,
+// same partial rows, same fused BatchNorm-backward form.  HBM-bound: (S + 1) x 64 KiB per block.
+__global__ __launch_bounds__(256) void w43_slab_reduce_kernel(const W43Params P) {
+  __shared__ float sBw[4 * W43_BM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane >> 4, l16 = lane & 15;
+  const int lid = blockIdx.x;
+  const int mbb = lid % P.mblocks, pt = lid / P.mblocks;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = P.fold ? 0 : pt / tpi;
+  const int rt = pt - n * tpi;
+  const int ty = rt / P.tiles_x;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+  const int q = wave * 16 + l16;
+  const bool q_ok = q < P.TH * P.TWq;
+  const int tr = q_ok ? q / P.TWq : 0;
+  const int tq = q_ok ? q - tr * P.TWq : 0;
+  int vmask = 0, n_t, h_t;
+  w43_row(P, n, h0 + tr, n_t, h_t);
+  if (q_ok && h_t >= 0 && h_t < P.H) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (w0 + 4 * tq + i < P.W) vmask |= 1 << i;
+  }
+  if (P.bw_raw != nullptr) {
+    if (tid < W43_BM) {
+      const int co = mbb * W43_BM + tid < P.Cout ? mbb * W43_BM + tid : 0;
+      sBw[tid] = P.bw_scale[co];
+      sBw[W43_BM + tid] = P.bw_shift[co];
+      sBw[2 * W43_BM + tid] = P.bw_mean[co];
+      sBw[3 * W43_BM + tid] = P.bw_invstd[co];
+    }
+    __syncthreads();
+  }
+  const size_t sstride = (size_t)gridDim.x * W43_BM * 256;
+  const float* const tile = P.slabs + (size_t)lid * W43_BM * 256 + q * 4;
+  f32x4 ys[4][4];   // all 16 channel rows of slab 0 in flight, then one slab after the other on top
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ys[m][reg] = *reinterpret_cast<const f32x4*>(tile + (m * 16 + j * 4 + reg) * 256);
+  for (int k = 1; k < P.nslab; ++k) {
+    const float* const tk = tile + (size_t)k * sstride;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) ys[m][reg] += *reinterpret_cast<const f32x4*>(tk + (m * 16 + j * 4 + reg) * 256);
+  }
+  auto get_y = [&](int m, int reg, float (&y)[4]) {
+    y[0] = ys[m][reg][0], y[1] = ys[m][reg][1], y[2] = ys[m][reg][2], y[3] = ys[m][reg][3];
+  };
+  w43_epilogue<1>(P, n, pt, wave, 0, mbb, mbb * W43_BM, j, l16, n_t, h_t, w0, tq, vmask, sBw, get_y);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -935,7 +1036,7 @@ bool plan_w43(int N, int H, int W, int M, W43Plan* best) {
   for (int fold = 0; fold <= 1; ++fold) {
     if (fold && (fold_mode == 0 || N <= 1 || (long)H * W > 8192)) continue;
     static const int tws[9] = {32, 64, 16, 8, 4, 28, 56, 24, 48};
-    for (int k = 0; k < (fold ? 9 : 5); ++k) {
+    for (int k = 0; k < (fold ? 9 : 5); ++k) {   // (7- and 14-tile rows without folding, folding at 80 x 106: measured, no gain)
       const int tw = tws[k];
       if (force_tw && tw != force_tw) continue;
       const int twq = tw / 4;
@@ -1021,17 +1122,28 @@ int halo_read_cycles(int TWq, int LP, int PS, int off) {
 }
 
 // one launcher per kernel instantiation (the address of the kernel keys the per-device launch-attribute cache)
-template <int WM, int X4, int NL, bool FAST, bool PLAIN = false>
+template <int WM, int X4, int NL, bool FAST, bool PLAIN = false, bool SPLIT = false>
 int launch_one(const W43Params& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN, SPLIT>);
   if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w43: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL((conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN>), dim3(grid), dim3(256 * WM + 64 * NL), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w43_kernel<WM, X4, NL, FAST, PLAIN, SPLIT>), dim3(grid), dim3(256 * WM + 64 * NL), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w43");
+  return GSD_OK;
+}
+
+// K-slab form: the SPLIT blocks (grid = tile blocks x slabs), then the reducer over the tile blocks
+int launch_split(const W43Params& P, int base_grid, size_t lds, hipStream_t st, bool x4, bool plain) {
+  const int grid = base_grid * P.nslab;
+  int e = x4 ? (plain ? launch_one<1, 1, 0, true, true, true>(P, grid, lds, st) : launch_one<1, 1, 0, true, false, true>(P, grid, lds, st))
+             : (plain ? launch_one<1, 0, 0, true, true, true>(P, grid, lds, st) : launch_one<1, 0, 0, true, false, true>(P, grid, lds, st));
+  if (e != GSD_OK) return e;
+  hipLaunchKernelGGL(w43_slab_reduce_kernel, dim3(base_grid), dim3(256), 0, st, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_w43 (slab reduce)");
   return GSD_OK;
 }
 
@@ -1045,7 +1157,49 @@ int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm,
   return x4 ? launch_one<1, true, 0, false>(P, grid, lds, st) : launch_one<1, false, 0, false>(P, grid, lds, st);
 }
 
+// K slabs of a launch of `base` tile blocks of `nchunks` 4-channel chunks (1: the launch runs as it is).  Two blocks are resident
+// per CU and the dispatcher deals blocks over the 256 CUs, so a CU ends up with k = ceil(blocks / 256) of them and the launch takes
+// as long as that CU: pairs of blocks at the shared rate and, for an odd k, one block that has the CU to itself and runs 1.8x
+// faster.  The 20 x 26 level at batch 8 is 304 (152) blocks of 128-256 chunks: k = 2 (1) where 1.19 (0.59) would do.  Cutting the
+// chunks into S slabs multiplies the blocks and divides their length; it costs the fixed part of a block S times over and the
+// reducer's launch and pass over (S + 1) x 64 KiB per tile block.  Constants fitted to profiles/r05_kslabs_b{8,16,32}.txt (117
+// timings of 22 launch shapes, S = 1..8: rms error 4 %; the fitted model picks the fastest measured S on 20 of the 22 shapes
+// and is within 0.5 % on the other two): 2.6 us per chunk of a block that shares its CU, 4 us per block, a lone block at 0.55 of a
+// pair's time, the reducer at 12 us + 6 TB/s.  GSD_W43_SPLIT: 0 / 1 never, S >= 2 that many wherever the shape admits it.
+int w43_pick_slabs(long base, int nchunks, bool bw) {
+  const int forced = gsd_env_int("GSD_W43_SPLIT", -1);
+  if (forced == 0 || forced == 1) return 1;
+  auto t_us = [&](int S) {
+    const long k = (base * S + 255) / 256;
+    const double cu = (double)(k / 2) + (k & 1 ? 0.55 : 0.0);
+    double t = cu * (2.6 * nchunks / S + 4.0);
+    if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
+    return t;
+  };
+  int best = 1;
+  double tb = t_us(1) * (forced > 1 ? 1e9 : 0.97);   // a split has to buy 3 %
+  for (int S = 2; S <= 8 && nchunks / S >= 8; ++S) {
+    if (forced > 1 && S != forced) continue;
+    const double t = t_us(S);
+    if (t < tb) {
+      tb = t;
+      best = S;
+    }
+  }
+  return best;
+}
+
 }  // namespace
+
+// Floats of K-slab scratch gsd_conv3x3_w43_ws wants for this shape (0: it runs unsplit).
+extern "C" int64_t gsd_conv3x3_w43_workspace(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 != 0) return 0;
+  W43Plan p;
+  if (!plan_w43(N, H, W, Cout, &p)) return 0;
+  const long base = (long)(p.fold ? 1 : N) * p.tiles_y * p.tiles_x * p.mblocks;
+  const int S = w43_pick_slabs(base, Cin / 4, true);
+  return S > 1 ? (int64_t)S * base * W43_BM * 256 : 0;
+}
 
 extern "C" int gsd_conv3x3_w43_partial_rows(int N, int H, int W, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
@@ -1063,7 +1217,7 @@ extern "C" int64_t gsd_conv3x3_w43_mfma_count(int N, int H, int W, int Cin, int 
 
 static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
                     float* partials, const float* bw_raw, const float* bw_scale, const float* bw_shift, const float* bw_mean,
-                    const float* bw_invstd, int N, int H, int W, void* stream) {
+                    const float* bw_invstd, int N, int H, int W, void* stream, float* ws = nullptr, int64_t ws_elems = 0) {
   GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: null argument");
   GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: nsrc/ndst must be 1 or 2");
   GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: bad sizes");
@@ -1168,18 +1322,37 @@ static int w43_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
     }
   }
   P.fold = pl.fold;
+  P.nslab = 1;
+  P.slabs = nullptr;
   const long grid = (long)(pl.fold ? 1 : N) * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: grid too large");
   GSD_REQUIRE(!pl.fold || nl == 0, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w43: the loader-wave form does not fold rows (GSD_W43_FOLD=0)");
   const size_t lds = (size_t)(2 * (WM * W43_WTILE + (u4 ? P.NI * 256 : 4 * P.PS)) + 2 * 4 * P.nchunks + 4 * WM * W43_BM) * sizeof(float);
   bool plain = gsd_env_int("GSD_W43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any source segment
   for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
+  // K slabs (the caller lends scratch): straight-fill 4-wave form only; the slab count shrinks to what the scratch holds
+  if (ws != nullptr && fast && WM == 1 && nl == 0 && !u4) {
+    GSD_REQUIRE(((uintptr_t)ws & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w43: workspace must be 16-byte aligned");
+    int S = w43_pick_slabs(grid, P.nchunks, bw_raw != nullptr);
+    while (S > 1 && (int64_t)S * grid * W43_BM * 256 > ws_elems) --S;
+    if (S > 1 && grid * S < 2147483647L) {
+      P.nslab = S;
+      P.slabs = ws;
+      return launch_split(P, (int)grid, lds, (hipStream_t)stream, x4, plain);
+    }
+  }
   return launch_w43(P, (int)grid, lds, (hipStream_t)stream, WM, x4, nl, fast, plain, u4);
 }
 
 extern "C" int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
                                float* partials, int N, int H, int W, void* stream) {
   return w43_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, stream);
+}
+
+extern "C" int gsd_conv3x3_w43_ws(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                                  float* partials, float* ws, int64_t ws_elems, int N, int H, int W, void* stream) {
+  return w43_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, stream, ws,
+                  ws_elems);
 }
 
 extern "C" int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
@@ -1190,4 +1363,15 @@ extern "C" int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt,
   GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
               "gsd_conv3x3_w43_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
   return w43_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream);
+}
+
+extern "C" int gsd_conv3x3_w43_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                               const float* raw, const float* scale, const float* shift, const float* mean,
+                                               const float* invstd, float* partials, float* ws, int64_t ws_elems, int N, int H,
+                                               int W, void* stream) {
+  GSD_REQUIRE(dst && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w43_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w43_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
+  return w43_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream, ws, ws_elems);
 }

@@ -45,6 +45,20 @@ class _ConvForm:
         self.dgrad_bnrelu = lib.gsd_conv3x3_w43_dgrad_bnrelu if algo else lib.gsd_conv3x3_dgrad_bnrelu
         self.partial_rows = lib.gsd_conv3x3_w43_partial_rows if algo else lib.gsd_conv3x3_partial_rows
         self.mode_f, self.mode_d = (4, 5) if algo else (0, 1)
+        # K-slab scratch the form would like for a shape (the Winograd form only; 0: the shape runs unsplit)
+        self.workspace = lib.gsd_conv3x3_w43_workspace if algo else (lambda *a: 0)
+
+    def run(self, ws, src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st):
+        """conv3x3 forward / dX; `ws`: the engine's K-slab scratch (train mode) or None."""
+        if self.algo and ws is not None:
+            return lib.gsd_conv3x3_w43_ws(src, nsrc, wt, cin, cout, dst, ndst, part, ws.data_ptr(), ws.numel(), n, h, w, st)
+        return self.conv(src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st)
+
+    def run_bnrelu(self, ws, src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st):
+        if self.algo and ws is not None:
+            return lib.gsd_conv3x3_w43_dgrad_bnrelu_ws(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part,
+                                                       ws.data_ptr(), ws.numel(), n, h, w, st)
+        return self.dgrad_bnrelu(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st)
 
 
 class _Unit:
@@ -142,6 +156,7 @@ class UNetEngine:
         max_part = 1
         max_ws = 1
         max_gp = 0
+        max_slab = 0
         for u in self.units:
             lh, lw = hs[u.level], ws[u.level]
             if u.raw is None:
@@ -166,6 +181,10 @@ class UNetEngine:
             rows = u.form_f.partial_rows(n, lh, lw, u.cout)
             max_part = max(max_part, rows * 2 * _r64(u.cout))
             if train:
+                # K slabs (gsd_conv3x3_w43_ws) for the launches that would leave most of the chip idle: train mode only --
+                # an eval-mode forward keeps the one summation order whatever the batch (image i of a batch == the image alone)
+                max_slab = max(max_slab, u.form_f.workspace(n, lh, lw, u.cin, u.cout),
+                               u.form_d.workspace(n, lh, lw, u.cout, u.cin) if u.need_dgrad else 0)
                 max_part = max(max_part, lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw) * 3 * u.cout)
                 max_ws = max(max_ws, lib.gsd_conv3x3_wgrad_workspace(n, lh, lw, u.cin, u.cout))
                 # d_raw goes to a row-pitched scratch buffer (16-byte aligned rows) when both of its readers -- dW and dX
@@ -197,6 +216,7 @@ class UNetEngine:
                                  for l in range(1, self.L + 1)] if train else [None] * self.L)
         self.gp = torch.empty((max_gp,), **f32) if (train and max_gp) else None   # pitched d_raw scratch, one unit at a time
         self.partials = torch.empty((max_part,), **f32)
+        self.conv_ws = torch.empty((max_slab,), **f32) if (train and max_slab) else None
         # fp64 column sums of a dX launch's statistics (ConvT bias gradients): gsd_bn_reduce_partials wants (1 + 64) x 2 C doubles
         self.db_sums = torch.empty((65 * 2 * max(u.cin for u in self.units),), device=dev, dtype=torch.float64) if train else None
         self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
@@ -220,7 +240,8 @@ class UNetEngine:
         dst = L.dst_array([L.make_dst(u.raw)])
         part = self.partials.data_ptr() if train else None
         ev = self._log_begin()
-        check(u.form_f.conv(arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part, n, lh, lw, st), "conv3x3")
+        check(u.form_f.run(self.conv_ws if train else None, arr, len(srcs), u.wt_f.data_ptr(), u.cin, u.cout, dst, 1, part,
+                           n, lh, lw, st), "conv3x3")
         self._log_end(ev, u.cout, u.cin, n, lh, lw, u.form_f.algo)
         if train:
             rows = u.form_f.partial_rows(n, lh, lw, u.cout)
@@ -390,8 +411,8 @@ class UNetEngine:
         check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.src_array([L.make_src(u.dsrc)])
         ev = self._log_begin()
-        check(u.form_d.conv(s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts),
-                            self.partials.data_ptr() if stats else None, n, lh, lw, st), "conv3x3 dgrad")
+        check(u.form_d.run(self.conv_ws, s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts),
+                           self.partials.data_ptr() if stats else None, n, lh, lw, st), "conv3x3 dgrad")
         self._log_end(ev, u.cin, u.cout, n, lh, lw, u.form_d.algo)
         return u.form_d.partial_rows(n, lh, lw, u.cin) if stats else 0
 
@@ -404,9 +425,9 @@ class UNetEngine:
         d = L.make_dst(prev.g)
         prev.fused_rows = u.form_d.partial_rows(n, lh, lw, u.cin)
         ev = self._log_begin()
-        check(u.form_d.dgrad_bnrelu(C.byref(s), u.wt_d.data_ptr(), u.cout, u.cin, C.byref(d), prev.raw.data_ptr(),
-                                           prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
-                                           prev.invstd.data_ptr(), self.partials.data_ptr(), n, lh, lw, st),
+        check(u.form_d.run_bnrelu(self.conv_ws, C.byref(s), u.wt_d.data_ptr(), u.cout, u.cin, C.byref(d), prev.raw.data_ptr(),
+                                  prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
+                                  prev.invstd.data_ptr(), self.partials.data_ptr(), n, lh, lw, st),
               "conv3x3_dgrad_bnrelu")
         self._log_end(ev, u.cin, u.cout, n, lh, lw, u.form_d.algo)
 

@@ -152,6 +152,20 @@ int gsd_conv3x3_w43(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
 int gsd_conv3x3_w43_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
                                  const float* raw, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, float* partials, int N, int H, int W, void* stream);
+/* "K slab" form of the two Winograd entry points for launches whose tile grid leaves most of the chip idle (the 40x53 and
+ * 20x26 levels at small per-GPU batches: 150-600 blocks for 512 block slots): the input channels are cut into S slabs, block
+ * (tile, slab) writes its un-reduced output tile to `ws`, and a second launch adds the slabs in slab order (run-to-run
+ * bitwise) and runs the usual epilogue (crop, statistics, fused BatchNorm-backward).  gsd_conv3x3_w43_workspace gives the
+ * floats of scratch the library would like for a shape (0: it runs the shape unsplit); a smaller or null `ws` reduces S, down
+ * to the plain launch.  The rounding differs from the unsplit launch (two partial sums instead of one), so a caller that
+ * needs batch-size-independent bits (eval-mode inference) passes ws = NULL.  Same operators as above (unet.py:11,14). */
+int64_t gsd_conv3x3_w43_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_w43_ws(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                       float* partials, float* ws, int64_t ws_elems, int N, int H, int W, void* stream);
+int gsd_conv3x3_w43_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                    const float* raw, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, float* partials, float* ws, int64_t ws_elems, int N, int H, int W,
+                                    void* stream);
 
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 6. */

@@ -4,7 +4,7 @@ tag=$1; shift; ctrs=$1; shift
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_pmc.log 2>&1
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-parity "$@" > gpurun_out/${tag}_pmc.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY' > gpurun_out/${tag}_pmc.txt
 import csv, sys, collections

@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-parity "$@" > gpurun_out/${tag}_bench.log 2>&1
 grep '^{' gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench.json
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${tag}_kernel_stats.csv
