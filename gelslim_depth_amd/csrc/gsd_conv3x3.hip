@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 3 : 2) void conv3x3_dma_kernel(const
     if (opix[t] >= 0) {
       const int h = h0 + (opix[t] >> 16), w = w0 + (opix[t] & 0xffff);
       int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
-      if ((unsigned)hd < (unsigned)P.dst0.H && (unsigned)wd < (unsigned)P.dst0.W) ooff0[t] = hd * P.dst0.W + wd;
+      if ((unsigned)hd < (unsigned)P.dst0.H && (unsigned)wd < (unsigned)P.dst0.W) ooff0[t] = hd * P.dst0.ws + wd;
       hd = h - P.dst1.oh;
       wd = w - P.dst1.ow;
-      if ((unsigned)hd < (unsigned)P.dst1.H && (unsigned)wd < (unsigned)P.dst1.W) ooff1[t] = hd * P.dst1.W + wd;
+      if ((unsigned)hd < (unsigned)P.dst1.H && (unsigned)wd < (unsigned)P.dst1.W) ooff1[t] = hd * P.dst1.ws + wd;
     }
   }
   float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
@@ -440,7 +440,7 @@ static int conv3x3_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, 
   GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3: source segments hold %d channels, Cin=%d", csum, Cin);
   csum = 0;
   for (int i = 0; i < ndst; ++i) {
-    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3 dst")) return e;
+    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3 dst", true)) return e;   // the epilogue addresses rows through w_stride
     csum += dst[i].C;
   }
   GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3: destination segments hold %d channels, Cout=%d", csum, Cout);

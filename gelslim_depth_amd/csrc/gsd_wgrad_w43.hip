@@ -51,7 +51,7 @@ extern "C" void gsd_wg43_set_stamp_buffer(void* p) { g_wg43_stamp_buf = (unsigne
 struct WgW43Params {
   SrcD a0, a1;  // activation (B operand), up to two concatenated segments
   SrcD dy;      // gradient w.r.t. the raw conv output (plain)
-  float* slabs; // [split][18 = r*6+f][M][Ncols]
+  float* slabs; // [split][9 = r*3+s][M][Ncols]: G^T applied per split
   int M, Ncols;
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, XS;
@@ -731,8 +731,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       const int mr = m0 + wm * 32 + m * 16 + j * 4 + reg;
       const int col = n0 + wn * 16 + l16;
       if (mr < P.M && col < P.Ncols) {
+        // G^T (6 frequencies -> 3 taps of kernel row r) HERE, per split: it is linear, so the slab reduction only adds -- and
+        // the slabs are 9 planes instead of 18 (half the stores of this epilogue, half the reducer's reads)
 #pragma unroll
-        for (int t = 0; t < 18; ++t) P.slabs[(((size_t)split * 18 + t) * P.M + mr) * P.Ncols + col] = acc[m][t][reg];
+        for (int r = 0; r < 3; ++r) {
+          const float D0 = acc[m][r * 6 + 0][reg], D1 = acc[m][r * 6 + 1][reg], D2 = acc[m][r * 6 + 2][reg];
+          const float D3 = acc[m][r * 6 + 3][reg], D4 = acc[m][r * 6 + 4][reg], D5 = acc[m][r * 6 + 5][reg];
+          float* const o = P.slabs + (((size_t)split * 9 + r * 3) * P.M + mr) * P.Ncols + col;
+          const size_t pl = (size_t)P.M * P.Ncols;
+          o[0] = 0.25f * D0 - (1.f / 6.f) * (D1 + D2) + (1.f / 24.f) * (D3 + D4);
+          o[pl] = (1.f / 6.f) * (D2 - D1) + (1.f / 12.f) * (D3 - D4);
+          o[2 * pl] = (1.f / 6.f) * (D3 + D4 - D1 - D2) + D5;
+        }
       }
     }
 #ifdef GSD_WG43_STAMPS
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
 #endif
 }
 
-// slab[split][r*6+f][co][ci] -> dW[co][ci][r][s] = sum_f G[f][s] * (sum over splits, in a fixed order).
+// slab[split][r*3+s][co][ci] -> dW[co][ci][r][s] = sum over splits, in a fixed order (the blocks applied G^T themselves).
 // Block = 64 elements x 16 split lanes: the layers with few (co, ci) pairs are the ones with hundreds of splits, and one
 // thread per element would walk them serially (95 us per launch on average before, most of it latency).
 template <int WR_LANES>
@@ -755,33 +765,29 @@ __global__ __launch_bounds__(WR_LANES == 1 ? 256 : 64 * WR_LANES) void wgrad_w43
   const long long plane = (long long)M * Ncols;
   const long long total = 3 * plane;
   const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
-  __shared__ float red[6][WR_LANES][EL];
+  __shared__ float red[3][WR_LANES][EL];
   for (long long e0 = (long long)blockIdx.x * EL; e0 < total; e0 += (long long)gridDim.x * EL) {
     const long long e = e0 + el;
     const bool ok = e < total;
     const int r = ok ? (int)(e / plane) : 0;
     const long long mc = ok ? e - r * plane : 0;
-    float D[6];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) {
+    for (int f = 0; f < 3; ++f) {
       float s = 0.f;
       if (ok)
-        for (int k = sl; k < splits; k += WR_LANES) s += slabs[((size_t)k * 18 + r * 6 + f) * plane + mc];
+        for (int k = sl; k < splits; k += WR_LANES) s += slabs[((size_t)k * 9 + r * 3 + f) * plane + mc];
       red[f][sl][el] = s;
     }
     __syncthreads();
     if (sl == 0 && ok) {
+      float* o = dw + (size_t)mc * 9 + r * 3;
 #pragma unroll
-      for (int f = 0; f < 6; ++f) {
+      for (int f = 0; f < 3; ++f) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < WR_LANES; ++i) s += red[f][i][el];
-        D[f] = s;
+        o[f] = s;
       }
-      float* o = dw + (size_t)mc * 9 + r * 3;
-      o[0] = 0.25f * D[0] - (1.f / 6.f) * (D[1] + D[2]) + (1.f / 24.f) * (D[3] + D[4]);
-      o[1] = (1.f / 6.f) * (D[2] - D[1]) + (1.f / 12.f) * (D[3] - D[4]);
-      o[2] = (1.f / 6.f) * (D[3] + D[4] - D[1] - D[2]) + D[5];
     }
     __syncthreads();
   }
@@ -829,7 +835,7 @@ WgW43Plan plan_wg43(int N, int H, int W, int M, int Ncols) {
   if (splits > 2048) splits = 2048;
   if (splits < 1) splits = 1;
   p.splits = splits;
-  p.slab_elems = (int64_t)splits * 18 * M * Ncols;
+  p.slab_elems = (int64_t)splits * 9 * M * Ncols;
   return p;
 }
 
