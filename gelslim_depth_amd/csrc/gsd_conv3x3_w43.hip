@@ -1166,16 +1166,18 @@ int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm,
 // timings of 22 launch shapes, S = 1..8: rms error 4 %; the fitted model picks the fastest measured S on 20 of the 22 shapes
 // and is within 0.5 % on the other two): 2.6 us per chunk of a block that shares its CU, 4 us per block, a lone block at 0.55 of a
 // pair's time, the reducer at 12 us + 6 TB/s.  GSD_W43_SPLIT: 0 / 1 never, S >= 2 that many wherever the shape admits it.
+double w43_time_us(long base, int nchunks, int S, bool bw) {
+  const long k = (base * S + 255) / 256;
+  const double cu = (double)(k / 2) + (k & 1 ? 0.55 : 0.0);
+  double t = cu * (2.6 * nchunks / S + 4.0);
+  if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
+  return t;
+}
+
 int w43_pick_slabs(long base, int nchunks, bool bw) {
   const int forced = gsd_env_int("GSD_W43_SPLIT", -1);
   if (forced == 0 || forced == 1) return 1;
-  auto t_us = [&](int S) {
-    const long k = (base * S + 255) / 256;
-    const double cu = (double)(k / 2) + (k & 1 ? 0.55 : 0.0);
-    double t = cu * (2.6 * nchunks / S + 4.0);
-    if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
-    return t;
-  };
+  auto t_us = [&](int S) { return w43_time_us(base, nchunks, S, bw); };
   int best = 1;
   double tb = t_us(1) * (forced > 1 ? 1e9 : 0.97);   // a split has to buy 3 %
   for (int S = 2; S <= 8 && nchunks / S >= 8; ++S) {
@@ -1199,6 +1201,17 @@ extern "C" int64_t gsd_conv3x3_w43_workspace(int N, int H, int W, int Cin, int C
   const long base = (long)(p.fold ? 1 : N) * p.tiles_y * p.tiles_x * p.mblocks;
   const int S = w43_pick_slabs(base, Cin / 4, true);
   return S > 1 ? (int64_t)S * base * W43_BM * 256 : 0;
+}
+
+// Modelled run time of the launch in microseconds (w43_pick_slabs' model; slabs != 0: with the K-slab form where it pays):
+// what gsd_conv3x3_prefers_w2d compares the two-dimensional form against.
+extern "C" double gsd_conv3x3_w43_estimate_us(int N, int H, int W, int Cin, int Cout, int slabs) {
+  W43Plan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w43(N, H, W, Cout, &p)) return 0.0;
+  const long base = (long)(p.fold ? 1 : N) * p.tiles_y * p.tiles_x * p.mblocks;
+  const int nchunks = ceil_div(Cin, 4);
+  const int S = (slabs && Cin % 4 == 0) ? w43_pick_slabs(base, nchunks, false) : 1;
+  return w43_time_us(base, nchunks, S, false);
 }
 
 extern "C" int gsd_conv3x3_w43_partial_rows(int N, int H, int W, int Cout) {

@@ -59,6 +59,8 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
     case 4: *rows = round_up(Ci, 4) * 18; *M = Co; break;       // k = ci*18+r*6+f   m = co   (Winograd F(4,3) rows)
     case 5: *rows = round_up(Co, 4) * 18; *M = Ci; break;       // k = co*18+r*6+f (flip) m = ci
     case 7: *rows = round_up(Co, 8) * 4; *M = Ci; break;        // k = co*4+khkw     m = ci   (convT dgrad, LDS-DMA kernel)
+    case 8: *rows = round_up(Ci, 4) * 24; *M = Co; break;       // k = ci*24+fr*6+fc m = co   (Winograd F(2x4,3x3), gsd_conv3x3_w2d)
+    case 9: *rows = round_up(Co, 4) * 24; *M = Ci; break;       // k = co*24+fr*6+fc (flip) m = ci
     default: *rows = round_up(Ci, 32); *M = Co * 4; break;      // k = ci            m = co*4+khkw  (mode 6)
   }
   if (mode == 6 || mode == 7) {
@@ -80,7 +82,7 @@ static void layout_dims(int mode, int Co, int Ci, int* rows, int* M, int* BM, in
   }
 }
 extern "C" int64_t gsd_weight_layout_size(int mode, int Co, int Ci) {
-  if (mode < 0 || mode > 7 || Co <= 0 || Ci <= 0) return 0;
+  if (mode < 0 || mode > 9 || Co <= 0 || Ci <= 0) return 0;
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
   return (int64_t)mblocks * rows * pitch;
@@ -165,10 +167,70 @@ __global__ __launch_bounds__(256) void weight_layout_w43_kernel(int mode, const 
     o[320] = g2;
   }
 }
+// Modes 8 / 9 (two-dimensional Winograd U = G2 g G4^T), one thread per (m-block, k channel, output channel of the block): the nine
+// taps are read once and the 24 transformed values written.  G2 of F(2,3): rows (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1); G4 of
+// F(4,3) as above.  Image of one (m-block, 4-channel chunk): [ci & 3][frequency pair f >> 1 (12)][channel half (2)][l (16)][f & 1][m-tile
+// of the half (2)] with channel = half*32 + m-tile*16 + l: a wave of gsd_conv3x3_w2d owns one channel half, and its 16 lanes l read
+// the two frequencies x two m-tiles of a pair as 16 consecutive 16-byte pieces.
+__global__ __launch_bounds__(256) void weight_layout_w2d_kernel(int mode, const float* __restrict__ w, int Co, int Ci,
+                                                                 float* __restrict__ wt, int kpad, int M, int mblocks) {
+  const long long total = (long long)mblocks * kpad * 64;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int cm = (int)(e & 63);           // channel inside the m-block
+    const long long t = e >> 6;
+    const int kch = (int)(t % kpad);
+    const int mb = (int)(t / kpad);
+    const int m = mb * 64 + cm;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[r][c] = 0.f;
+    if (m < M && kch < (mode == 8 ? Ci : Co)) {
+      // forward: g = W[m][kch]; dX: the flipped kernel with the channels swapped, g[r][c] = W[kch][m][2-r][2-c]
+      const float* src = mode == 8 ? w + ((size_t)m * Ci + kch) * 9 : w + ((size_t)kch * Ci + m) * 9;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[r][c] = mode == 8 ? src[r * 3 + c] : src[(2 - r) * 3 + (2 - c)];
+    }
+    const int half = cm >> 5, mtl = (cm >> 4) & 1, l = cm & 15;
+    float* o = wt + ((size_t)mb * kpad + (kch & ~3)) * (24 * 64) + (size_t)(kch & 3) * (12 * 128) + half * 64 + l * 4 + mtl;
+#pragma unroll
+    for (int fr = 0; fr < 4; ++fr) {
+      float gr[3];   // G2 down the kernel's rows
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        gr[c] = fr == 0 ? g[0][c] : fr == 3 ? g[2][c] : fr == 1 ? 0.5f * (g[0][c] + g[1][c] + g[2][c]) : 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+      const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+      float u[6];
+      u[0] = g0 * 0.25f;
+      u[1] = -(g0 + g1 + g2) * (1.f / 6.f);
+      u[2] = -(g0 - g1 + g2) * (1.f / 6.f);
+      u[3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+      u[4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+      u[5] = g2;
+#pragma unroll
+      for (int fc = 0; fc < 6; ++fc) {
+        const int f = fr * 6 + fc;
+        o[(f >> 1) * 128 + (f & 1) * 2] = u[fc];
+      }
+    }
+  }
+}
 extern "C" int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream) {
-  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 7 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
+  GSD_REQUIRE(w && wt && mode >= 0 && mode <= 9 && Co > 0 && Ci > 0, GSD_ERR_BAD_ARG, "gsd_weight_layout: bad argument");
   int rows, M, BM, pitch, mblocks;
   layout_dims(mode, Co, Ci, &rows, &M, &BM, &pitch, &mblocks);
+  if (mode == 8 || mode == 9) {
+    const int kpad = rows / 24;
+    const long long threads = (long long)mblocks * kpad * 64;
+    const int grid = (int)(ceil_div64(threads, 256) < 16384 ? ceil_div64(threads, 256) : 16384);
+    hipLaunchKernelGGL(weight_layout_w2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, w, Co, Ci, wt, kpad, M,
+                       mblocks);
+    GSD_LAUNCH_CHECK("gsd_weight_layout (w2d)");
+    return GSD_OK;
+  }
   if (mode == 4 || mode == 5) {
     const int kpad = rows / 18;
     const long long threads = (long long)mblocks * kpad * 3 * 64;

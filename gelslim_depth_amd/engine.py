@@ -37,25 +37,35 @@ def _r4(w: int) -> int:
 
 
 class _ConvForm:
-    """Entry points and weight-layout modes of one of the two conv3x3 forms: 0 direct taps, 1 Winograd F(4,3) along rows."""
+    """Entry points and weight-layout modes of one of the three conv3x3 forms: 0 direct taps, 1 Winograd F(4,3) along rows,
+    2 two-dimensional Winograd F(2x4,3x3)."""
 
     def __init__(self, algo: int):
         self.algo = algo
-        self.conv = lib.gsd_conv3x3_w43 if algo else lib.gsd_conv3x3
-        self.dgrad_bnrelu = lib.gsd_conv3x3_w43_dgrad_bnrelu if algo else lib.gsd_conv3x3_dgrad_bnrelu
-        self.partial_rows = lib.gsd_conv3x3_w43_partial_rows if algo else lib.gsd_conv3x3_partial_rows
-        self.mode_f, self.mode_d = (4, 5) if algo else (0, 1)
-        # K-slab scratch the form would like for a shape (the Winograd form only; 0: the shape runs unsplit)
-        self.workspace = lib.gsd_conv3x3_w43_workspace if algo else (lambda *a: 0)
+        self.conv = (lib.gsd_conv3x3, lib.gsd_conv3x3_w43, lib.gsd_conv3x3_w2d)[algo]
+        self.dgrad_bnrelu = (lib.gsd_conv3x3_dgrad_bnrelu, lib.gsd_conv3x3_w43_dgrad_bnrelu, lib.gsd_conv3x3_w2d_dgrad_bnrelu)[algo]
+        self.partial_rows = (lib.gsd_conv3x3_partial_rows, lib.gsd_conv3x3_w43_partial_rows, lib.gsd_conv3x3_w2d_partial_rows)[algo]
+        self.mode_f, self.mode_d = ((0, 1), (4, 5), (8, 9))[algo]
+        # K-slab scratch the form would like for a shape (the row form only; 0: the shape runs unsplit)
+        self.workspace = lib.gsd_conv3x3_w43_workspace if algo == 1 else (lambda *a: 0)
+
+    @staticmethod
+    def choose(n: int, h: int, w: int, cin: int, c0: int, cout: int, train: bool) -> "_ConvForm":
+        """The library's preference for a launch shape (include/gsd.h: gsd_conv3x3_algo, gsd_conv3x3_prefers_w2d).  c0: channels
+        of the first source segment.  Eval mode gets the forms whose bits do not depend on the batch (no row folding, no K slabs)."""
+        algo = lib.gsd_conv3x3_algo(n, h, w, cin, cout)
+        if algo == 1 and lib.gsd_conv3x3_w2d_supported(cin, c0) and lib.gsd_conv3x3_prefers_w2d(n, h, w, cin, cout, int(train)):
+            algo = 2
+        return _ConvForm(algo)
 
     def run(self, ws, src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st):
         """conv3x3 forward / dX; `ws`: the engine's K-slab scratch (train mode) or None."""
-        if self.algo and ws is not None:
+        if self.algo == 1 and ws is not None:
             return lib.gsd_conv3x3_w43_ws(src, nsrc, wt, cin, cout, dst, ndst, part, ws.data_ptr(), ws.numel(), n, h, w, st)
         return self.conv(src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st)
 
     def run_bnrelu(self, ws, src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st):
-        if self.algo and ws is not None:
+        if self.algo == 1 and ws is not None:
             return lib.gsd_conv3x3_w43_dgrad_bnrelu_ws(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part,
                                                        ws.data_ptr(), ws.numel(), n, h, w, st)
         return self.dgrad_bnrelu(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st)
@@ -72,6 +82,7 @@ class _Unit:
         self.gname, self.bname = bn + "weight", bn + "bias"
         self.rmname, self.rvname, self.nbtname = bn + "running_mean", bn + "running_var", bn + "num_batches_tracked"
         self.need_dgrad = True
+        self.c0 = cin              # channels of the first source segment (the decoder's first convs: the skip tensor's)
         # device buffers (filled by the engine)
         self.wt_f = self.wt_d = None
         self.scale = self.shift = self.mean = self.invstd = self.c1 = self.c2 = None
@@ -82,6 +93,7 @@ class _Unit:
         self.fused_dw = False  # first layer: no dX, so dW forms d_raw itself (gsd_conv3x3_wgrad_bn) and the apply pass is skipped
         self.srcs = None  # gsd_src array kept for wgrad
         self.form_f = self.form_d = None   # _ConvForm of the forward / dX launch for the current shape
+        self.forms_f = None                # ... of the forward launch in eval (False) and train (True) mode
         self.fused_rows = 0                # partial rows written by the dX launch that produced this unit's dz
 
 
@@ -120,6 +132,7 @@ class UNetEngine:
             p = f"up.{j}.conv"
             # DoubleConv(in_channels=cin, out=cout): input = cat[skip (dims[i-1]), up (cin//2)]
             self.dec.append((_Unit(p, 0, 1, cin, cout, i - 1), _Unit(p, 3, 4, cout, cout, i - 1)))
+            self.dec[-1][0].c0 = dims[i - 1]
         self.units: List[_Unit] = [u for pair in self.enc for u in pair] + [u for pair in self.dec for u in pair]
         self._shape = None
         self._dev = None
@@ -168,9 +181,12 @@ class UNetEngine:
                     setattr(u, nm, torch.empty((u.cout,), **f32))
                 u.sums = torch.empty((65 * 3 * u.cout,), device=dev, dtype=torch.float64)
             # direct taps or Winograd F(4,3) rows, per layer shape and per direction (include/gsd.h: gsd_conv3x3_algo)
-            u.form_f = _ConvForm(lib.gsd_conv3x3_algo(n, lh, lw, u.cin, u.cout))
-            u.form_d = _ConvForm(lib.gsd_conv3x3_algo(n, lh, lw, u.cout, u.cin)) if u.need_dgrad else None
-            need = lib.gsd_weight_layout_size(u.form_f.mode_f, u.cout, u.cin)
+            # direct taps, Winograd F(4,3) rows or two-dimensional Winograd, per layer shape, per direction and per mode: an
+            # eval-mode forward takes the forms whose bits do not depend on the batch size (_ConvForm.choose)
+            u.forms_f = {t: _ConvForm.choose(n, lh, lw, u.cin, u.c0, u.cout, t) for t in (False, True)}
+            u.form_f = u.forms_f[train]
+            u.form_d = _ConvForm.choose(n, lh, lw, u.cout, u.cout, u.cin, True) if u.need_dgrad else None
+            need = max(lib.gsd_weight_layout_size(f.mode_f, u.cout, u.cin) for f in u.forms_f.values())
             if u.wt_f is None or u.wt_f.numel() != need or u.wt_f.device != dev:
                 u.wt_f = torch.empty((need,), **f32)
             if u.need_dgrad:
@@ -178,7 +194,7 @@ class UNetEngine:
                 if u.wt_d is None or u.wt_d.numel() != need or u.wt_d.device != dev:
                     u.wt_d = torch.empty((need,), **f32)
                 max_part = max(max_part, u.form_d.partial_rows(n, lh, lw, u.cin) * 2 * _r64(u.cin))
-            rows = u.form_f.partial_rows(n, lh, lw, u.cout)
+            rows = max(f.partial_rows(n, lh, lw, u.cout) for f in u.forms_f.values())
             max_part = max(max_part, rows * 2 * _r64(u.cout))
             if train:
                 # K slabs (gsd_conv3x3_w43_ws) for the launches that would leave most of the chip idle: train mode only --
@@ -190,7 +206,7 @@ class UNetEngine:
                 # d_raw goes to a row-pitched scratch buffer (16-byte aligned rows) when both of its readers -- dW and dX
                 # of this unit -- are the Winograd kernels, which then move it as aligned 16-byte LDS-DMA pieces
                 u.pitched = bool(lib.gsd_conv3x3_wgrad_takes_pitched_dy(n, lh, lw, u.cin, u.cout)) and \
-                    (not u.need_dgrad or u.form_d.algo == 1)
+                    (not u.need_dgrad or u.form_d.algo >= 1)
                 if u.pitched:
                     max_gp = max(max_gp, n * u.cout * lh * _r4(lw))
                 u.fused_dw = (not u.need_dgrad) and bool(lib.gsd_conv3x3_wgrad_bn_supported(n, lh, lw, u.cin, u.cout))
@@ -234,6 +250,7 @@ class UNetEngine:
     def _run_unit(self, u: _Unit, srcs: List[L.gsd_src], P: Dict[str, torch.Tensor], train: bool, st: int) -> None:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
+        u.form_f = u.forms_f[train]
         check(lib.gsd_weight_layout(u.form_f.mode_f, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
         arr = L.src_array(srcs)
         u.srcs = arr
@@ -276,7 +293,10 @@ class UNetEngine:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         flops = 2.0 * m * k_ch * 9 * n * lh * lw
-        if algo:
+        if algo == 2:
+            variant = "conv3x3_w2d_kernel"
+            executed = 2048.0 * lib.gsd_conv3x3_w2d_mfma_count(n, lh, lw, k_ch, m)
+        elif algo:
             variant = "conv3x3_w43_kernel"
             executed = 2048.0 * lib.gsd_conv3x3_w43_mfma_count(n, lh, lw, k_ch, m)   # one v_mfma_f32_16x16x4_f32 = 2048 flops
         else:
@@ -463,7 +483,7 @@ class UNetEngine:
             skip = self.enc[lvl][1]
             # the ConvT bias gradient is the per-channel sum of up.dout: the Winograd dX launch that writes up.dout leaves it
             # as statistics of its second (cropped) destination -- no second pass over up.dout
-            db_fused = u0.form_d.algo == 1
+            db_fused = u0.form_d.algo >= 1
             rows = self._dgrad(u0, P, [L.make_dst(skip.g), L.make_dst(up.dout, off=self._pad_off(lvl))], st, stats=db_fused)
             if db_fused:
                 check(lib.gsd_partials_channel_sums(self.partials.data_ptr(), rows, _r64(u0.cin), u0.cin, skip.cout, up.cout,

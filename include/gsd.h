@@ -112,6 +112,8 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * mode 5: conv3x3 dgrad,   Winograd F(4,3) rows: k = co*18+r*6+f (flipped kernel), m = ci
  * mode 6: convT   forward, LDS-DMA kernel: k = ci (rows padded to 32), m = co*4+kh*2+kw in 128-column blocks
  * mode 7: convT   dgrad,   LDS-DMA kernel: k = co*4+kh*2+kw (rows padded to 32), m = ci in 128-column blocks
+ * mode 8: conv3x3 forward, Winograd F(2x4,3x3): k = ci*24+fr*6+fc, m = co   (see gsd_conv3x3_w2d)
+ * mode 9: conv3x3 dgrad,   Winograd F(2x4,3x3): k = co*24+fr*6+fc (flipped kernel), m = ci
  * Modes 0/1 are tiled for the LDS-DMA kernel: [m-block][k row][BM] with BM = 64 (M <= 64) or 128, columns
  * permuted inside each 64-group (slot l*4+t = column t*16+l), so one K-chunk of one m-block is a contiguous LDS
  * image whose A operands are aligned float4s; modes 2/3 are [k row][M rounded up to 64].
@@ -166,6 +168,24 @@ int gsd_conv3x3_w43_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin
                                     const float* raw, const float* scale, const float* shift, const float* mean,
                                     const float* invstd, float* partials, float* ws, int64_t ws_elems, int N, int H, int W,
                                     void* stream);
+
+/* The same two operators with the TWO-dimensional Winograd identity F(2x4, 3x3): F(4,3) along the rows combined with F(2,3)
+ * down the columns -- 24 products per 2x4 outputs and input channel, a third of the direct form's and two thirds of the
+ * row-only form's MFMA work; same fp32 storage and accumulation.  Weights from gsd_weight_layout modes 8 (forward) / 9 (dX):
+ * [m-block of 64][k row = ci*24 + fr*6 + fc][64], U = G2 g G4^T.  Needs Cin % 4 == 0 and a first source segment of a multiple
+ * of 4 channels (gsd_conv3x3_w2d_supported); no K-slab form and no row folding: the caller keeps gsd_conv3x3_w43 for the small
+ * deep levels.  Partial-row layout as gsd_conv3x3, its own row count (two rows per pixel tile). */
+int gsd_conv3x3_w2d_supported(int Cin, int C0);
+int gsd_conv3x3_prefers_w2d(int N, int H, int W, int Cin, int Cout, int train);   /* 1: run this Winograd launch in the 2-D form */
+double gsd_conv3x3_w2d_estimate_us(int N, int H, int W, int Cin, int Cout);          /* the planner's run-time models */
+double gsd_conv3x3_w43_estimate_us(int N, int H, int W, int Cin, int Cout, int slabs);
+int gsd_conv3x3_w2d_partial_rows(int N, int H, int W, int Cout);
+int64_t gsd_conv3x3_w2d_mfma_count(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_w2d(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout,
+                    const gsd_dst* dst, int ndst, float* partials, int N, int H, int W, void* stream);
+int gsd_conv3x3_w2d_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                 const float* raw, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, float* partials, int N, int H, int W, void* stream);
 
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 6. */

@@ -120,6 +120,22 @@ def test_conv_form_choice_and_size_queries(monkeypatch):
             assert lib.gsd_weight_layout_size(4, co, ci) == -(-co // 64) * 64 * (-(-ci // 4) * 4) * 18
             assert lib.gsd_weight_layout_size(5, co, ci) == -(-ci // 64) * 64 * (-(-co // 4) * 4) * 18
             assert lib.gsd_conv3x3_wgrad_workspace(32, h, w, ci, co) > 0
+            # two-dimensional Winograd F(2x4,3x3): a third of the direct MFMA work (+ tile padding; no row folding at the deep
+            # levels), 24 weight rows per input channel; preferred at batch 32 wherever the model prices it faster, always in
+            # eval mode (its bits do not depend on the batch), never for the 3-channel layer
+            if ci >= 16:
+                w2d = lib.gsd_conv3x3_w2d_mfma_count(32, h, w, ci, co)
+                assert direct_mfma / 3 <= w2d <= 0.56 * direct_mfma, (lvl, w2d / direct_mfma)
+                assert lib.gsd_conv3x3_w2d_supported(ci, ci) == 1 and lib.gsd_conv3x3_w2d_partial_rows(32, h, w, co) > 0
+                assert lib.gsd_weight_layout_size(8, co, ci) == -(-co // 64) * 64 * ci * 24
+                assert lib.gsd_weight_layout_size(9, co, ci) == -(-ci // 64) * 64 * co * 24
+                assert lib.gsd_conv3x3_prefers_w2d(32, h, w, ci, co, 0) == 1
+                t2, t1 = lib.gsd_conv3x3_w2d_estimate_us(32, h, w, ci, co), lib.gsd_conv3x3_w43_estimate_us(32, h, w, ci, co, 1)
+                assert t1 > 0 and t2 > 0 and lib.gsd_conv3x3_prefers_w2d(32, h, w, ci, co, 1) == int(t2 < t1)
+                if lvl <= 2:
+                    assert t2 < t1, (lvl, ci, co, t2, t1)
+            else:
+                assert lib.gsd_conv3x3_prefers_w2d(32, h, w, ci, co, 0) == 0 and lib.gsd_conv3x3_w2d_supported(ci, ci) == 0
         h, w = h // 2, w // 2
     monkeypatch.setenv("GSD_CONV_ALGO", "0")
     assert lib.gsd_conv3x3_algo(32, 320, 427, 64, 64) == 0

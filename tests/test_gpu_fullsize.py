@@ -59,25 +59,32 @@ def test_config2_batch32_train_step_is_deterministic_and_forms_agree(monkeypatch
     st = synth.make_state(3, 1, DIMS, 0, "conditioned")
     x, t = device_batch(32, 22)
     runs = {}
-    for tag, algo in (("w43_a", None), ("w43_b", None), ("direct", "0")):
-        if algo is None:
-            monkeypatch.delenv("GSD_CONV_ALGO", raising=False)
-            monkeypatch.delenv("GSD_WGRAD_ALGO", raising=False)
-        else:
-            monkeypatch.setenv("GSD_CONV_ALGO", algo)
-            monkeypatch.setenv("GSD_WGRAD_ALGO", algo)
+    # default: the planner's mix of the two Winograd forms (two-dimensional F(2x4,3x3) wherever it is modelled faster, F(4,3) rows
+    # with K slabs at the deep levels); "rows": GSD_CONV_W2D=0, the row form everywhere; "direct": direct taps everywhere
+    for tag, algo, w2d in (("wino_a", None, None), ("wino_b", None, None), ("rows", None, "0"), ("direct", "0", None)):
+        for k, v in (("GSD_CONV_ALGO", algo), ("GSD_WGRAD_ALGO", algo), ("GSD_CONV_W2D", w2d)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
         m = make_model(st).train()
         step = TrainStep(m)
         loss = float(step(x, t))
-        forms = {u.form_f.algo for u in m._engine.units[1:]}
-        assert forms == ({0} if algo == "0" else {1}), forms
+        forms = {u.form_f.algo for u in m._engine.units[1:]} | {u.form_d.algo for u in m._engine.units[1:]}
+        if algo == "0":
+            assert forms == {0}, forms
+        elif w2d == "0":
+            assert forms == {1}, forms
+        else:
+            assert forms <= {1, 2} and 2 in forms, forms
         runs[tag] = (loss, step.g_flat.clone(), step.p_flat.clone(), dict(step.offsets))
         del m, step
         torch.cuda.empty_cache()
-    a, b, d = runs["w43_a"], runs["w43_b"], runs["direct"]
+    a, b, d = runs["wino_a"], runs["wino_b"], runs["direct"]
     assert np.isfinite(a[0]) and a[0] == b[0]
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])                  # bitwise reproducible at batch 32
     assert abs(a[0] - d[0]) <= 1e-5 * abs(d[0])                                 # the loss sees forward noise only
+    assert abs(runs["rows"][0] - d[0]) <= 1e-5 * abs(d[0])
     off = a[3]
 
     def dev(name):

@@ -80,8 +80,13 @@ def bcast(v):
     return v[None, :, None, None]
 
 
-@pytest.mark.parametrize("unit,n", CASES, ids=[f"{u[0]}-N{n}" for u, n in CASES])
-def test_conv3x3_unit_at_network_shape(gsd, unit, n):
+FORM_CASES = [(u, n, f) for u, n in CASES for f in ("w43", "w2d")]
+
+
+@pytest.mark.parametrize("unit,n,form", FORM_CASES, ids=[f"{u[0]}-N{n}-{f}" for u, n, f in FORM_CASES])
+def test_conv3x3_unit_at_network_shape(gsd, unit, n, form):
+    """form: the Winograd F(4,3)-rows kernels (gsd_conv3x3_w43*) or the two-dimensional F(2x4,3x3) kernels (gsd_conv3x3_w2d*) for
+    the forward and dX launches; dW is the same kernel in both."""
     from oracle import unet_numpy as on
     name, lvl, c0, c1, co, pooled = unit
     h, w = HS[lvl], WS[lvl]
@@ -89,6 +94,11 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
     L = gsd.lib
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + n)
     assert L.gsd_conv3x3_algo(n, h, w, ci, co) == 1 and L.gsd_conv3x3_algo(n, h, w, co, ci) == 1, "Winograd layers"
+    if form == "w2d":
+        assert L.gsd_conv3x3_w2d_supported(ci, c0) == 1 and L.gsd_conv3x3_w2d_supported(co, co) == 1
+        conv, conv_bn, conv_rows, mode_f, mode_d = (L.gsd_conv3x3_w2d, L.gsd_conv3x3_w2d_dgrad_bnrelu, L.gsd_conv3x3_w2d_partial_rows, 8, 9)
+    else:
+        conv, conv_bn, conv_rows, mode_f, mode_d = (L.gsd_conv3x3_w43, L.gsd_conv3x3_w43_dgrad_bnrelu, L.gsd_conv3x3_w43_partial_rows, 4, 5)
     sub = list(range(n)) if n <= 2 else [0, 13, n - 1]          # images whose forward / dX the oracle computes
 
     # ---- operands as the engine holds them
@@ -122,11 +132,11 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
 
     # ---- forward (+ BatchNorm partial sums)
     y = torch.full((n, co, h, w), float("nan"), device="cuda")
-    rows = L.gsd_conv3x3_w43_partial_rows(n, h, w, co)
+    rows = conv_rows(n, h, w, co)
     mpad = (co + 63) // 64 * 64
     part = torch.zeros(rows * 2 * mpad, device="cuda")
-    gsd.check(L.gsd_conv3x3_w43(src, len(segs), layout(gsd, 4, wd, co, ci).data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1,
-                                part.data_ptr(), n, h, w, gsd.stream_ptr()))
+    gsd.check(conv(src, len(segs), layout(gsd, mode_f, wd, co, ci).data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1,
+                   part.data_ptr(), n, h, w, gsd.stream_ptr()))
     assert bool(torch.isfinite(y).all()), "every output element must be written"
     ref = on.conv3x3_fwd(a[sub], wt_)
     assert rel_l1(y[sub].cpu().numpy(), ref) < 1e-5
@@ -140,16 +150,16 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
     # ---- dX, in the form the engine launches for this unit
     dy = rnd(rng, n, co, h, w)
     dyp = pitched(dev(dy))
-    wl_d = layout(gsd, 5, wd, co, ci)
+    wl_d = layout(gsd, mode_d, wd, co, ci)
     dxr, _ = on.conv3x3_bwd(a[sub], wt_, dy[sub])
     if c1:        # decoder c0: (skip gradient | cropped gradient of the up-sampled tensor) + its per-channel sums (ConvT bias grad)
         g_skip = torch.full((n, c0, h, w), float("nan"), device="cuda")
         g_up = torch.full((n, c1, uh, uw), float("nan"), device="cuda")
-        rows_d = L.gsd_conv3x3_w43_partial_rows(n, h, w, ci)
+        rows_d = conv_rows(n, h, w, ci)
         part_d = torch.zeros(rows_d * 2 * ((ci + 63) // 64 * 64), device="cuda")
-        gsd.check(L.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(dyp)]), 1, wl_d.data_ptr(), co, ci,
-                                    gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))]), 2,
-                                    part_d.data_ptr(), n, h, w, gsd.stream_ptr()))
+        gsd.check(conv(gsd.src_array([gsd.make_src(dyp)]), 1, wl_d.data_ptr(), co, ci,
+                       gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))]), 2,
+                       part_d.data_ptr(), n, h, w, gsd.stream_ptr()))
         assert rel_l1(g_skip[sub].cpu().numpy(), dxr[:, :c0]) < 1e-5
         assert rel_l1(g_up[sub].cpu().numpy(), dxr[:, c0:, top:top + uh, left:left + uw]) < 1e-5
         sums_d = torch.zeros(65 * 2 * ci, device="cuda", dtype=torch.float64)
@@ -158,8 +168,8 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
         del g_skip, g_up
     elif pooled:  # encoder c0 below level 0: plain dX into the pooled tensor's gradient
         g = torch.full((n, ci, h, w), float("nan"), device="cuda")
-        gsd.check(L.gsd_conv3x3_w43(gsd.src_array([gsd.make_src(dyp)]), 1, wl_d.data_ptr(), co, ci,
-                                    gsd.dst_array([gsd.make_dst(g)]), 1, None, n, h, w, gsd.stream_ptr()))
+        gsd.check(conv(gsd.src_array([gsd.make_src(dyp)]), 1, wl_d.data_ptr(), co, ci,
+                       gsd.dst_array([gsd.make_dst(g)]), 1, None, n, h, w, gsd.stream_ptr()))
         assert rel_l1(g[sub].cpu().numpy(), dxr) < 1e-5
         del g
     else:         # c1 of a DoubleConv: dX fused with the backward of the producer's ReLU + BatchNorm reduce pass
@@ -167,12 +177,12 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
         dz_ref = dxr * (a0[sub] > 0)
         vecs = [scd, shd, dev(mean), dev(invstd)]
         dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
-        rows_d = L.gsd_conv3x3_w43_partial_rows(n, h, w, ci)
+        rows_d = conv_rows(n, h, w, ci)
         mp = (ci + 63) // 64 * 64
         part_d = torch.zeros(rows_d * 2 * mp, device="cuda")
         s, d = gsd.make_src(dyp), gsd.make_dst(dz)
-        gsd.check(L.gsd_conv3x3_w43_dgrad_bnrelu(C.byref(s), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
-                                                 *[v.data_ptr() for v in vecs], part_d.data_ptr(), n, h, w, gsd.stream_ptr()))
+        gsd.check(conv_bn(C.byref(s), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
+                          *[v.data_ptr() for v in vecs], part_d.data_ptr(), n, h, w, gsd.stream_ptr()))
         assert rel_l1(dz[sub].cpu().numpy(), dz_ref) < 1e-5
         sums_d = torch.zeros(65 * 2 * ci, device="cuda", dtype=torch.float64)
         gsd.check(L.gsd_bn_reduce_partials(part_d.data_ptr(), rows_d, mp, ci, sums_d.data_ptr(), gsd.stream_ptr()))
@@ -184,6 +194,8 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n):
         del dz, dz64, xhat
     del dxr
 
+    if form == "w2d":
+        return          # dW does not depend on the forward / dX form: checked once, in the w43 case
     # ---- dW (activation segments as in the forward, dy from the row-pitched buffer)
     dwr = np.zeros((co, ci, 3, 3), np.float64)
     wdummy = np.zeros((co, ci, 3, 3), np.float32)

@@ -303,20 +303,28 @@ def test_winograd_and_direct_forms_agree(monkeypatch):
     x, tgt = synth.make_batch(3, 72, 101, 12)
     xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
     res = {}
-    for algo in ("0", "1"):
-        monkeypatch.setenv("GSD_CONV_ALGO", algo)
-        monkeypatch.setenv("GSD_WGRAD_ALGO", algo)
+    # "0": direct taps; "1": Winograd F(4,3) rows everywhere; "2": the two-dimensional F(2x4,3x3) wherever the shape admits it
+    # (Cin a multiple of 4: everything but the 3-channel first layer, which then keeps the row form)
+    for algo in ("0", "1", "2"):
+        monkeypatch.setenv("GSD_CONV_ALGO", min(algo, "1"))
+        monkeypatch.setenv("GSD_WGRAD_ALGO", min(algo, "1"))
+        monkeypatch.setenv("GSD_CONV_W2D", "1" if algo == "2" else "0")
         m = make_model(dims, st)
         m.train()
         out = m(x=xd)
         mse_loss(out, td).backward()
         forms = [u.form_f.algo for u in m._engine.units]
-        assert all(f == int(algo) for f in forms), forms     # forcing a form includes the 3-channel first layer
+        if algo == "2":
+            assert forms[0] == 1 and all(f == 2 for f in forms[1:]), forms
+            assert all(u.form_d.algo == 2 for u in m._engine.units[1:]), "dX launches too"
+        else:
+            assert all(f == int(algo) for f in forms), forms     # forcing a form includes the 3-channel first layer
         res[algo] = (out.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()})
-    assert rel_l1(res["1"][0], res["0"][0]) < 1e-5
-    dev = {k: rel_l1(res["1"][1][k], res["0"][1][k]) for k in res["0"][1]}
-    assert dev["up.2.conv.double_conv.3.weight"] < 2e-4, dev["up.2.conv.double_conv.3.weight"]
-    assert max(dev.values()) < 5e-2, max(dev.values())
+    for algo in ("1", "2"):
+        assert rel_l1(res[algo][0], res["0"][0]) < 1e-5
+        dev = {k: rel_l1(res[algo][1][k], res["0"][1][k]) for k in res["0"][1]}
+        assert dev["up.2.conv.double_conv.3.weight"] < 2e-4, (algo, dev["up.2.conv.double_conv.3.weight"])
+        assert max(dev.values()) < 5e-2, (algo, max(dev.values()))
 
 
 @pytest.mark.parametrize("dims,h,w", [([64, 128, 256, 512, 1024], 320, 427), ([16, 32, 64], 37, 53)])

@@ -38,18 +38,21 @@ def layout(gsd, mode, w, co, ci):
 
 
 class ConvForm:
-    """The two forms of the conv3x3 entry points: direct taps (gsd_conv3x3*) and Winograd F(4,3) rows (gsd_conv3x3_w43*)."""
-    def __init__(self, gsd, algo):
+    """The three forms of the conv3x3 entry points: direct taps (gsd_conv3x3*), Winograd F(4,3) rows (gsd_conv3x3_w43*) and the
+    two-dimensional Winograd F(2x4,3x3) (gsd_conv3x3_w2d*)."""
+    def __init__(self, gsd, algo, cin=None, c0=None):
         L = gsd.lib
-        self.conv = L.gsd_conv3x3_w43 if algo else L.gsd_conv3x3
-        self.dgrad_bnrelu = L.gsd_conv3x3_w43_dgrad_bnrelu if algo else L.gsd_conv3x3_dgrad_bnrelu
-        self.partial_rows = L.gsd_conv3x3_w43_partial_rows if algo else L.gsd_conv3x3_partial_rows
-        self.mode_f, self.mode_d = (4, 5) if algo else (0, 1)
-        # F(4,3) adds two roundings per operand in the transforms (constants up to 8 and 1/24)
+        self.conv = (L.gsd_conv3x3, L.gsd_conv3x3_w43, L.gsd_conv3x3_w2d)[algo]
+        self.dgrad_bnrelu = (L.gsd_conv3x3_dgrad_bnrelu, L.gsd_conv3x3_w43_dgrad_bnrelu, L.gsd_conv3x3_w2d_dgrad_bnrelu)[algo]
+        self.partial_rows = (L.gsd_conv3x3_partial_rows, L.gsd_conv3x3_w43_partial_rows, L.gsd_conv3x3_w2d_partial_rows)[algo]
+        self.mode_f, self.mode_d = ((0, 1), (4, 5), (8, 9))[algo]
+        # F(4,3) adds two roundings per operand in the transforms (constants up to 8 and 1/24); F(2,3) constants are 1 and 1/2
         self.tol = 1e-5 if algo else TOL
+        if algo == 2 and cin is not None and not L.gsd_conv3x3_w2d_supported(cin, cin if c0 is None else c0):
+            pytest.skip("the two-dimensional form wants channel counts that are multiples of 4 (gsd_conv3x3_w2d_supported)")
 
 
-ALGOS = pytest.mark.parametrize("algo", [0, 1], ids=["direct", "w43"])
+ALGOS = pytest.mark.parametrize("algo", [0, 1, 2], ids=["direct", "w43", "w2d"])
 
 
 def test_mfma_lane_maps(gsd):
@@ -68,7 +71,7 @@ def test_mfma_lane_maps(gsd):
 @ALGOS
 def test_conv3x3_plain(gsd, algo, n, ci, co, h, w):
     from oracle import unet_numpy as on
-    F = ConvForm(gsd, algo)
+    F = ConvForm(gsd, algo, ci)
     rng = np.random.default_rng(n * 1000 + ci)
     x, wt_ = rnd(rng, n, ci, h, w), rnd(rng, co, ci, 3, 3, scale=0.2)
     xd, wd = dev(x), dev(wt_)
@@ -101,7 +104,7 @@ def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo, c0, c1, co):
     segments (general fills); (8, 12), (64, 32): every chunk lies in one segment -- the straight fills with the one
     segment switch per block and the re-written padding positions."""
     from oracle import unet_numpy as on
-    F = ConvForm(gsd, algo)
+    F = ConvForm(gsd, algo, c0 + c1, c0)
     rng = np.random.default_rng(7)
     n, h, w = 2, 9, 11
     skip_raw = rnd(rng, n, c0, h, w)
@@ -435,15 +438,15 @@ def test_bad_arguments_are_refused(gsd):
     assert gsd.lib.gsd_conv3x3(src, 1, None, 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
     assert gsd.lib.gsd_conv3x3(src, 3, wt.data_ptr(), 4, 4, dst, 1, None, 1, 8, 8, gsd.stream_ptr()) == -1
     with pytest.raises(gsd.GsdError):
-        gsd.check(gsd.lib.gsd_weight_layout(8, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
+        gsd.check(gsd.lib.gsd_weight_layout(10, x.data_ptr(), 4, 4, wt.data_ptr(), gsd.stream_ptr()), "weight_layout")
 
 
-@pytest.mark.parametrize("n,ci,co,h,w", [(2, 6, 9, 9, 11), (1, 64, 130, 21, 29)])
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 6, 9, 9, 11), (1, 64, 130, 21, 29), (2, 10, 12, 10, 13), (1, 70, 128, 21, 29)])
 @ALGOS
 def test_conv3x3_dgrad_fused_with_bn_relu_backward(gsd, algo, n, ci, co, h, w):
     """gsd_conv3x3_dgrad_bnrelu == conv dX followed by gsd_bn_bwd_reduce(mode PLAIN): dz and (sum dz, sum dz*xhat)."""
     from oracle import unet_numpy as on
-    F = ConvForm(gsd, algo)
+    F = ConvForm(gsd, algo, co, co)       # the dX launch contracts over the unit's OUTPUT channels
     rng = np.random.default_rng(co)
     # forward unit "prev": raw (n, ci, h, w) with its BN; this conv maps ci -> co
     raw, g, b, mean, invstd, scale, shift, a = _bn_setup(rng, n, ci, h, w)
