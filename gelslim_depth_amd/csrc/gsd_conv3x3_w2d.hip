@@ -45,6 +45,9 @@ struct W2DParams {
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
 };
 
+#ifndef W2D_PIPE   // 1: pin the interleave of a frequency row's MFMAs with the next row's transform (sched_group_barrier)
+#define W2D_PIPE 1
+#endif
 #ifndef W2D_ABL   // diagnostic builds only (profiles/build_diag_one.sh; results are then garbage): 1 no weight fills after a block's first,
 #define W2D_ABL 0 // 2 no halo fills after the first, 4 barrier without the wait for the fills, 8 no MFMAs, 16 no operand transform
 #endif
@@ -254,12 +257,12 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
         for (int c = 0; c < 6; ++c) d[i][c] = fmaxf(fmaf(d[i][c], sc, sh), lo);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // frequency rows in the order that retires window rows early: t0 = d0 - d2, t3 = d1 - d3, t1 = d1 + d2, t2 = d2 - d1
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi) {
-      constexpr int FR[4] = {0, 3, 1, 2};
-      const int fr = FR[fi];
-      float t[6], v[6];
+    // frequency rows in the order that retires window rows early: t0 = d0 - d2, t3 = d1 - d3, t1 = d1 + d2, t2 = d2 - d1.
+    // Software pipeline over the rows: the operand transform of row fi + 1 (about 19 vector instructions) is issued between the
+    // 12 MFMAs of row fi -- an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, three vector instructions fit its shadow.
+    constexpr int FR[4] = {0, 3, 1, 2};
+    auto freq_row = [&](int fr, float (&v)[6]) {
+      float t[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c)
         t[c] = fr == 0 ? d[0][c] - d[2][c] : fr == 3 ? d[1][c] - d[3][c] : fr == 1 ? d[1][c] + d[2][c] : d[2][c] - d[1][c];
@@ -269,7 +272,14 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 #else
       row_transform(t, v);
 #endif
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    float v[2][6];
+    freq_row(FR[0], v[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+      const int fr = FR[fi];
+      if (fi + 1 < 4) freq_row(FR[fi + 1], v[(fi + 1) & 1]);
 #pragma unroll
       for (int fc = 0; fc < 6; ++fc) {
         const int s = fi * 6 + fc, f = fr * 6 + fc;
@@ -279,11 +289,11 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
         }
         const f32x4& ap = av[(s >> 1) & 1];
 #if (W2D_ABL) & 8
-        acc[0][f][0] += ap[(s & 1) * 2] * v[fc];
-        acc[1][f][0] += ap[(s & 1) * 2 + 1] * v[fc];
+        acc[0][f][0] += ap[(s & 1) * 2] * v[fi & 1][fc];
+        acc[1][f][0] += ap[(s & 1) * 2 + 1] * v[fi & 1][fc];
 #else
-        acc[0][f] = mfma16(ap[(s & 1) * 2], v[fc], acc[0][f]);
-        acc[1][f] = mfma16(ap[(s & 1) * 2 + 1], v[fc], acc[1][f]);
+        acc[0][f] = mfma16(ap[(s & 1) * 2], v[fi & 1][fc], acc[0][f]);
+        acc[1][f] = mfma16(ap[(s & 1) * 2 + 1], v[fi & 1][fc], acc[1][f]);
 #endif
         // the next chunk's fills ride in the first k-steps: the weights in one k-step (shared LDS bases), then the halo
         if (more && s < 3) {
@@ -295,9 +305,20 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
             halo_slot(2 * s - 2, Wn + WTILE);
             halo_slot(2 * s - 1, Wn + WTILE);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+#if W2D_PIPE
+      if (fi > 0 || !more) {   // (row 0 carries the fills: its k-steps are pinned above)
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // two MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // at most one LDS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four vector instructions of the next row's transform
+        }
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
