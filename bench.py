@@ -47,6 +47,10 @@ def parse_args(argv=None):
                     help="skip the short extra legs at N=1 (configs[1] inference, configs[3] shares at batch 16 / 8, bf16 at 16 / 32)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the 'val L1 vs ref' leg at N=1 (one eval forward against tests/golden/gfull_b1.npz, outside the timed region)")
+    ap.add_argument("--dry-run-ranks", type=int, default=0,
+                    help="first-contact rehearsal of the N-rank flow on a box with fewer GPUs: N ranks share GPU 0 over gloo at tiny "
+                         "dimensions, the parent checks rank 0's line (n_ranks_seen, per-rank ms, allreduce fields, strong leg) and that "
+                         "no other rank writes to stdout.  Timings are meaningless; at most 6 ranks (the GPU box's process guard)")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--per-layer", action="store_true", help="print per-shape conv3x3 TFLOP/s to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -90,6 +94,52 @@ def self_launch(args) -> int:
     return proc.returncode
 
 
+def dry_run_ranks(n: int) -> int:
+    """`--dry-run-ranks N`: start the N-rank job exactly as the driver does (python -m torch.distributed.run ... bench.py --gpus N),
+    but with the ranks sharing GPU 0 over gloo (GSD_BENCH_BACKEND / GSD_BENCH_SHARE_GPU) and tiny dimensions (GSD_BENCH_TINY), and
+    check what the first real multi-GPU run will be judged on.  Prints one JSON line with the checks; exit code 0 iff all hold."""
+    if n < 2 or n > 6:
+        print("bench.py: --dry-run-ranks wants 2..6 ranks (the GPU box allows 6 processes on its card)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    env = dict(os.environ, GSD_BENCH_BACKEND="gloo", GSD_BENCH_SHARE_GPU="1", GSD_BENCH_TINY="1", OMP_NUM_THREADS="2")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out_lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    checks = {"exit_code_0": proc.returncode == 0,
+              "stdout_is_one_json_line": len(out_lines) == 1 and out_lines[0].startswith("{")}
+    rec = {}
+    if checks["stdout_is_one_json_line"]:
+        try:
+            rec = json.loads(out_lines[0])
+        except ValueError:
+            checks["stdout_is_one_json_line"] = False
+    ar = rec.get("allreduce") or {}
+    strong = (rec.get("extra") or {}).get("configs[3] strong scaling: global batch 64 fp32") or {}
+    checks.update({
+        "n_gpus_and_n_ranks_seen": rec.get("n_gpus") == n and rec.get("n_ranks_seen") == n,
+        "per_rank_ms_per_step": isinstance(rec.get("per_rank_ms_per_step"), list) and len(rec.get("per_rank_ms_per_step")) == n,
+        "value_is_whole_job": bool(rec) and abs(rec["value"] - rec["config"]["global_batch"] * 1e3 / rec["ms_per_step"]) <= 1e-2 * rec["value"],
+        "scaling_weak": rec.get("scaling") == "weak",
+        "allreduce_fields": all(k in ar for k in ("allreduce_ms_per_step", "exposed_ms_per_step", "bus_GBps", "MB_per_step",
+                                                  "per_rank_allreduce_ms")) and len(ar.get("per_rank_allreduce_ms", [])) == n,
+        "strong_leg": (64 % n != 0) or (strong.get("scaling") == "strong" and strong.get("n_gpus") == n
+                                        and strong.get("global_batch") == 64 and "allreduce" in strong),
+        "labelled_rehearsal": "REHEARSAL" in (rec.get("config") or {}).get("workload", ""),
+    })
+    ok = all(checks.values())
+    print(json.dumps({"dry_run_ranks": n, "ok": ok, "checks": checks, "rank0_line": rec,
+                      "stdout_lines_seen": [ln[:200] for ln in out_lines] if not ok else len(out_lines),
+                      "stderr_tail": proc.stderr.splitlines()[-5:] if not ok else []}), flush=True)
+    return 0 if ok else 1
+
+
 def host_cores() -> int:
     """CPU cores this process may actually use: min(affinity mask, cgroup quota, logical CPUs)."""
     n = os.cpu_count() or 1
@@ -131,6 +181,20 @@ def cpu_baseline(seconds_budget: float = 25.0):
     return {"value": round(b / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} full train steps (fwd+MSE+bwd+Adam) of batch {b} at 3x{H}x{W} fp32, "
                       f"torch CPU operators as the reference executes them, median {med:.2f} s/step"}
+
+
+def traffic_provenance(tj):
+    """How a committed rocprofv3 --pmc figure relates to the library this run loads: the JSON carries the source digest of the
+    library the passes ran (profiles/make_traffic.py); `stale` says that the sources have changed since (the figure may still
+    hold -- most changes do not touch the kernel -- but nobody has re-measured it)."""
+    try:
+        from gelslim_depth_amd import build as b
+        cur = b.source_digest()
+    except Exception:      # noqa: BLE001 -- provenance only
+        cur = None
+    rec = tj.get("library_source_digest")
+    return {"profiled_library_digest": rec[:16] if rec else None, "this_library_digest": cur[:16] if cur else None,
+            "stale": bool(rec is None or cur is None or rec != cur)}
 
 
 def parity_vs_reference(dev, dtype):
@@ -272,8 +336,8 @@ class Leg:
             pass
         extra = {}
         if traffic:
-            extra = {"traffic": traffic, "traffic_source": traffic_src, "traffic_vs_algorithmic": round(traffic / by, 3),
-                     "traffic_TBps": round(traffic / (avg * 1e-3) / 1e12, 3)}
+            extra = {"traffic": traffic, "traffic_source": traffic_src, "traffic_provenance": traffic_provenance(tj),
+                     "traffic_vs_algorithmic": round(traffic / by, 3), "traffic_TBps": round(traffic / (avg * 1e-3) / 1e12, 3)}
         return {**extra, "bound": "hbm", "kernel": "inc double-conv forward (3->64->64 @320x427): "
                 + ("statistics-only first conv + fused kernel (rebuilds relu(bn(conv(x))) per halo tile, weights-resident 64->64 "
                    "conv) + BN finalize x2 + BN-apply with the max-pool (gsd_bf16_inc.hip)"
@@ -351,8 +415,13 @@ def workload_name(dtype, workload, B):
 
 def main():
     args = parse_args()
+    if args.dry_run_ranks:
+        sys.exit(dry_run_ranks(args.dry_run_ranks))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if os.environ.get("GSD_BENCH_TINY"):       # rehearsal dimensions (--dry-run-ranks): a small net on small images
+        global DIMS, H, W
+        DIMS, H, W = [16, 32, 64], 40, 53
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,10 +452,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend=backend)
+        # ... and the C++ side of a backend may write to fd 1 while it connects (gloo: "[Gloo] Rank r is connected to ..."): the
+        # process's stdout points at stderr for the duration of the rendezvous
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(backend=backend)
+                dist.barrier()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         pg = dist.group.WORLD
         n_ranks_seen = dist.get_world_size()
 
@@ -463,6 +542,7 @@ def main():
             if tj.get("kernel") == dom and B == 32 and args.dtype == "f32":
                 roof["traffic"] = round(float(tj["hbm_bytes_per_launch"]))
                 roof["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes: %s)" % ", ".join(tj.get("sources", []))
+                roof["traffic_provenance"] = traffic_provenance(tj)
         except (OSError, ValueError, KeyError):
             pass
         if hbm is not None:
@@ -488,8 +568,10 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 6),
                        "conv3x3_form": ("bf16 MFMA implicit GEMM" if args.dtype == "bf16" else
-                                        {"0": "direct taps", "1": "winograd F(4,3) rows"}.get(
-                                            os.environ.get("GSD_CONV_ALGO", ""), "winograd F(4,3) rows, fp32 (Cin>=16) / direct taps (first layer)"))},
+                                        {"0": "direct taps", "1": "winograd, fp32"}.get(
+                                            os.environ.get("GSD_CONV_ALGO", ""),
+                                            "fp32: two-dimensional winograd F(2x4,3x3) or winograd F(4,3) rows with K slabs, per launch by "
+                                            "the library's run-time models (Cin>=16) / direct taps (first layer)"))},
             "roofline": roof,
         }
         if comm is not None:

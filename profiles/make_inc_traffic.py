@@ -34,7 +34,9 @@ out = {"block": "inc double-conv forward (3->64->64 @320x427, train mode, batch 
        "per_kernel_KB": {k: {"FETCH_SIZE_x2": 2 * fper.get(k, 0.0) / runs_total, "WRITE_SIZE": wper.get(k, 0.0) / runs_total}
                          for k in sorted(set(fper) | set(wper))},
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE",
-       "sources": [f"profiles/{tag}_inc_{prec}_pmc_fetch_size.txt", f"profiles/{tag}_inc_{prec}_pmc_write_size.txt"]}
+       "sources": [f"profiles/{tag}_inc_{prec}_pmc_fetch_size.txt", f"profiles/{tag}_inc_{prec}_pmc_write_size.txt"],
+       "library_source_digest": (open("gelslim_depth_amd/csrc/libgsd.so.stamp").read().strip()
+                                 if __import__("os").path.exists("gelslim_depth_amd/csrc/libgsd.so.stamp") else None)}
 try:
     allj = json.load(open("profiles/inc_traffic.json"))
 except (OSError, ValueError):

@@ -1,13 +1,22 @@
 """Build profiles/traffic.json from three rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 0` (FETCH_SIZE; WRITE_SIZE;
 SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), as written by profiles/run_pmc.sh.  All template variants of the dominant
 kernel are pooled.  FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request: MI355X_MICROARCH.md, HBM).
-usage: python profiles/make_traffic.py <tag>     (reads gpurun_out/<tag>_{fetch,write,sq}_pmc.txt, profiles named per round)"""
+usage: python profiles/make_traffic.py <tag> [kernel]     (reads gpurun_out/<tag>_{fetch,write,sq}_pmc.txt, profiles named per round;
+kernel: the dominant kernel's name, default conv3x3_w2d_kernel).  The JSON records the source digest of the library the passes ran
+(gelslim_depth_amd/csrc/libgsd.so.stamp): bench.py marks the figure stale when it differs from the library it runs."""
 import json
 import re
 import sys
 
 tag = sys.argv[1]
-KERNEL = "conv3x3_w43_kernel"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_w2d_kernel"
+
+
+def lib_digest():
+    try:
+        return open("gelslim_depth_amd/csrc/libgsd.so.stamp").read().strip()
+    except OSError:
+        return None
 
 
 def pooled(path, counters):
@@ -43,6 +52,7 @@ out = {
     "mfma_busy": busy,
     "cycles_per_launch": cycles,
     "sources": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt", f"profiles/{tag}_pmc_sq.txt"],
+    "library_source_digest": lib_digest(),
 }
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
