@@ -43,6 +43,7 @@ struct W2DParams {
   int Cin, Cout, Mpad, nchunks, mblocks;
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
+  int NP, NI;   // X4: 16-byte pieces per window row (TW / 4 + 2), DMA instructions per channel plane
 };
 
 #ifndef W2D_PIPE   // 1: pin the interleave of a frequency row's MFMAs with the next row's transform (sched_group_barrier)
@@ -60,8 +61,17 @@ constexpr int W2D_WTILE = 96 * W2D_BM;   // floats per weight chunk (24 KiB)
 // NWP: pixel groups of 16 tiles (128 pixels) per block.  2: four waves, 64 channels x 256 pixels, two blocks per CU.  4: eight
 // waves, 64 x 512 pixels, one block per CU -- the 24-KiB weight chunk then feeds twice the MFMAs: with a third of the direct
 // form's multiplications the L2 -> LDS fills (30 KiB per 192 MFMAs in the four-wave form) are what the kernel waits for.
-template <bool PLAIN, int NWP>
+//
+// X4: the halo windows move as ALIGNED 16-byte pieces (global_load_lds_dwordx4) instead of dword gathers: a quarter of the halo's
+// DMA instructions (2 instead of 6 per channel plane of a 10 x 34 window), and the LDS-DMA issue -- 60-180 cycles an instruction --
+// is what this kernel waits for besides its MFMAs.  Possible when every source row starts 16-byte aligned and a piece lies wholly
+// inside or wholly outside a row: ONE plain source segment with a row pitch that is a multiple of 4 floats whose pad columns hold
+// zeros -- the row-pitched d_raw buffer every dX launch reads (gsd_bn_bwd_apply's out-of-place form).  A window row is the NP =
+// TW/4 + 2 pieces that cover image columns w0-4 .. w0+TW+3; the planes are shifted by ONE float in LDS so that image column w0-1
+// lands 16-byte aligned and the consumer reads stay one b128 + one b64 per window row.
+template <bool PLAIN, int NWP, bool X4 = false>
 __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DParams P) {
+  static_assert(!X4 || PLAIN, "16-byte halo pieces: a plain, row-pitched source");
   constexpr int BM = W2D_BM, WTILE = W2D_WTILE, NT = 128 * NWP, NW = 2 * NWP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PS = P.PS;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   const bool q_ok = q < (P.TH >> 1) * P.TWq && q < 16 * NWP;
   const int tr2 = q_ok ? q / P.TWq : 0;
   const int tq = q_ok ? q - tr2 * P.TWq : 0;
-  const int baddr = WTILE + j * PS + (2 * tr2) * P.WCp + 4 * tq;   // halo columns 4*tq .. 4*tq+5 of halo rows 2*tr2 .. 2*tr2+3
+  const int baddr = WTILE + j * PS + (2 * tr2) * P.WCp + 4 * tq + (X4 ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows 2*tr2 .. 2*tr2+3
   int vmask = 0;   // bits 0..3: pixels of the tile's first row that exist in the image, bits 4..7: of its second row
   if (q_ok) {
 #pragma unroll
@@ -106,6 +116,18 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
     xo0[pp] = xo1[pp] = -2;
+    if constexpr (X4) {
+      // unit u = (channel plane u / NI, instruction u % NI) of the chunk: its 64 lanes are 64 consecutive pieces of the plane
+      const int u = wave8 + NW * pp;
+      p_on[pp] = u < 4 * P.NI;
+      const int piece = (u % P.NI) * 64 + lane;
+      const int rr = piece / P.NP, pc = piece - rr * P.NP;
+      if (rr < P.WR) {
+        const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
+        xo0[pp] = ((unsigned)gh < (unsigned)P.src0.H && gw >= 0 && gw + 4 <= P.src0.ws) ? gh * P.src0.ws + gw : -1;
+      }
+      continue;
+    }
     p_on[pp] = wave8 + NW * pp < P.NPV;
     const int pos = (wave8 + NW * pp) * 64 + lane;
     const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
@@ -125,9 +147,16 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     for (int pp = 0; pp < 2; ++pp)
       if (p_on[pp] && xo0[pp] == -1) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (X4) {   // the unit's own plane
+            const int u = wave8 + NW * pp;
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad0;
+            for (int e = 0; e < 4; ++e) smem[b * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4 + e] = pad0;
+          } else {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad0;
+          }
+        }
       }
   }
   const float* d_base = P.src0.p + (long long)n * P.src0.ns;   // channel plane of the next halo slot
@@ -159,6 +188,13 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     for (int pp = 0; pp < 2; ++pp)
       if (p_on[pp] && f_xl[pp] >= 0) __builtin_amdgcn_global_load_lds(d_base + f_xl[pp], Xb + ch * PS + (wave8 + NW * pp) * 64, 4, 0, 0);
     d_base += d_cs;
+  };
+  // X4: unit pp of this wave (one instruction of one of the chunk's four planes); d_base stays at the chunk's first plane
+  auto halo_unit = [&](int pp, float* Xb) {
+    const int u = wave8 + NW * pp;
+    if (p_on[pp] && f_xl[pp] >= 0)
+      __builtin_amdgcn_global_load_lds(d_base + (u / P.NI) * d_cs + f_xl[pp], Xb + (u / P.NI) * PS + 1 + (u % P.NI) * 256, 16, 0, 0);
+    if (pp == 1) d_base += 4 * d_cs;
   };
   constexpr int WPW = 24 / NW;   // 1-KiB weight pieces per wave and chunk (6 or 3)
   const float* const wsrc0 = P.wt + (size_t)mbb * P.nchunks * WTILE + wave8 * (WPW * 256) + lane * 4;
@@ -224,8 +260,13 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   const int a_lane = mh * 64 + l16 * 4;   // this wave's (f, f+1) x two m-tiles of a frequency pair: 16 lanes read 256 contiguous bytes
   begin_fill(0, 0);
   weight_fill(0, smem);
+  if constexpr (X4) {
+    halo_unit(0, smem + WTILE);
+    halo_unit(1, smem + WTILE);
+  } else {
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch) halo_slot(ch, smem + WTILE);
+    for (int ch = 0; ch < 4; ++ch) halo_slot(ch, smem + WTILE);
+  }
 
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
@@ -302,8 +343,12 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
             begin_fill(chunk + 1, cur ^ 1);
             if (!((W2D_ABL) & 1)) weight_fill(chunk + 1, Wn);
           } else if (!((W2D_ABL) & 2)) {
-            halo_slot(2 * s - 2, Wn + WTILE);
-            halo_slot(2 * s - 1, Wn + WTILE);
+            if constexpr (X4) {
+              halo_unit(s - 1, Wn + WTILE);
+            } else {
+              halo_slot(2 * s - 2, Wn + WTILE);
+              halo_slot(2 * s - 1, Wn + WTILE);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -585,16 +630,38 @@ bool plan_w2d(int N, int H, int W, int M, W2DPlan* best) {
   return true;
 }
 
-template <bool PLAIN, int NWP>
+// X4: plane stride of the shifted planes (row pitch 4 NP floats) with the fewest bank conflicts of the consumers' reads
+int w2d_x4_plane_stride(int TWq, int WCp, int WR) {
+  struct Memo { std::atomic<int> key{0}; int ps = 0; };
+  static Memo memo[8];
+  const int key = (TWq << 20) | (WCp << 8) | WR;
+  Memo& mm = memo[(TWq + WR) & 7];
+  if (mm.key.load(std::memory_order_acquire) == key) return mm.ps;
+  int best = -1, ps_best = WR * WCp + 4;
+  for (int ps = WR * WCp + 4; ps < WR * WCp + 4 + 68; ps += 4) {
+    const int c = w2d_read_cycles(TWq, WCp, ps, 2);
+    if (best < 0 || c < best) {
+      best = c;
+      ps_best = ps;
+    }
+  }
+  if (mm.key.exchange(0, std::memory_order_acq_rel) == 0) {
+    mm.ps = ps_best;
+    mm.key.store(key, std::memory_order_release);
+  }
+  return ps_best;
+}
+
+template <bool PLAIN, int NWP, bool X4 = false>
 int launch_w2d(const W2DParams& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, X4>);
   if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP>), dim3(grid), dim3(128 * NWP), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, X4>), dim3(grid), dim3(128 * NWP), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w2d");
   return GSD_OK;
 }
@@ -696,9 +763,21 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   GSD_REQUIRE(P.NPV <= 4 * pl.nwp, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: halo window too large");
   const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: grid too large");
-  const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
   bool plain = true;
   for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
+  // 16-byte halo pieces: one plain source whose rows start 16-byte aligned (pitch, plane and image strides multiples of 4 floats);
+  // its pad columns must hold zeros -- the engine's row-pitched d_raw buffer does (GSD_W2D_X4=0: dword gathers, A/B runs)
+  P.NP = pl.TW / 4 + 2;
+  P.NI = ceil_div(P.WR * P.NP, 64);
+  const bool x4 = plain && nsrc == 1 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_X4", 1) != 0 &&
+                  ((uintptr_t)src[0].ptr & 15) == 0 && src[0].w_stride % 4 == 0 && src[0].c_stride % 4 == 0 && src[0].n_stride % 4 == 0 &&
+                  src[0].off_h == 0 && src[0].off_w == 0 && src[0].w_stride >= round_up(src[0].W, 4);
+  if (x4) {
+    P.WCp = 4 * P.NP;
+    P.PS = w2d_x4_plane_stride(pl.TWq, P.WCp, P.WR);
+  }
+  const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
+  if (x4) return launch_w2d<true, 2, true>(P, (int)grid, lds, (hipStream_t)stream);
   if (pl.nwp == 2)
     return plain ? launch_w2d<true, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2>(P, (int)grid, lds, (hipStream_t)stream);
   return plain ? launch_w2d<true, 4>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 4>(P, (int)grid, lds, (hipStream_t)stream);

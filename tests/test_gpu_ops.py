@@ -123,6 +123,8 @@ def test_conv3x3_deferred_bn_two_segments_and_crop(gsd, algo, c0, c1, co):
                      gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
     assert rel_l1(y.cpu().numpy(), ref) < F.tol
     # dgrad with split destinations: dX of the same conv, routed to (skip grad | cropped up grad)
+    if algo == 2 and not gsd.lib.gsd_conv3x3_w2d_supported(co, co):
+        return          # the dX launch contracts over co channels: 9 and 70 are no multiples of 4 (the (8, 12, 20) case covers it)
     dy = rnd(rng, n, co, h, w)
     dxr, _ = on.conv3x3_bwd(np.concatenate([a0, upp], 1), wt_, dy)
     g_skip = torch.zeros((n, c0, h, w), device="cuda")
