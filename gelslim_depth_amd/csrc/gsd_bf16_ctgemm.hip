@@ -436,8 +436,10 @@ int gsd_ctgemm_partial_rows(int N, int H, int W, int M) {
 // and stay inside the buffer (the kernel has no zero line)
 bool gsd_ctgemm_operands(const gsd_nhwc* in, const gsd_nhwc* out, const gsd_bf16_bnbwd* bw, int ntaps, const int* ty, const int* tx, int H,
                          int W) {
-  if ((long long)in->N * in->H * in->W * in->pitch >= 2147483647LL || (long long)out->N * out->H * out->W * out->pitch >= 2147483647LL) return false;
-  if (bw != nullptr && (long long)bw->y->N * bw->y->H * bw->y->W * bw->y->pitch >= 2147483647LL) return false;
+  // 32-bit BYTE offsets per pixel, also for the (up to 512) pixel slots past the last item's end: (pixels + 512) * pitch * 2 < 2^32
+  auto fits = [](const gsd_nhwc* t) { return ((long long)t->N * t->H * t->W + 512) * t->pitch < 2147483647LL; };
+  if (!fits(in) || !fits(out)) return false;
+  if (bw != nullptr && !fits(bw->y)) return false;
   if (ntaps == 1) return ty[0] == 0 && tx[0] == 0 && in->H == H && in->W == W;
   const int oy = ty[0], ox = tx[0];
   if (oy < 0 || ox < 0 || ty[1] != oy || tx[1] != ox + 1 || ty[2] != oy + 1 || tx[2] != ox || ty[3] != oy + 1 || tx[3] != ox + 1) return false;

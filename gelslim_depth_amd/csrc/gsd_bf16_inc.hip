@@ -276,9 +276,13 @@ __global__ __launch_bounds__(512) void inc_fused_bf16_kernel(const IncP P) {
       }
       if (q < G::NPH) {
         const int sw = (g ^ ((c >> 1) & 2)) << 4;
-        if (!((INC_ABL) & 16) || pk[0] == 0x12345u)
-        *reinterpret_cast<u32x4*>(Al + q * 64 + sw) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-        *reinterpret_cast<u32x4*>(Al + G::ACT_PLANE + q * 64 + sw) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+#if (INC_ABL) & 16   // diagnostic: the rebuilt activation is not staged (the never-true test keeps pk alive)
+        if (pk[0] == 0x12345u)
+#endif
+        {
+          *reinterpret_cast<u32x4*>(Al + q * 64 + sw) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          *reinterpret_cast<u32x4*>(Al + G::ACT_PLANE + q * 64 + sw) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        }
         if (!((INC_ABL) & 1) && inimg && r >= 1 && r <= TH && c >= 1 && c <= I_TW) {   // the tile's own pixels: a0 goes to HBM once
           u16* o = P.a0 + ((long long)(n * P.H + h) * P.W + w) * P.a0_pitch + g * 8;
           inc_store16(o, u32x4{pk[0], pk[1], pk[2], pk[3]});

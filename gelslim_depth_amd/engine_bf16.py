@@ -109,11 +109,17 @@ class UNetEngineBF16:
         self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
 
     # ------------------------------------------------------------------ buffers
+    # tuning switches the library re-reads on every call and that change how many partial rows a launch writes: the buffers below
+    # are sized from them, so they are part of the shape key -- a switch flipped between two steps (a test's monkeypatch, a sweep
+    # in one process) re-sizes the buffers instead of overrunning them
+    _SIZING_ENV = ("GSD_BF16_BN_BLOCKS", "GSD_BF16_CTGEMM", "GSD_BF16_CT_BM", "GSD_BF16_TW", "GSD_BF16_XCD")
+
     def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
-        key = (n, h, w, str(dev), train)
+        import os
+        key = (n, h, w, str(dev), tuple(os.environ.get(k) for k in self._SIZING_ENV), train)
         if self._shape == key:
             return
-        if self._shape is not None and self._shape[:4] == key[:4] and not train:
+        if self._shape is not None and self._shape[:5] == key[:5] and not train:
             return                      # eval after train at the same shape: everything needed exists
         self._shape = key
         hs, ws = [h], [w]
@@ -318,7 +324,8 @@ class UNetEngineBF16:
         self._apply(u, dy, st, pool_to)
 
     def _use_c64(self, k: int, m: int) -> bool:
-        return self.c64 and bool(lib.gsd_bf16_conv3x3_c64_supported(k, m))
+        # (the weights-resident kernel fills through buffer descriptors: one image of an operand must stay below 2 GiB)
+        return self.c64 and bool(lib.gsd_bf16_conv3x3_c64_supported(k, m)) and self.hs[0] * self.ws[0] * 64 * 2 < (1 << 31)
 
     def _run_inc_fused(self, u0: _Unit, u1: _Unit, P, st: int, pool_to: Optional[torch.Tensor]) -> None:
         """Train-mode `inc` (unet.py:7-20, :67) without u0's raw output: statistics of conv(x) from a write-free pass, then ONE

@@ -71,6 +71,9 @@ def evaluate_loader(step, loader: Iterable[Dict], loss_kind: str = "mse") -> flo
     import torch
     from .train import loss_fwd_bwd
     sharded = getattr(loader, "world_size", 1) > 1 and hasattr(loader, "eval_shares")
+    if sharded and (getattr(step, "pg", None) is None or getattr(step, "dist", None) is None):
+        raise RuntimeError("evaluate_loader: the loader is sharded over %d ranks but the step was built without a process_group; "
+                           "pass the group to TrainStep or evaluate loader.unsharded()" % loader.world_size)
     buf = ws = None
     rows = []          # per (global) batch: device tensor [loss sum over this rank's valid elements, their count]
     dev = None
@@ -89,17 +92,23 @@ def evaluate_loader(step, loader: Iterable[Dict], loss_kind: str = "mse") -> flo
         if valid is not None and valid < out.shape[0]:
             out, t = out[:valid], t[:valid]       # leading-dimension slices stay contiguous: the padding is not scored
         loss_fwd_bwd(loss_kind, out, t, None, buf, ws)
-        cnt = float(out.numel())
-        rows.append(torch.stack([buf[0].double() * cnt, torch.tensor(cnt, device=dev, dtype=torch.float64)]))
+        rows.append((buf[0].double().clone(), float(out.numel())))      # the element counts stay on the host
     if not rows:
         return 0.0
     if dev is None:
         dev = getattr(getattr(step, "p_flat", None), "device", None) or torch.device("cpu")
-    zero = torch.zeros((2,), device=dev, dtype=torch.float64)
-    tab = torch.stack([r if r is not None else zero for r in rows])
-    if sharded:
+    counts = torch.tensor([r[1] if r is not None else 0.0 for r in rows], dtype=torch.float64)
+    zero = torch.zeros((), device=dev, dtype=torch.float64)
+    losses = torch.stack([r[0] if r is not None else zero for r in rows])
+    if not sharded:
+        vals = losses.cpu().tolist()                                    # single process: the batch losses themselves
+    else:
+        tab = torch.stack([losses * counts.to(dev), counts.to(dev)], dim=1)      # one upload, one all-reduce, one download
         step.dist.all_reduce(tab, group=step.pg)
-    vals = (tab[:, 0] / tab[:, 1]).cpu().tolist()
+        tab = tab.cpu()
+        if bool((tab[:, 1] == 0).any()):
+            raise RuntimeError("evaluate_loader: a global batch was scored by no rank (the ranks' loaders disagree on the batch order)")
+        vals = (tab[:, 0] / tab[:, 1]).tolist()
     return _mean_loss([0.0 if v != v else v for v in vals], len(vals))
 
 
@@ -123,6 +132,10 @@ def fit(step, train_loader, val_loader, test_loader, weights_path: str, weights_
         from .dataset import train_epoch as train_pass
     if eval_pass is None:
         eval_pass = evaluate_loader
+    elif getattr(val_loader, "world_size", 1) > 1 and hasattr(val_loader, "unsharded"):
+        # a caller-supplied pass does not know about shares: it gets single-process loaders (no wrap-around-padded shards in the
+        # loss early stopping reads); the default pass scores every rank's share of the GLOBAL batches instead
+        val_loader, test_loader = val_loader.unsharded(), test_loader.unsharded()
     if save is None:
         def save(st, path):
             st.save_checkpoint(path, use_ema=True)
