@@ -56,6 +56,10 @@ class gsd_bf16_bnbwd(C.Structure):
                 ("invstd", C.c_void_p)]
 
 
+class gsd_wl_job(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("mode", C.c_int32), ("Co", C.c_int32), ("Ci", C.c_int32), ("reserved", C.c_int32)]
+
+
 class gsd_bf16_wimg_job(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("mode", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("reserved", C.c_int32)]
@@ -72,6 +76,7 @@ SIGNATURES = {
     "gsd_selftest_mfma": (_I, [_P, _P, _P, _P]),
     "gsd_weight_layout_size": (_L, [_I, _I, _I]),
     "gsd_weight_layout": (_I, [_I, _P, _I, _I, _P, _P]),
+    "gsd_weight_layout_batch": (_I, [C.POINTER(gsd_wl_job), _I, _P]),
     "gsd_conv3x3_partial_rows": (_I, [_I, _I, _I, _I]),
     "gsd_conv3x3": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _I, _I, _I, _P]),
     "gsd_conv3x3_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -144,6 +144,10 @@ class UNetEngine:
         self.guard = None          # non-finite guard of the current step (_lib.make_guard), set by TrainStep per step
         self.generation = 0        # forwards so far: a backward belongs to exactly one (models/unet.py checks it)
         # bench hook: when a list, every conv3x3 launch appends (variant, flops, start_event, end_event)
+        import os
+        # partial-row count up to which BatchNorm's column sums and finalize run as ONE launch (gsd_bn_[bwd_]reduce_finalize)
+        self.one_launch_rows = int(os.environ.get("GSD_BN_ONE_LAUNCH_ROWS", "4096"))
+        self.batch_wl = os.environ.get("GSD_WL_BATCH", "1") != "0"   # a pass's weight layouts through gsd_weight_layout_batch
         self.kernel_log: Optional[list] = None
         self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
 
@@ -244,6 +248,14 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
+    def _layouts(jobs, st: int) -> None:
+        """gsd_weight_layout_batch over (mode, weights, Co, Ci, image) tuples."""
+        arr = (L.gsd_wl_job * len(jobs))()
+        for i, (mode, w, co, ci, wt) in enumerate(jobs):
+            arr[i].w, arr[i].wt, arr[i].mode, arr[i].Co, arr[i].Ci = w.data_ptr(), wt.data_ptr(), mode, co, ci
+        check(lib.gsd_weight_layout_batch(arr, len(jobs), st), "weight_layout_batch")
+
+    @staticmethod
     def _act_src(u: _Unit) -> L.gsd_src:
         return L.make_src(u.raw, u.scale, u.shift, relu=True, slack=L.SLACK)
 
@@ -251,7 +263,8 @@ class UNetEngine:
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
         u.form_f = u.forms_f[train]
-        check(lib.gsd_weight_layout(u.form_f.mode_f, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
+        if not self.batch_wl:
+            check(lib.gsd_weight_layout(u.form_f.mode_f, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_f.data_ptr(), st), "weight_layout")
         arr = L.src_array(srcs)
         u.srcs = arr
         dst = L.dst_array([L.make_dst(u.raw)])
@@ -262,9 +275,19 @@ class UNetEngine:
         self._log_end(ev, u.cout, u.cin, n, lh, lw, u.form_f.algo)
         if train:
             rows = u.form_f.partial_rows(n, lh, lw, u.cout)
+            count = float(n * lh * lw)
+            if self.sync_fn is None and rows <= self.one_launch_rows:
+                # a few hundred partial rows (the deep levels; every level at small batches): column sums + finalize in ONE
+                # launch instead of three (no SyncBN exchange in between)
+                check(lib.gsd_bn_reduce_finalize(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), count,
+                                                 P[u.gname].data_ptr(), P[u.bname].data_ptr(), BN_EPS, BN_MOMENTUM,
+                                                 P[u.rmname].data_ptr(), P[u.rvname].data_ptr(), u.mean.data_ptr(),
+                                                 u.invstd.data_ptr(), u.scale.data_ptr(), u.shift.data_ptr(), self.guard, st),
+                      "bn_reduce_finalize")
+                self._nbt.append(P[u.nbtname])
+                return
             check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
                   "bn_reduce_partials")
-            count = float(n * lh * lw)
             if self.sync_fn is not None:
                 self.sync_fn(u.sums[:2 * u.cout])
                 count *= self.world
@@ -325,6 +348,9 @@ class UNetEngine:
         self._x = x
         self._saved_train = train
         self.generation += 1       # every forward overwrites the saved activations
+        if self.batch_wl:          # every forward-mode weight layout of the pass: the 2-D Winograd images in one launch
+            self._layouts([(u.forms_f[train].mode_f, P[u.wname], u.cout, u.cin, u.wt_f) for u in self.units] +
+                          [(6, P[up.wname], up.cout, up.cin, up.wt_f) for up in self.ups], st)
         region = self._log_begin() if self.region_log is not None else None
         for lvl in range(self.L + 1):
             u0, u1 = self.enc[lvl]
@@ -350,7 +376,8 @@ class UNetEngine:
         for j in range(self.L):
             up = self.ups[j]
             lvl = self.L - 1 - j
-            check(lib.gsd_weight_layout(6, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_layout")
+            if not self.batch_wl:
+                check(lib.gsd_weight_layout(6, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_f.data_ptr(), st), "weight_layout")
             s = self._act_src(cur)
             d = L.make_dst(up.out)
             check(lib.gsd_convT2x2(C.byref(s), up.wt_f.data_ptr(), P[up.bname].data_ptr(), up.cin, up.cout, C.byref(d), n,
@@ -376,24 +403,29 @@ class UNetEngine:
         fused: the partials come from gsd_conv3x3_dgrad_bnrelu (conv layout) instead of gsd_bn_bwd_reduce."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        if fused:
-            rows = u.fused_rows   # of the dX launch that wrote them (_dgrad_fused)
-            check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
-                  "bn_reduce_partials")
-        else:
-            rows = lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw)
-            check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
-                  "bn_bwd_reduce_partials")
+        rows = u.fused_rows if fused else lib.gsd_bn_bwd_partial_rows(n, u.cout, lh, lw)   # fused: of the dX launch (_dgrad_fused)
         count = float(n * lh * lw)
-        gsum = None
-        if self.sync_fn is not None:
-            gsum = u.sums[:2 * u.cout].clone()
-            self.sync_fn(gsum)
-            count *= self.world
-        check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), L.ptr(gsum), u.cout, count, G[u.gname].data_ptr(),
-                                      G[u.bname].data_ptr(), None if dwout is None else dwout.data_ptr(),
-                                      u.c1.data_ptr(), u.c2.data_ptr(), st),
-              "bn_bwd_finalize")
+        if self.sync_fn is None and rows <= self.one_launch_rows and (dwout is None or not fused):
+            check(lib.gsd_bn_bwd_reduce_finalize(self.partials.data_ptr(), rows, _r64(u.cout) if fused else 0, u.cout,
+                                                 u.sums.data_ptr(), count, G[u.gname].data_ptr(), G[u.bname].data_ptr(),
+                                                 None if dwout is None else dwout.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), st),
+                  "bn_bwd_reduce_finalize")
+        else:
+            if fused:
+                check(lib.gsd_bn_reduce_partials(self.partials.data_ptr(), rows, _r64(u.cout), u.cout, u.sums.data_ptr(), st),
+                      "bn_reduce_partials")
+            else:
+                check(lib.gsd_bn_bwd_reduce_partials(self.partials.data_ptr(), rows, u.cout, u.sums.data_ptr(), st),
+                      "bn_bwd_reduce_partials")
+            gsum = None
+            if self.sync_fn is not None:
+                gsum = u.sums[:2 * u.cout].clone()
+                self.sync_fn(gsum)
+                count *= self.world
+            check(lib.gsd_bn_bwd_finalize(u.sums.data_ptr(), L.ptr(gsum), u.cout, count, G[u.gname].data_ptr(),
+                                          G[u.bname].data_ptr(), None if dwout is None else dwout.data_ptr(),
+                                          u.c1.data_ptr(), u.c2.data_ptr(), st),
+                  "bn_bwd_finalize")
         if u.fused_dw:
             check(lib.gsd_conv3x3_wgrad_bn(u.srcs, u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
                                            u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), u.cin, u.cout,
@@ -428,7 +460,8 @@ class UNetEngine:
         stored in self.partials (the conv epilogue's BatchNorm-statistics path); returns their row count."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        if not self.batch_wl:
+            check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.src_array([L.make_src(u.dsrc)])
         ev = self._log_begin()
         check(u.form_d.run(self.conv_ws, s, 1, u.wt_d.data_ptr(), u.cout, u.cin, L.dst_array(dsts), len(dsts),
@@ -440,7 +473,8 @@ class UNetEngine:
         """dX of unit u straight into prev.g as dz of prev's relu(bn(.)) (+ partial sums): u's input is prev's output."""
         n = u.raw.shape[0]
         lh, lw = self.hs[u.level], self.ws[u.level]
-        check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
+        if not self.batch_wl:
+            check(lib.gsd_weight_layout(u.form_d.mode_d, P[u.wname].data_ptr(), u.cout, u.cin, u.wt_d.data_ptr(), st), "weight_layout")
         s = L.make_src(u.dsrc)
         d = L.make_dst(prev.g)
         prev.fused_rows = u.form_d.partial_rows(n, lh, lw, u.cin)
@@ -459,6 +493,9 @@ class UNetEngine:
         dout = dout.contiguous()
         st = L.stream_ptr()
         n = dout.shape[0]
+        if self.batch_wl:          # the dX-mode weight layouts (the weights have not changed since the forward)
+            self._layouts([(u.form_d.mode_d, P[u.wname], u.cout, u.cin, u.wt_d) for u in self.units if u.need_dgrad] +
+                          [(up.mode_d, P[up.wname], up.cout, up.cin, up.wt_d) for up in self.ups], st)
         last = self.dec[-1][1] if self.L > 0 else self.enc[0][1]
         self._reduce(2, last, st, dout=dout, wout=P["outc.conv.weight"])
         check(lib.gsd_sum_planes(dout.data_ptr(), n, self.n_classes, dout.shape[2] * dout.shape[3],
@@ -495,7 +532,8 @@ class UNetEngine:
             check(lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
                                          None if db_fused else G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(),
                                          self.wgrad_ws.numel(), n, hi, wi, st), "convT2x2_wgrad")
-            check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
+            if not self.batch_wl:
+                check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
             check(lib.gsd_convT2x2_dgrad_as(up.mode_d, C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
                   "convT2x2_dgrad")

@@ -121,6 +121,14 @@ int gsd_selftest_mfma(const float* a, const float* b, float* out, void* stream);
  * must be 16-byte aligned. */
 int64_t gsd_weight_layout_size(int mode, int Co, int Ci);
 int gsd_weight_layout(int mode, const float* w, int Co, int Ci, float* wt, void* stream);
+/* Several layouts in as few launches as possible: the 2-D Winograd images (modes 8 / 9) of all jobs in ONE launch (up to 40 per
+ * launch), every other mode as gsd_weight_layout would.  `jobs` is read on the host during the call. */
+typedef struct {
+  const float* w;   /* (Co, Ci, 3, 3) weights */
+  float* wt;        /* gsd_weight_layout_size(mode, Co, Ci) floats */
+  int32_t mode, Co, Ci, reserved;
+} gsd_wl_job;
+int gsd_weight_layout_batch(const gsd_wl_job* jobs, int n, void* stream);
 
 /* ---- convolution family (implicit GEMM on v_mfma_f32_16x16x4_f32) -------------------------- */
 /* conv3x3, stride 1, pad 1, no bias.  Replaces aten::convolution at unet.py:11,14 (forward,
