@@ -69,9 +69,18 @@ constexpr int W2D_WTILE = 96 * W2D_BM;   // floats per weight chunk (24 KiB)
 // zeros -- the row-pitched d_raw buffer every dX launch reads (gsd_bn_bwd_apply's out-of-place form).  A window row is the NP =
 // TW/4 + 2 pieces that cover image columns w0-4 .. w0+TW+3; the planes are shifted by ONE float in LDS so that image column w0-1
 // lands 16-byte aligned and the consumer reads stay one b128 + one b64 per window row.
-template <bool PLAIN, int NWP, bool X4 = false>
+//
+// HM = 2 ("U4"): the same 16-byte pieces on the same w0-4 piece grid, straight from UNALIGNED rows -- any source (a
+// global_load_lds_dwordx4 takes any 4-byte aligned global address at full rate).  On that grid a piece never straddles the LEFT
+// image edge of a segment that starts at column 0; one that straddles a segment's right edge (W % 4 != 0: every level of the
+// U-Net) is loaded as it lies in memory -- the caller vouches for 4 readable floats around the tensor, gsd_src.slack -- and the
+// lane that moved it overwrites its outside floats with the padding value once its own fills have landed, in front of the chunk's
+// barrier (only lanes of blocks at that edge do anything).
+template <bool PLAIN, int NWP, int HM = 0>
 __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DParams P) {
-  static_assert(!X4 || PLAIN, "16-byte halo pieces: a plain, row-pitched source");
+  constexpr bool X4 = HM == 1, U4 = HM == 2, PC = HM != 0;   // PC: the halo lies in LDS as 16-byte pieces
+  constexpr int W2D_NONE = -2147483647 - 1, W2D_PAD = -2147483647;   // lane offsets: no position / a padding position (prefilled)
+  static_assert(!X4 || PLAIN, "aligned 16-byte halo pieces: a plain, row-pitched source");
   constexpr int BM = W2D_BM, WTILE = W2D_WTILE, NT = 128 * NWP, NW = 2 * NWP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PS = P.PS;
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   const bool q_ok = q < (P.TH >> 1) * P.TWq && q < 16 * NWP;
   const int tr2 = q_ok ? q / P.TWq : 0;
   const int tq = q_ok ? q - tr2 * P.TWq : 0;
-  const int baddr = WTILE + j * PS + (2 * tr2) * P.WCp + 4 * tq + (X4 ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows 2*tr2 .. 2*tr2+3
+  const int baddr = WTILE + j * PS + (2 * tr2) * P.WCp + 4 * tq + (PC ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows 2*tr2 .. 2*tr2+3
   int vmask = 0;   // bits 0..3: pixels of the tile's first row that exist in the image, bits 4..7: of its second row
   if (q_ok) {
 #pragma unroll
@@ -113,10 +122,11 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   // ---- halo DMA lane geometry: the block's waves cover the (up to) 128 NW window positions once, dword gathers --------------------
   int xo0[2], xo1[2];
   bool p_on[2];
+  int pmask = 0;   // U4: floats of this lane's pieces that lie outside their row (bits 4 pp .. 4 pp + 3: first segment, + 8: second)
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
-    xo0[pp] = xo1[pp] = -2;
-    if constexpr (X4) {
+    xo0[pp] = xo1[pp] = W2D_NONE;
+    if constexpr (PC) {
       // unit u = (channel plane u / NI, instruction u % NI) of the chunk: its 64 lanes are 64 consecutive pieces of the plane
       const int u = wave8 + NW * pp;
       p_on[pp] = u < 4 * P.NI;
@@ -124,7 +134,27 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
       const int rr = piece / P.NP, pc = piece - rr * P.NP;
       if (rr < P.WR) {
         const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
-        xo0[pp] = ((unsigned)gh < (unsigned)P.src0.H && gw >= 0 && gw + 4 <= P.src0.ws) ? gh * P.src0.ws + gw : -1;
+        if constexpr (X4) {
+          xo0[pp] = ((unsigned)gh < (unsigned)P.src0.H && gw >= 0 && gw + 4 <= P.src0.ws) ? gh * P.src0.ws + gw : W2D_PAD;
+        } else {
+          int hs = gh - P.src0.oh, c0 = gw - P.src0.ow;
+          xo0[pp] = W2D_PAD;
+          if ((unsigned)hs < (unsigned)P.src0.H && c0 + 3 >= 0 && c0 < P.src0.W) {
+            xo0[pp] = hs * P.src0.ws + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < 0 || c0 + e >= P.src0.W) pmask |= 1 << (4 * pp + e);
+          }
+          hs = gh - P.src1.oh;
+          c0 = gw - P.src1.ow;
+          xo1[pp] = W2D_PAD;
+          if (P.src1.C > 0 && (unsigned)hs < (unsigned)P.src1.H && c0 + 3 >= 0 && c0 < P.src1.W) {
+            xo1[pp] = hs * P.src1.ws + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < 0 || c0 + e >= P.src1.W) pmask |= 1 << (8 + 4 * pp + e);
+          }
+        }
       }
       continue;
     }
@@ -134,10 +164,10 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     if (rr < P.WR && cc < P.WC) {
       const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
       int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
-      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : -1;
+      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : W2D_PAD;
       hs = gh - P.src1.oh;
       ws = gw - P.src1.ow;
-      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : -1;
+      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : W2D_PAD;
     }
   }
   {
@@ -145,10 +175,10 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
-      if (p_on[pp] && xo0[pp] == -1) {
+      if (p_on[pp] && xo0[pp] == W2D_PAD) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          if constexpr (X4) {   // the unit's own plane
+          if constexpr (PC) {   // the unit's own plane
             const int u = wave8 + NW * pp;
 #pragma unroll
             for (int e = 0; e < 4; ++e) smem[b * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4 + e] = pad0;
@@ -178,21 +208,27 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     const float pad1 = P.src1.relu ? __builtin_nanf("") : 0.f;
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
-      if (p_on[pp] && f_xl[pp] == -1) {
+      if (p_on[pp] && f_xl[pp] == W2D_PAD) {
+        if constexpr (PC) {
+          const int u = wave8 + NW * pp;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) smem[buf * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad1;
+          for (int e = 0; e < 4; ++e) smem[buf * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4 + e] = pad1;
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) smem[buf * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad1;
+        }
       }
   };
   auto halo_slot = [&](int ch, float* Xb) {   // input channel ch of the chunk: the lanes that have a pixel move it
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
-      if (p_on[pp] && f_xl[pp] >= 0) __builtin_amdgcn_global_load_lds(d_base + f_xl[pp], Xb + ch * PS + (wave8 + NW * pp) * 64, 4, 0, 0);
+      if (p_on[pp] && f_xl[pp] > W2D_PAD) __builtin_amdgcn_global_load_lds(d_base + f_xl[pp], Xb + ch * PS + (wave8 + NW * pp) * 64, 4, 0, 0);
     d_base += d_cs;
   };
   // X4: unit pp of this wave (one instruction of one of the chunk's four planes); d_base stays at the chunk's first plane
   auto halo_unit = [&](int pp, float* Xb) {
     const int u = wave8 + NW * pp;
-    if (p_on[pp] && f_xl[pp] >= 0)
+    if (p_on[pp] && f_xl[pp] > W2D_PAD)
       __builtin_amdgcn_global_load_lds(d_base + (u / P.NI) * d_cs + f_xl[pp], Xb + (u / P.NI) * PS + 1 + (u % P.NI) * 256, 16, 0, 0);
     if (pp == 1) d_base += 4 * d_cs;
   };
@@ -260,7 +296,7 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   const int a_lane = mh * 64 + l16 * 4;   // this wave's (f, f+1) x two m-tiles of a frequency pair: 16 lanes read 256 contiguous bytes
   begin_fill(0, 0);
   weight_fill(0, smem);
-  if constexpr (X4) {
+  if constexpr (PC) {
     halo_unit(0, smem + WTILE);
     halo_unit(1, smem + WTILE);
   } else {
@@ -270,8 +306,28 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 
   for (int chunk = 0; chunk < P.nchunks; ++chunk) {
     const int cur = chunk & 1;
-    if ((W2D_ABL) & 4) __syncthreads();
-    else gsd_dma_barrier();   // the chunk's fills have landed; everyone has left the other image
+    if constexpr (U4) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the chunk have landed
+      // the outside floats of the straddling pieces this lane moved (the lane state still is the one the chunk was filled with)
+      const bool seg1 = f_sw >= 0 && chunk >= f_sw;
+      const int pm = seg1 ? pmask >> 8 : pmask & 0xff;
+      if (pm != 0) {
+        const float padv = (seg1 ? P.src1.relu : P.src0.relu) ? __builtin_nanf("") : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int u = wave8 + NW * pp;
+          float* pq = smem + cur * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (pm >> (4 * pp + e) & 1) pq[e] = padv;
+        }
+      }
+      __syncthreads();
+    } else if ((W2D_ABL) & 4) {
+      __syncthreads();
+    } else {
+      gsd_dma_barrier();   // the chunk's fills have landed; everyone has left the other image
+    }
     const int kc = chunk * 4 + j;
     float sc = 1.f, sh = 0.f, lo = 0.f;
     if constexpr (!PLAIN) {
@@ -343,7 +399,7 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
             begin_fill(chunk + 1, cur ^ 1);
             if (!((W2D_ABL) & 1)) weight_fill(chunk + 1, Wn);
           } else if (!((W2D_ABL) & 2)) {
-            if constexpr (X4) {
+            if constexpr (PC) {
               halo_unit(s - 1, Wn + WTILE);
             } else {
               halo_slot(2 * s - 2, Wn + WTILE);
@@ -652,16 +708,16 @@ int w2d_x4_plane_stride(int TWq, int WCp, int WR) {
   return ps_best;
 }
 
-template <bool PLAIN, int NWP, bool X4 = false>
+template <bool PLAIN, int NWP, int HM = 0>
 int launch_w2d(const W2DParams& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, X4>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, HM>);
   if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, X4>), dim3(grid), dim3(128 * NWP), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, HM>), dim3(grid), dim3(128 * NWP), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w2d");
   return GSD_OK;
 }
@@ -772,12 +828,18 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   const bool x4 = plain && nsrc == 1 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_X4", 1) != 0 &&
                   ((uintptr_t)src[0].ptr & 15) == 0 && src[0].w_stride % 4 == 0 && src[0].c_stride % 4 == 0 && src[0].n_stride % 4 == 0 &&
                   src[0].off_h == 0 && src[0].off_w == 0 && src[0].w_stride >= round_up(src[0].W, 4);
-  if (x4) {
+  // unaligned 16-byte pieces for every other source: each segment vouches for 4 readable floats around its tensor (slack), lane
+  // offsets stay 32-bit.  GSD_W2D_U4=1 selects it; default 0: measured neutral over the train step (97.7-97.9 ms either way,
+  // bit-identical) -- the aligned form's gain on the dX launches does not carry over to unaligned rows with the patch step
+  bool u4 = !x4 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_U4", 0) != 0;
+  for (int i = 0; i < nsrc && u4; ++i) u4 = src[i].slack >= 4;
+  if (x4 || u4) {
     P.WCp = 4 * P.NP;
     P.PS = w2d_x4_plane_stride(pl.TWq, P.WCp, P.WR);
   }
   const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
-  if (x4) return launch_w2d<true, 2, true>(P, (int)grid, lds, (hipStream_t)stream);
+  if (x4) return launch_w2d<true, 2, 1>(P, (int)grid, lds, (hipStream_t)stream);
+  if (u4) return plain ? launch_w2d<true, 2, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 2>(P, (int)grid, lds, (hipStream_t)stream);
   if (pl.nwp == 2)
     return plain ? launch_w2d<true, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2>(P, (int)grid, lds, (hipStream_t)stream);
   return plain ? launch_w2d<true, 4>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 4>(P, (int)grid, lds, (hipStream_t)stream);

@@ -259,6 +259,48 @@ def test_first_layer_at_network_shape(gsd, n):
     assert rel_l1(dw.cpu().numpy(), dwr) < 5e-5
 
 
+@pytest.mark.parametrize("lvl,c0,c1,co", [(3, 512, 512, 512), (1, 128, 0, 128), (0, 64, 64, 64)])
+def test_w2d_halo_forms_are_bit_identical(gsd, monkeypatch, lvl, c0, c1, co):
+    """The three ways gsd_conv3x3_w2d moves its halo windows -- dword gathers (default for unaligned sources), unaligned 16-byte
+    pieces with the right-edge patch (GSD_W2D_U4=1) and, for a row-pitched plain source, aligned 16-byte pieces (default there;
+    GSD_W2D_X4=0: dword gathers) -- bring the same values to the same products: outputs are bit-identical.  Two-segment source
+    with the F.pad offset (segment switch + both segments' right edges), deferred BatchNorm, every tile column of the level."""
+    from oracle import unet_numpy as on
+    L = gsd.lib
+    n, h, w = 2, HS[lvl], WS[lvl]
+    ci = c0 + c1
+    rng = np.random.default_rng(lvl + 5)
+    sc, sh = dev(rng.uniform(0.5, 1.5, c0).astype(np.float32)), dev(rnd(rng, c0, scale=0.3))
+    r0 = slack_dev(gsd, rnd(rng, n, c0, h, w))
+    segs = [gsd.make_src(r0, sc, sh, relu=True, slack=gsd.SLACK)]
+    keep = [r0]
+    if c1:
+        uh, uw = 2 * HS[lvl + 1], 2 * WS[lvl + 1]
+        up = rnd(rng, n, c1, uh, uw)
+        _, (top, left) = on.pad_to(up[:1, :1], h, w)
+        upd = slack_dev(gsd, up)
+        segs.append(gsd.make_src(upd, off=(top, left), slack=gsd.SLACK))
+        keep.append(upd)
+    wd = dev(rnd(rng, co, ci, 3, 3, scale=1.0 / np.sqrt(9 * ci)))
+    wl_f, wl_d = layout(gsd, 8, wd, co, ci), layout(gsd, 9, wd, co, ci)
+    src = gsd.src_array(segs)
+    dyp = pitched(dev(rnd(rng, n, co, h, w)))
+    outs = {}
+    for tag, env in (("dword", {"GSD_W2D_U4": "0", "GSD_W2D_X4": "0"}), ("pieces", {"GSD_W2D_U4": "1", "GSD_W2D_X4": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        y = torch.full((n, co, h, w), float("nan"), device="cuda")
+        gsd.check(L.gsd_conv3x3_w2d(src, len(segs), wl_f.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w,
+                                    gsd.stream_ptr()))
+        g = torch.full((n, ci, h, w), float("nan"), device="cuda")
+        gsd.check(L.gsd_conv3x3_w2d(gsd.src_array([gsd.make_src(dyp)]), 1, wl_d.data_ptr(), co, ci, gsd.dst_array([gsd.make_dst(g)]), 1,
+                                    None, n, h, w, gsd.stream_ptr()))
+        outs[tag] = (y, g)
+    assert bool(torch.isfinite(outs["pieces"][0]).all()) and bool(torch.isfinite(outs["pieces"][1]).all())
+    assert torch.equal(outs["dword"][0], outs["pieces"][0]), "forward: unaligned pieces vs dword gathers"
+    assert torch.equal(outs["dword"][1], outs["pieces"][1]), "dX: aligned pieces vs dword gathers"
+
+
 CONVT = [("up0.up", 4, 1024), ("up1.up", 3, 512), ("up2.up", 2, 256), ("up3.up", 1, 128)]
 CONVT_CASES = [(c, 2) for c in CONVT] + [(c, 32) for c in CONVT[:2]]
 
