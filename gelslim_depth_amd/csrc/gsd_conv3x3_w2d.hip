@@ -23,6 +23,7 @@
 // dword-gather form: every 4-channel chunk lies inside one source segment -- always true in the U-Net).
 #include "gsd_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 __device__ const float gsd_pad_w2d[2] = {0.f, __builtin_nanf("")};
@@ -645,7 +646,10 @@ bool plan_w2d(int N, int H, int W, int M, W2DPlan* best) {
     const int ty = ceil_div(H, th);
     th = round_up(ceil_div(H, ty), 2);
     const long blocks = (long)ty * ceil_div(W, tw) * N;
-    const long cost = blocks * 8 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3);
+    // 8-pixel rows (32 x 8 tiles) save a few blocks on 213-pixel rows (135 against 140 per image) but their halo is 34 rows of 40
+    // bytes -- and too many pieces for the 16-byte fills: they have to save GSD_W2D_TW8_PCT percent (default 8) to be taken
+    // (measured: step 97.35 -> 96.66 ms; 8 x 32 instead of 16 x 16 tiles at 320 x 427, 560 against 540 per image: +0.2 ms, not taken)
+    const long cost = (blocks * 8 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3)) * (tw == 8 ? 100 + gsd_env_int("GSD_W2D_TW8_PCT", 8) : 100);
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       best->TH = th; best->TW = tw; best->TWq = twq;
@@ -838,6 +842,10 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
     P.PS = w2d_x4_plane_stride(pl.TWq, P.WCp, P.WR);
   }
   const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
+  if (gsd_env_set("GSD_W2D_TRACE"))
+    fprintf(stderr, "w2d M%d K%d %dx%d N%d nsrc %d ndst %d plain %d x4 %d u4 %d | ptr&15 %d ws %d cs%%4 %d ns%%4 %d NI %d tile %dx%d\n", Cout, Cin, H, W, N,
+            nsrc, ndst, (int)plain, (int)x4, (int)u4, (int)((uintptr_t)src[0].ptr & 15), src[0].w_stride, (int)(src[0].c_stride % 4),
+            (int)(src[0].n_stride % 4), P.NI, pl.TH, pl.TW);
   if (x4) return launch_w2d<true, 2, 1>(P, (int)grid, lds, (hipStream_t)stream);
   if (u4) return plain ? launch_w2d<true, 2, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 2>(P, (int)grid, lds, (hipStream_t)stream);
   if (pl.nwp == 2)
