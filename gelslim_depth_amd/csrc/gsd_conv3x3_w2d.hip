@@ -51,7 +51,8 @@ struct W2DParams {
 #define W2D_PIPE 1
 #endif
 #ifndef W2D_ABL   // diagnostic builds only (profiles/build_diag_one.sh; results are then garbage): 1 no weight fills after a block's first,
-#define W2D_ABL 0 // 2 no halo fills after the first, 4 barrier without the wait for the fills, 8 no MFMAs, 16 no operand transform
+#define W2D_ABL 0 // 2 no halo fills after the first, 4 barrier without the wait for the fills, 8 no MFMAs, 16 no operand transform,
+                  // 32 no barrier (own fills only)
 #endif
 namespace {
 constexpr int W2D_BM = 64;
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
         }
       }
       __syncthreads();
+    } else if ((W2D_ABL) & 32) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // diagnostic: own fills only, no barrier at all (racy: what the barrier itself costs)
     } else if ((W2D_ABL) & 4) {
       __syncthreads();
     } else {
