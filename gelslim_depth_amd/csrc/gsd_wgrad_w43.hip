@@ -22,6 +22,7 @@
 // gsd_wgrad.hip: bitwise reproducible.
 #include "gsd_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 __device__ const float gsd_pad_wg43[2] = {0.f, __builtin_nanf("")};
@@ -910,6 +911,9 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   const size_t lds = (r3 ? 3 : 2) * img;
   bool plain = gsd_env_int("GSD_WG43_PLAIN", 1) != 0;   // no deferred BatchNorm / ReLU on any activation segment
   for (int i = 0; i < nsrc; ++i) plain = plain && a[i].scale == nullptr && a[i].relu == 0;
+  if (gsd_env_set("GSD_WG43_TRACE"))   // tuning: one line per launch
+    fprintf(stderr, "wg43 M%d N%d %dx%d B%d tile %dx%d stages %d splits %d blocks %ld BM %d BN %d ax4 %d bx4 %d rr %d plain %d lds %zu\n", Cout,
+            Cin, H, W, N, pl.TH, pl.TW, pl.stages_total, pl.splits, grid, pl.BM, pl.BN, (int)ax4, (int)bx4, rr, (int)plain, lds);
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
   // one launcher per instantiation: the kernel's address keys the per-device cache of the launch attribute (gsd_common.h)
