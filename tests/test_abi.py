@@ -143,6 +143,48 @@ def test_conv_form_choice_and_size_queries(monkeypatch):
     assert lib.gsd_conv3x3_algo(32, 320, 427, 3, 64) == 1
 
 
+def test_eval_forms_do_not_depend_on_the_batch_and_slab_scratch_is_consistent(monkeypatch):
+    """Host-side planning only.  (1) Eval-mode inference promises that image i of a batch gets the bits the image alone gets: the
+    conv form the engine takes for an eval forward (gsd_conv3x3_algo + gsd_conv3x3_prefers_w2d(train=0)) must be the same at
+    every batch size, for every unit of the U-Net -- and it must be a form whose arithmetic does not depend on the batch (the
+    two-dimensional Winograd kernel: no row folding, no K slabs; or direct taps for the 3-channel layer).  (2) The K-slab scratch
+    the row form asks for is S x (tile blocks) x 64 x 256 floats with 2 <= S <= 8, and only the small deep levels ask."""
+    from gelslim_depth_amd import _lib
+    lib = _lib.lib
+    for k in ("GSD_CONV_ALGO", "GSD_CONV_W2D", "GSD_W43_SPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    dims = [64, 128, 256, 512, 1024]
+    units = []          # (level, cin, first-segment channels, cout)
+    for lvl, c in enumerate(dims):
+        cin = 3 if lvl == 0 else dims[lvl - 1]
+        units += [(lvl, cin, cin, c), (lvl, c, c, c)]
+    for lvl in range(3, -1, -1):
+        units += [(lvl, 2 * dims[lvl], dims[lvl], dims[lvl]), (lvl, dims[lvl], dims[lvl], dims[lvl])]
+    hs, ws = [320, 160, 80, 40, 20], [427, 213, 106, 53, 26]
+    for lvl, cin, c0, cout in units:
+        forms = set()
+        for n in (1, 2, 3, 8, 16, 32, 64):
+            algo = lib.gsd_conv3x3_algo(n, hs[lvl], ws[lvl], cin, cout)
+            if algo == 1 and lib.gsd_conv3x3_w2d_supported(cin, c0) and lib.gsd_conv3x3_prefers_w2d(n, hs[lvl], ws[lvl], cin, cout, 0):
+                algo = 2
+            forms.add(algo)
+        assert forms == ({0} if cin < 16 else {2}), (lvl, cin, cout, forms)
+    asked = 0
+    for lvl, cin, c0, cout in units:
+        for n in (1, 4, 8, 16, 32):
+            for ci, co in ((cin, cout), (cout, cin)):          # forward and dX launches
+                if ci < 16:
+                    continue
+                need = lib.gsd_conv3x3_w43_workspace(n, hs[lvl], ws[lvl], ci, co)
+                rows = lib.gsd_conv3x3_w43_partial_rows(n, hs[lvl], ws[lvl], co)
+                base = rows // 4 * (-(-co // 64))
+                assert need % (base * 64 * 256) == 0 and need // (base * 64 * 256) in (0, 2, 3, 4, 5, 6, 7, 8), (lvl, n, ci, co, need)
+                if need:
+                    asked += 1
+                    assert base < 3 * 512, ("only launches of less than three rounds of the chip's 512 block slots are cut", lvl, n, base)
+    assert asked > 0
+
+
 def test_guard_struct_and_bench_self_launch_refuses_cleanly():
     """gsd_guard layout; and `python bench.py --gpus N` without a rank environment starts its own ranks as a child job --
     on a machine with fewer than N GPUs (this container has none) it must say so and exit non-zero without a traceback."""
