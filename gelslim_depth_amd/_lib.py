@@ -100,6 +100,8 @@ SIGNATURES = {
     "gsd_convT2x2_dgrad_layout": (_I, [_SRC, _I, _I, _I, _I, _I]),
     "gsd_convT2x2_dgrad": (_I, [_SRC, _P, _I, _I, _DST, _I, _I, _I, _P]),
     "gsd_convT2x2_dgrad_as": (_I, [_I, _SRC, _P, _I, _I, _DST, _I, _I, _I, _P]),
+    "gsd_convT2x2_dgrad_bnrelu_partial_rows": (_I, [_SRC, _I, _I, _I, _I, _I]),
+    "gsd_convT2x2_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad": (_I, [_SRC, _I, _SRC, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_takes_pitched_dy": (_I, [_I, _I, _I, _I, _I]),

@@ -423,8 +423,19 @@ struct ConvTDgParams {
   const float* wt;    // mode 7: [mblock][Kpad][128], k = co*4 + kh*2 + kw
   int K, Kpad, M, nchunks, mblocks;
   int N, H, W, Wv, tiles_flat;
+  // BW (gsd_convT2x2_dgrad_bnrelu): dst is the gradient buffer of the conv+BN+ReLU unit that produced the ConvT's input, whose raw
+  // output bw_raw has dst's strides: dz = relu'(bn(raw)) * dx goes to dst, (sum dz, sum dz * xhat) per channel to `partials`
+  // ([pixel tile * 2 + pixel half][2 * Mpad], Mpad = round_up(Cin, 64)) -- the reduce pass of that unit's BatchNorm backward disappears
+  const float* bw_raw;
+  const float* bw_scale;
+  const float* bw_shift;
+  const float* bw_mean;
+  const float* bw_invstd;
+  float* partials;
+  int Mpad;
 };
 
+template <bool BW>
 __global__ __launch_bounds__(256, 2) void convT_dgrad_dma_kernel(const ConvTDgParams P) {
   constexpr int BM = 128, BN = 128, KC = 32, MT = 4, NT = 4;
   constexpr int WIMG = KC * BM, XIMG = (KC / 2) * (2 * BN), BUF = WIMG + XIMG;
@@ -517,6 +528,74 @@ __global__ __launch_bounds__(256, 2) void convT_dgrad_dma_kernel(const ConvTDgPa
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   const DstD& D = P.dst;
   const long long qa = q0 + wn * 64 + l16 * 4;
+  if constexpr (BW) {
+    // the block's 128 channels' coefficients through LDS (the operand images are dead now), then per (m, reg): raw, mask, store, sums
+    __syncthreads();
+    float* sBw = smem;   // [4][128]: scale, shift, mean, invstd
+    if (tid < BM) {
+      const int c = m0 + tid < D.C ? m0 + tid : 0;
+      sBw[tid] = P.bw_scale[c];
+      sBw[BM + tid] = P.bw_shift[c];
+      sBw[2 * BM + tid] = P.bw_mean[c];
+      sBw[3 * BM + tid] = P.bw_invstd[c];
+    }
+    __syncthreads();
+    // this lane's four virtual pixels: plane offset and validity (a pixel past the batch or in the virtual column is not stored)
+    long long off[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const long long q = qa + t;
+      ok[t] = q < QT;
+      const int nn = ok[t] ? (int)(q / HWv) : 0;
+      const int r = ok[t] ? (int)(q - (long long)nn * HWv) : 0;
+      const int h = r / P.Wv, w = r - h * P.Wv;
+      ok[t] = ok[t] && w < P.W;
+      off[t] = (long long)nn * D.ns + (long long)h * D.ws + w;
+    }
+    const bool row4 = ok[0] && ok[3] && off[3] == off[0] + 3;   // four real pixels of one image row: 16-byte accesses
+    float* const prow = P.partials + (size_t)(pt * 2 + wn) * (2 * P.Mpad);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cl = wm * 64 + m * 16 + j * 4 + reg, ci = m0 + cl;
+        const bool c_ok = ci < D.C;
+        const long long cp = (long long)(c_ok ? ci : 0) * D.cs;
+        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        float x[NT], dz[NT];
+        if (row4) {
+          const f32x4 tv = *reinterpret_cast<const f32x4u*>(P.bw_raw + cp + off[0]);
+          x[0] = tv[0], x[1] = tv[1], x[2] = tv[2], x[3] = tv[3];
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) x[t] = ok[t] ? P.bw_raw[cp + off[t]] : 0.f;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          dz[t] = (c_ok && ok[t] && fmaf(x[t], bsc, bsh) > 0.f) ? acc[m][t][reg] : 0.f;
+          s1 += dz[t];
+          s2 = fmaf(dz[t], (x[t] - bmu) * bis, s2);
+        }
+        if (c_ok) {
+          if (row4) {
+            *reinterpret_cast<f32x4u*>(D.p + cp + off[0]) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+          } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              if (ok[t]) D.p[cp + off[t]] = dz[t];
+          }
+        }
+        s1 = reduce16_to_lane15(s1);
+        s2 = reduce16_to_lane15(s2);
+        if (l16 == 15 && ci < P.Mpad) {
+          prow[ci] = s1;
+          prow[P.Mpad + ci] = s2;
+        }
+      }
+    return;
+  }
   if (qa < QT) {
     const int na = (int)(qa / HWv);
     const int ra = (int)(qa - (long long)na * HWv);
@@ -679,11 +758,14 @@ extern "C" int gsd_convT2x2_dgrad_as(int wt_mode, const gsd_src* src, const floa
     GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_convT2x2_dgrad: grid too large");
     const size_t lds = (size_t)(2 * (32 * 128 + 16 * 256)) * sizeof(float);   // 64 KiB: two blocks per CU
     static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-    if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_dgrad_dma_kernel)); e != hipSuccess) {
+    Q.bw_raw = Q.bw_scale = Q.bw_shift = Q.bw_mean = Q.bw_invstd = nullptr;
+    Q.partials = nullptr;
+    Q.Mpad = 0;
+    if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_dgrad_dma_kernel<false>)); e != hipSuccess) {
       gsd_set_error("gsd_convT2x2_dgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return GSD_ERR_HIP;
     }
-    hipLaunchKernelGGL(convT_dgrad_dma_kernel, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, Q);
+    hipLaunchKernelGGL(convT_dgrad_dma_kernel<false>, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, Q);
     GSD_LAUNCH_CHECK("gsd_convT2x2_dgrad");
     return GSD_OK;
   }
@@ -697,4 +779,65 @@ extern "C" int gsd_convT2x2_dgrad_as(int wt_mode, const gsd_src* src, const floa
   P.nchunks = ceil_div(Cout, 4);
   P.N = N; P.H = H; P.W = W;
   return run<CT_DGRAD>(P, (hipStream_t)stream, "gsd_convT2x2_dgrad");
+}
+
+// dX of the transposed convolution fused with the backward of the relu(bn(raw)) that produced its INPUT (the ConvT reads the
+// activated output of the conv unit below: unet.py:41 after :12-13 / :15-16): dst receives dz = dx * [raw*scale+shift > 0], the
+// partials (sum dz, sum dz*xhat) per channel in rows of 2*Mpad floats, Mpad = round_up(Cin, 64) -- as gsd_conv3x3_dgrad_bnrelu,
+// so the separate gsd_bn_bwd_reduce pass over that unit (one read of g and raw, one write of g) disappears.  The LDS-DMA kernel
+// only (weight layout mode 7); gsd_convT2x2_dgrad_bnrelu_partial_rows: 0 when the arguments do not admit it.
+static bool ct_dma_admits(const gsd_src* src, int Cin, int Cout, int N, int H, int W) {
+  if (src == nullptr || Cin <= 0 || Cout <= 0 || N <= 0 || H <= 0 || W <= 0) return false;
+  return !((W & 1) && src->slack < 2) && (int64_t)N * src->n_stride < (1LL << 40);
+}
+
+extern "C" int gsd_convT2x2_dgrad_bnrelu_partial_rows(const gsd_src* src, int Cin, int Cout, int N, int H, int W) {
+  if (!ct_dma_admits(src, Cin, Cout, N, H, W)) return 0;
+  return (int)ceil_div64((int64_t)N * H * round_up(W, 2), 128) * 2;
+}
+
+extern "C" int gsd_convT2x2_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, const float* raw,
+                                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                                         float* partials, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(src && dst && wt && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_convT2x2_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad_bnrelu: bad sizes");
+  GSD_REQUIRE(ct_dma_admits(src, Cin, Cout, N, H, W), GSD_ERR_UNSUPPORTED,
+              "gsd_convT2x2_dgrad_bnrelu: the arguments do not admit the LDS-DMA kernel (gsd_convT2x2_dgrad_bnrelu_partial_rows == 0)");
+  if (int e = gsd_check_src(*src, "gsd_convT2x2_dgrad_bnrelu src")) return e;
+  if (int e = gsd_check_dst(*dst, "gsd_convT2x2_dgrad_bnrelu dst")) return e;
+  GSD_REQUIRE(src->C == Cout && src->H == 2 * H && src->W == 2 * W && src->scale == nullptr && src->relu == 0 && src->off_h == 0 &&
+                  src->off_w == 0,
+              GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad_bnrelu: src must be the plain (Cout,2H,2W) gradient");
+  GSD_REQUIRE(((uintptr_t)src->ptr & 7) == 0 && (src->c_stride & 1) == 0 && (src->n_stride & 1) == 0, GSD_ERR_UNSUPPORTED,
+              "gsd_convT2x2_dgrad_bnrelu: src must be 8-byte aligned with even strides");
+  GSD_REQUIRE(dst->C == Cin && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_convT2x2_dgrad_bnrelu: dst must be the full (Cin,H,W) gradient buffer (raw shares its strides)");
+  GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_convT2x2_dgrad_bnrelu: the weight image must be 16-byte aligned");
+  ConvTDgParams Q;
+  Q.src = to_srcd(*src);
+  Q.dst = to_dstd(*dst);
+  Q.wt = wt;
+  Q.K = Cout * 4;
+  Q.Kpad = round_up(Cout, 8) * 4;
+  Q.M = Cin;
+  Q.nchunks = Q.Kpad / 32;
+  Q.mblocks = ceil_div(Cin, 128);
+  Q.N = N; Q.H = H; Q.W = W;
+  Q.Wv = round_up(W, 2);
+  Q.tiles_flat = (int)ceil_div64((int64_t)N * H * Q.Wv, 128);
+  Q.bw_raw = raw; Q.bw_scale = scale; Q.bw_shift = shift; Q.bw_mean = mean; Q.bw_invstd = invstd;
+  Q.partials = partials;
+  Q.Mpad = round_up(Cin, 64);
+  const long grid = (long)Q.tiles_flat * Q.mblocks;
+  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_convT2x2_dgrad_bnrelu: grid too large");
+  const size_t lds = (size_t)(2 * (32 * 128 + 16 * 256)) * sizeof(float);
+  static gsd_attr_once big_lds;
+  if (hipError_t e = gsd_allow_big_lds(big_lds, reinterpret_cast<const void*>(&convT_dgrad_dma_kernel<true>)); e != hipSuccess) {
+    gsd_set_error("gsd_convT2x2_dgrad_bnrelu: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
+  }
+  hipLaunchKernelGGL(convT_dgrad_dma_kernel<true>, dim3((int)grid), dim3(256), lds, (hipStream_t)stream, Q);
+  GSD_LAUNCH_CHECK("gsd_convT2x2_dgrad_bnrelu");
+  return GSD_OK;
 }

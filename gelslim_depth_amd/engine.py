@@ -105,6 +105,7 @@ class _Up:
         self.wname, self.bname = f"up.{j}.up.weight", f"up.{j}.up.bias"
         self.wt_f = self.wt_d = None
         self.mode_d = 3            # gsd_weight_layout mode of wt_d (gsd_convT2x2_dgrad_layout)
+        self.bn_rows = 0           # > 0: the dX launch also does pass 1 of the BatchNorm backward of the unit below (partial rows)
         self.out = self.dout = None
 
 
@@ -147,6 +148,7 @@ class UNetEngine:
         import os
         # partial-row count up to which BatchNorm's column sums and finalize run as ONE launch (gsd_bn_[bwd_]reduce_finalize)
         self.one_launch_rows = int(os.environ.get("GSD_BN_ONE_LAUNCH_ROWS", "4096"))
+        self.convt_dg_bn = os.environ.get("GSD_CONVT_DG_BN", "1") != "0"   # ConvT dX + pass 1 of the BatchNorm backward below it
         self.batch_wl = os.environ.get("GSD_WL_BATCH", "1") != "0"   # a pass's weight layouts through gsd_weight_layout_batch
         self.kernel_log: Optional[list] = None
         self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
@@ -229,6 +231,12 @@ class UNetEngine:
                 need = lib.gsd_weight_layout_size(up.mode_d, up.cout, up.cin)
                 if up.wt_d is None or up.wt_d.numel() != need or up.wt_d.device != dev:
                     up.wt_d = torch.empty((need,), **f32)
+                # the LDS-DMA dX kernel can leave dz of the unit below and its per-channel sums (gsd_convT2x2_dgrad_bnrelu)
+                up.bn_rows = 0
+                if up.mode_d == 7 and self.convt_dg_bn:
+                    up.bn_rows = lib.gsd_convT2x2_dgrad_bnrelu_partial_rows(C.byref(L.make_src(up.dout, slack=L.SLACK)), up.cin,
+                                                                            up.cout, n, hs[li], ws[li])
+                    max_part = max(max_part, up.bn_rows * 2 * _r64(up.cin))
             if train:
                 max_ws = max(max_ws, lib.gsd_convT2x2_wgrad_workspace(n, hs[li], ws[li], up.cin, up.cout))
         self.pooled = [None] + [L.slack_empty((n, self.dims[l - 1], hs[l], ws[l]), dev) for l in range(1, self.L + 1)]
@@ -513,7 +521,8 @@ class UNetEngine:
             u0, u1 = self.dec[j]
             up = self.ups[j]
             lvl = self.L - 1 - j
-            self._bn_bwd_tail(u1, P, G, st, dwout)
+            # dz of u1 came from the output conv (j = L-1) or from the ConvT dX of the level above -- with its sums when fused
+            self._bn_bwd_tail(u1, P, G, st, dwout, fused=j < self.L - 1 and self.ups[j + 1].bn_rows > 0)
             dwout = None
             self._dgrad_fused(u1, u0, P, st)
             self._bn_bwd_tail(u0, P, G, st, fused=True)
@@ -535,16 +544,24 @@ class UNetEngine:
             if not self.batch_wl:
                 check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
-            check(lib.gsd_convT2x2_dgrad_as(up.mode_d, C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
-                  "convT2x2_dgrad")
-            self._reduce(0, prev, st)
+            if up.bn_rows:
+                check(lib.gsd_convT2x2_dgrad_bnrelu(C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), prev.raw.data_ptr(),
+                                                    prev.scale.data_ptr(), prev.shift.data_ptr(), prev.mean.data_ptr(),
+                                                    prev.invstd.data_ptr(), self.partials.data_ptr(), n, hi, wi, st),
+                      "convT2x2_dgrad_bnrelu")
+                prev.fused_rows = up.bn_rows
+            else:
+                check(lib.gsd_convT2x2_dgrad_as(up.mode_d, C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
+                      "convT2x2_dgrad")
+                self._reduce(0, prev, st)
             if self.block_done_cb is not None:
                 self.block_done_cb(f"dec{j}")      # up.{j}.* (and outc with the last decoder) are final
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
             if lvl < self.L:
                 self._reduce(1, u1, st, dpool=self.dpooled[lvl + 1])
-            self._bn_bwd_tail(u1, P, G, st, dwout)
+            # the bottom unit's dz came from the first ConvT dX -- with its sums when that launch was the fused one
+            self._bn_bwd_tail(u1, P, G, st, dwout, fused=lvl == self.L and self.L > 0 and self.ups[0].bn_rows > 0)
             dwout = None
             self._dgrad_fused(u1, u0, P, st)
             self._bn_bwd_tail(u0, P, G, st, fused=True)

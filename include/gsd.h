@@ -210,6 +210,16 @@ int gsd_convT2x2_dgrad(const gsd_src* src, const float* wt, int Cin, int Cout,
  * time; a mode the arguments do not admit is refused with GSD_ERR_BAD_ARG. */
 int gsd_convT2x2_dgrad_as(int wt_mode, const gsd_src* src, const float* wt, int Cin, int Cout,
                           const gsd_dst* dst, int N, int H, int W, void* stream);
+/* dX of the transposed convolution fused with the backward of the relu(bn(raw)) that produced its INPUT (unet.py:41 reads the
+ * output of the DoubleConv below, unet.py:12-16): dst receives dz = dx * [raw*scale+shift > 0] and `partials` the per-channel
+ * (sum dz, sum dz*xhat) as rows of 2*round_up(Cin,64) floats -- the layout gsd_conv3x3_dgrad_bnrelu leaves, for
+ * gsd_bn_reduce_partials / gsd_bn_bwd_reduce_finalize -- so gsd_bn_bwd_reduce(mode 0) over that unit disappears.  `raw` has dst's
+ * strides; wt: layout mode 7 (the LDS-DMA kernel only).  gsd_convT2x2_dgrad_bnrelu_partial_rows: the row count, 0 when the
+ * arguments do not admit the kernel (odd W without src->slack >= 2); it does not read the environment. */
+int gsd_convT2x2_dgrad_bnrelu_partial_rows(const gsd_src* src, int Cin, int Cout, int N, int H, int W);
+int gsd_convT2x2_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst, const float* raw,
+                              const float* scale, const float* shift, const float* mean, const float* invstd,
+                              float* partials, int N, int H, int W, void* stream);
 
 /* dW of conv3x3: dW[co][ci][kh][kw] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+kh-1,w+kw-1].
  * `a` is given as up to two segments with deferred BN (recomputed on load), `dy` plain.

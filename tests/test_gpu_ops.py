@@ -254,6 +254,54 @@ def test_convT_fwd_bwd(gsd, monkeypatch, n, ci, h, w):
     assert rel_l1(db.cpu().numpy(), dbr) < TOL
 
 
+@pytest.mark.parametrize("n,ci,h,w", [(2, 8, 4, 5), (1, 128, 20, 26), (2, 36, 7, 9), (3, 24, 5, 53), (1, 264, 3, 2), (2, 16, 1, 1),
+                                       (2, 192, 12, 11)])
+def test_convT_dgrad_bnrelu_is_the_unfused_pair(gsd, n, ci, h, w):
+    """gsd_convT2x2_dgrad_bnrelu: dz bit-equal to the plain dX launch masked by relu'(bn(raw)); the partial rows sum to
+    (sum dz, sum dz * xhat) per channel (fp64 check), pad channels of a row are zero."""
+    rng = np.random.default_rng(ci + w)
+    co = ci // 2
+    raw = rnd(rng, n, ci, h, w)
+    sc, sh = rng.uniform(0.5, 1.5, ci).astype(np.float32), rnd(rng, ci, scale=0.3)
+    mu, inv = rnd(rng, ci, scale=0.2), rng.uniform(0.5, 2.0, ci).astype(np.float32)
+    wt_ = rnd(rng, ci, co, 2, 2, scale=0.2)
+    dy = rnd(rng, n, co, 2 * h, 2 * w)
+    dys = gsd.slack_empty(dy.shape, "cuda")
+    dys.copy_(dev(dy))
+    src_ = gsd.make_src(dys, slack=gsd.SLACK)
+    wimg = layout(gsd, 7, dev(wt_), co, ci)
+    rows = gsd.lib.gsd_convT2x2_dgrad_bnrelu_partial_rows(C.byref(src_), ci, co, n, h, w)
+    assert rows == 2 * -(-(n * h * (w + (w & 1))) // 128)
+    dx = torch.full((n, ci, h, w), float("nan"), device="cuda")
+    gsd.check(gsd.lib.gsd_convT2x2_dgrad_as(7, C.byref(src_), wimg.data_ptr(), ci, co, C.byref(gsd.make_dst(dx)), n, h, w, gsd.stream_ptr()))
+    rawd, scd, shd, mud, invd = dev(raw), dev(sc), dev(sh), dev(mu), dev(inv)
+    mp = -(-ci // 64) * 64
+    part = torch.full((rows, 2 * mp), float("nan"), device="cuda")
+    dz = torch.full((n, ci, h, w), float("nan"), device="cuda")
+    gsd.check(gsd.lib.gsd_convT2x2_dgrad_bnrelu(C.byref(src_), wimg.data_ptr(), ci, co, C.byref(gsd.make_dst(dz)), rawd.data_ptr(),
+                                                scd.data_ptr(), shd.data_ptr(), mud.data_ptr(), invd.data_ptr(), part.data_ptr(),
+                                                n, h, w, gsd.stream_ptr()))
+    mask = torch.addcmul(shd[None, :, None, None], rawd, scd[None, :, None, None]) > 0    # one fma, as the kernel's
+    want = torch.where(mask, dx, torch.zeros_like(dx))
+    assert torch.equal(dz, want)
+    p = part.cpu().numpy().astype(np.float64)
+    assert np.isfinite(p).all()
+    assert not p[:, ci:mp].any() and not p[:, mp + ci:].any()
+    z = want.cpu().numpy().astype(np.float64)
+    xhat = (raw.astype(np.float64) - mu[None, :, None, None]) * inv[None, :, None, None]
+    s1, s2 = z.sum(axis=(0, 2, 3)), (z * xhat).sum(axis=(0, 2, 3))
+    assert np.abs(p[:, :ci].sum(0) - s1).max() <= 2e-5 * max(1.0, np.abs(z).sum(axis=(0, 2, 3)).max())
+    assert np.abs(p[:, mp:mp + ci].sum(0) - s2).max() <= 2e-5 * max(1.0, np.abs(z * xhat).sum(axis=(0, 2, 3)).max())
+    # an odd-width gradient without the readable floats behind it is refused (the kernel reads pixel pairs)
+    if w % 2:
+        plain = gsd.make_src(dev(dy))
+        assert gsd.lib.gsd_convT2x2_dgrad_bnrelu_partial_rows(C.byref(plain), ci, co, n, h, w) == 0
+        rc = gsd.lib.gsd_convT2x2_dgrad_bnrelu(C.byref(plain), wimg.data_ptr(), ci, co, C.byref(gsd.make_dst(dz)), rawd.data_ptr(),
+                                               scd.data_ptr(), shd.data_ptr(), mud.data_ptr(), invd.data_ptr(), part.data_ptr(),
+                                               n, h, w, gsd.stream_ptr())
+        assert rc != 0
+
+
 def test_bn_finalize_and_eval_coeffs(gsd):
     from oracle import unet_numpy as on
     rng = np.random.default_rng(3)
