@@ -28,6 +28,7 @@ DIMS = [64, 128, 256, 512, 1024]
 H, W = 320, 427
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: bf16 MFMA dense peak (not the 2:1-sparsity figure)
+BF16_MFMA_SUSTAINED_TFLOPS = 1855.5  # measured: the ideal bf16 MFMA loop at the clock the chip holds under it (r04_mfma_shape_ubench.txt)
 HBM_PEAK_TBS = 8.0                   # same guide: HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 # SURVEY.md 8(d), the north-star kernel `inc` (3->64->64 @320x427), ideal-fusion fp32 bytes per image: read x 1.64 MB,
 # write + re-read raw c0 34.98 + 34.98, write raw c1 34.98  (the consumer's re-read of c1 belongs to the next kernel)
@@ -390,8 +391,14 @@ def conv_roofline(klog, dtype, steps, ms_per_step, per_layer=False):
     # achieved = flops the kernel's MFMA instructions EXECUTE (2048 per v_mfma_f32_16x16x4_f32, tile padding included) / time:
     # <= peak by construction.  The Winograd F(4,3) kernel needs half the multiplications of the direct convolution, so the
     # ALGORITHMIC rate (2*9*Cout*Cin flops per pixel / time, what SURVEY 8(d) prices) is reported next to it and may exceed peak.
+    roof = {}
+    if dtype != "f32":
+        # the NOMINAL peak assumes 2.4 GHz; under a saturated bf16 MFMA stream this chip holds 1.74-1.92 GHz and the ideal loop
+        # (all operand reads ahead, no fills) reaches 1.73-1.86 PFLOP/s: profiles/ubench/mfma_bf16_rate32.hip, r04_mfma_shape_ubench.txt
+        roof = {"sustained_peak": BF16_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": round(done / BF16_MFMA_SUSTAINED_TFLOPS, 4),
+                "sustained_source": "profiles/r04_mfma_shape_ubench.txt (ideal MFMA loop at the clock the chip holds under it)"}
     return dom, {"bound": "mfma", "kernel": dom, "achieved": round(done, 2), "peak": peak, "unit": "TFLOP/s",
-                 "frac": round(done / peak, 4),
+                 "frac": round(done / peak, 4), **roof,
                  "algorithmic_tflops": round(algorithmic, 2), "algorithmic_vs_peak": round(algorithmic / peak, 4),
                  "launches_timed": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                  "gflop_per_launch": round(flops / max(launches, 1) / 1e9, 2),
