@@ -17,6 +17,7 @@ Data layout in HBM (all fp32 NCHW):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -145,9 +146,12 @@ class UNetEngine:
         self.guard = None          # non-finite guard of the current step (_lib.make_guard), set by TrainStep per step
         self.generation = 0        # forwards so far: a backward belongs to exactly one (models/unet.py checks it)
         # bench hook: when a list, every conv3x3 launch appends (variant, flops, start_event, end_event)
-        import os
         # partial-row count up to which BatchNorm's column sums and finalize run as ONE launch (gsd_bn_[bwd_]reduce_finalize)
         self.one_launch_rows = int(os.environ.get("GSD_BN_ONE_LAUNCH_ROWS", "4096"))
+        # weight gradients on a side stream: dW of a unit runs beside its dX and the BatchNorm backward of the unit below (they only
+        # share d_raw as an input) -- one dW block and one dX block fit a CU together (LDS 96 + 60 KiB, 256 + 256 registers per SIMD lane)
+        self.side_dw = os.environ.get("GSD_SIDE_DW", "1") != "0"
+        self.side: Optional[torch.cuda.Stream] = None
         self.convt_dg_bn = os.environ.get("GSD_CONVT_DG_BN", "1") != "0"   # ConvT dX + pass 1 of the BatchNorm backward below it
         self.batch_wl = os.environ.get("GSD_WL_BATCH", "1") != "0"   # a pass's weight layouts through gsd_weight_layout_batch
         self.kernel_log: Optional[list] = None
@@ -242,12 +246,19 @@ class UNetEngine:
         self.pooled = [None] + [L.slack_empty((n, self.dims[l - 1], hs[l], ws[l]), dev) for l in range(1, self.L + 1)]
         self.dpooled = [None] + ([torch.empty((n, self.dims[l - 1], hs[l], ws[l]), **f32)
                                  for l in range(1, self.L + 1)] if train else [None] * self.L)
-        self.gp = torch.empty((max_gp,), **f32) if (train and max_gp) else None   # pitched d_raw scratch, one unit at a time
+        # pitched d_raw scratch: one unit at a time on one stream; with dW on the side stream two, used in turn (dW of a unit may
+        # still read its buffer while the BatchNorm backward of the next unit writes the other)
+        side = train and self.side_dw
+        self.side = torch.cuda.Stream(device=dev) if side else None   # (a high-priority side stream measured the same)
+        self.gps = [torch.empty((max_gp,), **f32) for _ in range(2 if side else 1)] if (train and max_gp) else None
+        self.gp_turn = 0
+        self.gp_free: List[Optional[torch.cuda.Event]] = [None, None]   # recorded on the side stream behind a buffer's last reader
         self.partials = torch.empty((max_part,), **f32)
         self.conv_ws = torch.empty((max_slab,), **f32) if (train and max_slab) else None
         # fp64 column sums of a dX launch's statistics (ConvT bias gradients): gsd_bn_reduce_partials wants (1 + 64) x 2 C doubles
         self.db_sums = torch.empty((65 * 2 * max(u.cin for u in self.units),), device=dev, dtype=torch.float64) if train else None
         self.wgrad_ws = torch.empty((max(max_ws, 64 * max(1, self.n_classes)),), **f32) if train else None
+        self.wgrad_ws_side = torch.empty((max(max_ws, 64),), **f32) if side else None
         self.outw_partials = self.outw_sums = None
         if train and self.n_classes > 1:    # dW of the output conv for K > 1 (gsd_conv1x1_out_wgrad)
             kc = self.n_classes * self.dims[0]
@@ -435,14 +446,19 @@ class UNetEngine:
                                           u.c1.data_ptr(), u.c2.data_ptr(), st),
                   "bn_bwd_finalize")
         if u.fused_dw:
-            check(lib.gsd_conv3x3_wgrad_bn(u.srcs, u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
-                                           u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), u.cin, u.cout,
-                                           G[u.wname].data_ptr(), self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, lh, lw, st),
-                  "conv3x3_wgrad_bn")
+            self._on_side(lambda sst, ws: check(
+                lib.gsd_conv3x3_wgrad_bn(u.srcs, u.g.data_ptr(), u.raw.data_ptr(), u.scale.data_ptr(), u.mean.data_ptr(),
+                                         u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), u.cin, u.cout,
+                                         G[u.wname].data_ptr(), ws.data_ptr(), ws.numel(), n, lh, lw, sst), "conv3x3_wgrad_bn"))
             return
+        turn = None
         if u.pitched:
             p = _r4(lw)
-            u.dsrc = self.gp[:n * u.cout * lh * p].view(n, u.cout, lh, p)[..., :lw]
+            turn = self.gp_turn = (self.gp_turn + 1) % len(self.gps)
+            if self.gp_free[turn] is not None:     # the dW launch that read this buffer two units ago
+                torch.cuda.current_stream().wait_event(self.gp_free[turn])
+                self.gp_free[turn] = None
+            u.dsrc = self.gps[turn][:n * u.cout * lh * p].view(n, u.cout, lh, p)[..., :lw]
             out_ptr = u.dsrc.data_ptr()
         else:
             p, u.dsrc, out_ptr = 0, u.g, None
@@ -450,8 +466,27 @@ class UNetEngine:
                                    u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), n, u.cout, lh, lw, out_ptr, p, st),
               "bn_bwd_apply")
         dy = L.make_src(u.dsrc)
-        check(lib.gsd_conv3x3_wgrad(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, G[u.wname].data_ptr(),
-                                    self.wgrad_ws.data_ptr(), self.wgrad_ws.numel(), n, lh, lw, st), "conv3x3_wgrad")
+        on_side = self._on_side(lambda sst, ws: check(
+            lib.gsd_conv3x3_wgrad(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, G[u.wname].data_ptr(), ws.data_ptr(), ws.numel(),
+                                  n, lh, lw, sst), "conv3x3_wgrad"))
+        if on_side and turn is not None:
+            self.gp_free[turn] = self.side.record_event()
+
+    def _on_side(self, launch) -> bool:
+        """Run launch(stream pointer, workspace tensor) -- one weight-gradient launch -- behind everything issued so far: on the
+        side stream when there is one (True), else on the current stream."""
+        if self.side is None or self.kernel_log is not None:    # (a per-kernel timing pass wants every kernel alone on the chip)
+            launch(L.stream_ptr(), self.wgrad_ws)
+            return False
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            launch(L.stream_ptr(), self.wgrad_ws_side)
+        return True
+
+    def _join_side(self) -> None:
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.gp_free = [None, None]
 
     def _reduce(self, mode: int, u: _Unit, st: int, dpool: Optional[torch.Tensor] = None,
                 dout: Optional[torch.Tensor] = None, wout: Optional[torch.Tensor] = None) -> None:
@@ -538,9 +573,10 @@ class UNetEngine:
             hi, wi = self.hs[lvl + 1], self.ws[lvl + 1]
             xs = self._act_src(prev)
             dys = L.make_src(up.dout, slack=L.SLACK)
-            check(lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
-                                         None if db_fused else G[up.bname].data_ptr(), self.wgrad_ws.data_ptr(),
-                                         self.wgrad_ws.numel(), n, hi, wi, st), "convT2x2_wgrad")
+            self._on_side(lambda sst, ws, up=up, xs=xs, dys=dys, db_fused=db_fused, hi=hi, wi=wi: check(
+                lib.gsd_convT2x2_wgrad(C.byref(xs), C.byref(dys), up.cin, up.cout, G[up.wname].data_ptr(),
+                                       None if db_fused else G[up.bname].data_ptr(), ws.data_ptr(), ws.numel(), n, hi, wi, sst),
+                "convT2x2_wgrad"))
             if not self.batch_wl:
                 check(lib.gsd_weight_layout(up.mode_d, P[up.wname].data_ptr(), up.cout, up.cin, up.wt_d.data_ptr(), st), "weight_layout")
             d = L.make_dst(prev.g)
@@ -555,6 +591,7 @@ class UNetEngine:
                       "convT2x2_dgrad")
                 self._reduce(0, prev, st)
             if self.block_done_cb is not None:
+                self._join_side()
                 self.block_done_cb(f"dec{j}")      # up.{j}.* (and outc with the last decoder) are final
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
@@ -566,6 +603,8 @@ class UNetEngine:
             self._dgrad_fused(u1, u0, P, st)
             self._bn_bwd_tail(u0, P, G, st, fused=True)
             if self.block_done_cb is not None:
+                self._join_side()
                 self.block_done_cb(f"enc{lvl}")
             if lvl > 0:
                 self._dgrad(u0, P, [L.make_dst(self.dpooled[lvl])], st)
+        self._join_side()

@@ -327,6 +327,35 @@ def test_winograd_and_direct_forms_agree(monkeypatch):
         assert max(dev.values()) < 5e-2, (algo, max(dev.values()))
 
 
+@pytest.mark.parametrize("dims,n,h,w", [([16, 32, 64, 128], 3, 72, 101), ([64, 128, 256], 2, 80, 107)])
+def test_side_stream_weight_gradients_are_bit_identical(monkeypatch, dims, n, h, w):
+    """The weight-gradient launches run on a side stream next to the dX chain (engine.py: _on_side; two d_raw scratch buffers used
+    in turn).  Same kernels on the same operands: every gradient must equal the single-stream schedule's bit for bit, over several
+    steps (a missing dependency between the streams shows up as a difference here)."""
+    from gelslim_depth_amd.train import mse_loss
+    st = synth.make_state(3, 1, dims, 5, "conditioned")
+    x, tgt = synth.make_batch(n, h, w, 6)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    res = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("GSD_SIDE_DW", side)
+        m = make_model(dims, st)
+        m.train()
+        assert (m._engine.side_dw) == (side == "1")
+        grads = []
+        for _ in range(3):
+            for p_ in m.parameters():
+                p_.grad = None
+            out = m(x=xd)
+            mse_loss(out, td).backward()
+            grads.append({k: p_.grad.detach().clone() for k, p_ in m.named_parameters()})
+        assert (m._engine.side is not None) == (side == "1")
+        res[side] = grads
+    for a_, b_ in zip(res["0"], res["1"]):
+        for k in a_:
+            assert torch.equal(a_[k], b_[k]), k
+
+
 @pytest.mark.parametrize("dims,h,w", [([64, 128, 256, 512, 1024], 320, 427), ([16, 32, 64], 37, 53)])
 def test_backward_teacher_forced_unit_by_unit(dims, h, w):
     """The whole-network gradient bounds above (2e-2 / 3e-2) rest on the argument that a ReLU / max-pool network amplifies
