@@ -376,6 +376,17 @@ def conv_roofline(klog, dtype, steps, ms_per_step, per_layer=False):
             for v, (f, t, c, _) in by_kernel.items():
                 print("%-16s launches %4d total %.2f ms/step  %.1f TFLOP/s" %
                       (v, c, t / steps, f / (t * 1e-3) / 1e12), file=sys.stderr)
+            agg = collections.OrderedDict()
+            for v, f, a, b, sig, _ in klog:
+                if sig is None:
+                    continue
+                d = agg.setdefault((v, sig), [0.0, 0.0, 0])
+                d[0] += f
+                d[1] += a.elapsed_time(b)
+                d[2] += 1
+            for (v, sig), (f, t, c) in agg.items():
+                print("%s M%-5d K%-5d %3dx%-3d launches %3d avg %.3f ms  %.1f TFLOP/s" %
+                      ((v,) + tuple(sig) + (c, t / c, f / (t * 1e-3) / 1e12)), file=sys.stderr)
         else:
             agg = collections.OrderedDict()
             for v, f, a, b, sig, _ in klog:

@@ -250,8 +250,8 @@ class UNetEngineBF16:
         e1.record()
         self.region_log.append((name, e0, e1))
 
-    def _log(self, name: str, flops: float):
-        """bench hook: returns a closer that records (name, flops, start, end)."""
+    def _log(self, name: str, flops: float, sig=None):
+        """bench hook: returns a closer that records (name, flops, start, end, shape signature)."""
         if self.kernel_log is None:
             return lambda: None
         e0 = torch.cuda.Event(enable_timing=True)
@@ -260,7 +260,7 @@ class UNetEngineBF16:
         def close():
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.kernel_log.append((name, flops, e0, e1, None))
+            self.kernel_log.append((name, flops, e0, e1, sig))
         return close
 
     def _run_unit(self, u: _Unit, src: Tuple[torch.Tensor, int, int], P, train: bool, st: int,
@@ -287,7 +287,7 @@ class UNetEngineBF16:
                                                   u.shift.data_ptr(), st), "conv1x1_bnrelu")
             else:
                 self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
-                done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+                done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw, (u.cout, u.cin, lh, lw))
                 check(lib.gsd_bf16_conv3x3_bnrelu(C.byref(din), u.wt_f.data_ptr(), C.byref(u.a), u.cin, u.cout, u.scale.data_ptr(),
                                                   u.shift.data_ptr(), st), "conv3x3_bnrelu")
                 done()
@@ -307,7 +307,7 @@ class UNetEngineBF16:
             done()
         elif self._use_c64(u.cin, u.cout):
             self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
-            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw, (u.cout, u.cin, lh, lw))
             check(lib.gsd_bf16_conv3x3_c64(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), part, None, st), "conv3x3_c64")
             done()
             self._finalize_stats(u, lib.gsd_bf16_conv3x3_c64_partial_rows(n, lh, lw), float(n * lh * lw), P, st)
@@ -315,7 +315,7 @@ class UNetEngineBF16:
             return
         else:
             self._wimage(0, P[u.wname], u.cout, u.cin, u.wt_f, st)
-            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+            done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw, (u.cout, u.cin, lh, lw))
             check(lib.gsd_bf16_conv3x3(C.byref(din), u.wt_f.data_ptr(), C.byref(dy), u.cin, u.cout, part, None, st), "conv3x3")
             done()
         rows = (lib.gsd_bf16_conv3x3_first_partial_rows(n, lh, lw, u.cout) if (u.first and self.first_direct)
@@ -630,7 +630,7 @@ class UNetEngineBF16:
         bw = keep = None
         if fuse is not None:
             bw, keep = self._bnbwd(fuse)
-        done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw)
+        done = self._log("bf16_conv3x3", 2.0 * u.cout * u.cin * 9 * n * lh * lw, (u.cout, u.cin, lh, lw))
         part = self.partials.data_ptr() if bw is not None else (stats_to.data_ptr() if stats_to is not None else None)
         if self._use_c64(u.cout, u.cin):
             check(lib.gsd_bf16_conv3x3_c64(C.byref(din), u.wt_d.data_ptr(), C.byref(dout), part, C.byref(bw) if bw is not None else None, st),
