@@ -1,0 +1,1029 @@
+// DIAGNOSTIC, NOT PRODUCT (round 5; not compiled by gelslim_depth_amd/build.py): gsd_conv3x3_w2d.hip with a fourth template parameter
+// WM = 4 -- "one wave per SIMD": four waves of 64 channels x 128 pixels, 384 accumulator registers per lane (256 AGPRs + 128 VGPRs,
+// the register class stated per accumulator through asm MFMAs), launched with GSD_W2D_WAVES=1.  Measured and rejected
+// (docs/LOG_r05.md section 5): correct in its first form (four MFMAs per asm statement: 169 op / layer-shape tests green), 27.6 ms
+// over the level 0-2 layer set against 22.2 for the product; the hand-pinned single-MFMA stream below is 26.3 ms and FAILS one
+// layer-shape test (not debugged).  Kept for the record of what the form looks like; profiles/ubench/mfma_f32_rate.hip is the
+// micro-benchmark that explains the result (profiles/r05_mfma_f32_issue_ubench.txt).
+// gsd_conv3x3_w2d.hip -- conv3x3 (pad 1, stride 1, no bias) forward and dX with the TWO-dimensional Winograd minimal-filtering
+// identity F(2 x 4, 3 x 3) on v_mfma_f32_16x16x4_f32 (gfx950): F(4,3) along the image rows (as gsd_conv3x3_w43.hip) combined
+// with F(2,3) down the columns.
+//
+// Same operator as gsd_conv3x3.hip / gsd_conv3x3_w43.hip (aten::convolution at /root/reference/gelslim_depth/models/unet.py:11,14
+// and the dX half of aten::convolution_backward), same fp32 storage and fp32 accumulation.  A tile of 2 x 4 outputs of one
+// channel needs a 4 x 6 input window and, per input channel, 4 x 6 = 24 products instead of 2 * 4 * 9 = 72:
+//
+//   Y (2x4) = A2^T [ (G2 g G4^T) .* (B2^T d B4) ] A4,     d = the 4 x 6 window, g = the 3 x 3 kernel
+//
+// a third of the direct form's multiplications and two thirds of the row-only form's (36 per 2 x 4 outputs).  The contraction
+// over the input channels stays on the MFMA: 24 GEMMs M_f[m][tile] = sum_ci U_f[ci][m] * V_f[ci][tile], f = (fr, fc).
+// F(2,3) is the mildest Winograd transform there is (constants 1 and 1/2): the op-level tests bound the combined form at the same
+// 1e-5 relative L1 against the fp64 oracle as the row-only form (north-star tolerance: 1e-3).
+//
+// Block = 4 waves on a 64-channel x 256-pixel tile, as the row-only kernel, but the waves split it 2 (channel halves) x 2 (pixel
+// halves): a wave owns 32 output channels x 16 tiles (128 pixels) = 2 MFMA m-tiles x 24 frequencies = 192 accumulator registers
+// (64 channels x 16 tiles would need 384), two blocks per CU.  Per 4-channel chunk a wave issues 24 k-steps x 2 MFMAs = 48 MFMAs for
+// 128 pixels where the row-only kernel issues 72 for 64.  The weight image of a chunk is 96 x 64 floats = 24 KiB (U = G2 g G4^T,
+// laid out once per optimiser step by gsd_weight_layout modes 8 / 9); the (TH + 2) x (TW + 2) halo window, the LDS-DMA fills, the
+// deferred BatchNorm + ReLU of the sources (NaN-sentinel padding), the two source segments (concat), the two cropped destinations,
+// the BatchNorm partial sums and the fused BatchNorm-backward dX epilogue are those of gsd_conv3x3_w43.hip (its straight-fill,
+// dword-gather form: every 4-channel chunk lies inside one source segment -- always true in the U-Net).
+#include "gsd_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+__device__ const float gsd_pad_w2d[2] = {0.f, __builtin_nanf("")};
+
+typedef float f32x4v __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+struct W2DParams {
+  SrcD src0, src1;
+  DstD dst0, dst1;
+  const float* wt;   // [mblocks][nchunks][4 ci][12 frequency pairs][2 channel halves][16][2 (f & 1)][2 m-tiles]: gsd_weight_layout modes 8 / 9
+  float* partials;   // [pixel tiles * NWP][2 * Mpad]: row (pixel tile, pixel group of the block)
+  const float* bw_raw;
+  const float* bw_scale;
+  const float* bw_shift;
+  const float* bw_mean;
+  const float* bw_invstd;
+  int Cin, Cout, Mpad, nchunks, mblocks;
+  int N, H, W;
+  int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
+  int NP, NI;   // X4: 16-byte pieces per window row (TW / 4 + 2), DMA instructions per channel plane
+};
+
+#ifndef W2D_PIPE   // 1: pin the interleave of a frequency row's MFMAs with the next row's transform (sched_group_barrier)
+#define W2D_PIPE 1
+#endif
+#ifndef W2D_ABL   // diagnostic builds only (profiles/build_diag_one.sh; results are then garbage): 1 no weight fills after a block's first,
+#define W2D_ABL 0 // 2 no halo fills after the first, 4 barrier without the wait for the fills, 8 no MFMAs, 16 no operand transform,
+                  // 32 no barrier (own fills only)
+#endif
+// WM = 4: the four MFMAs of a k-step (four m-tiles, one B operand) as ONE asm statement.  hipcc's MFMA selection puts every
+// accumulator of a function in AGPRs or every one in VGPRs; 384 accumulator registers need both files (256 AGPRs + 128 VGPRs), so the
+// register class is stated per accumulator ("+a" / "+v").  `s_nop 1`: the wait states between a VALU write of an operand and the
+// MFMA that reads it (nothing inside an asm string is padded by the compiler).  An accumulator is only read again by the MFMA
+// that takes it whole as C (no wait states) until the epilogue, which opens with the MFMA -> VALU wait states (w2d_mfma_drain).
+__device__ __forceinline__ void w2d_mfma4_aaaa(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, float a0, float a1, float a2, float a3, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\tv_mfma_f32_16x16x4_f32 %1, %5, %8, %1\n\t"
+               "v_mfma_f32_16x16x4_f32 %2, %6, %8, %2\n\tv_mfma_f32_16x16x4_f32 %3, %7, %8, %3"
+               : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));
+}
+__device__ __forceinline__ void w2d_mfma4_aaav(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, float a0, float a1, float a2, float a3, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\tv_mfma_f32_16x16x4_f32 %1, %5, %8, %1\n\t"
+               "v_mfma_f32_16x16x4_f32 %2, %6, %8, %2\n\tv_mfma_f32_16x16x4_f32 %3, %7, %8, %3"
+               : "+a"(c0), "+a"(c1), "+a"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));
+}
+__device__ __forceinline__ void w2d_mfma4_aavv(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, float a0, float a1, float a2, float a3, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\tv_mfma_f32_16x16x4_f32 %1, %5, %8, %1\n\t"
+               "v_mfma_f32_16x16x4_f32 %2, %6, %8, %2\n\tv_mfma_f32_16x16x4_f32 %3, %7, %8, %3"
+               : "+a"(c0), "+a"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));
+}
+__device__ __forceinline__ void w2d_mfma1_a(f32x4& c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void w2d_mfma1_v(f32x4& c, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void w2d_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+namespace {
+constexpr int W2D_BM = 64;
+constexpr int W2D_WTILE = 96 * W2D_BM;   // floats per weight chunk (24 KiB)
+}  // namespace
+
+// PLAIN: no source segment carries a deferred BatchNorm or ReLU (every dX launch; the pooled / up-sampled sources of the forward)
+// NWP: pixel groups of 16 tiles (128 pixels) per block.  2: four waves, 64 channels x 256 pixels, two blocks per CU.  4: eight
+// waves, 64 x 512 pixels, one block per CU -- the 24-KiB weight chunk then feeds twice the MFMAs: with a third of the direct
+// form's multiplications the L2 -> LDS fills (30 KiB per 192 MFMAs in the four-wave form) are what the kernel waits for.
+//
+// X4: the halo windows move as ALIGNED 16-byte pieces (global_load_lds_dwordx4) instead of dword gathers: a quarter of the halo's
+// DMA instructions (2 instead of 6 per channel plane of a 10 x 34 window), and the LDS-DMA issue -- 60-180 cycles an instruction --
+// is what this kernel waits for besides its MFMAs.  Possible when every source row starts 16-byte aligned and a piece lies wholly
+// inside or wholly outside a row: ONE plain source segment with a row pitch that is a multiple of 4 floats whose pad columns hold
+// zeros -- the row-pitched d_raw buffer every dX launch reads (gsd_bn_bwd_apply's out-of-place form).  A window row is the NP =
+// TW/4 + 2 pieces that cover image columns w0-4 .. w0+TW+3; the planes are shifted by ONE float in LDS so that image column w0-1
+// lands 16-byte aligned and the consumer reads stay one b128 + one b64 per window row.
+//
+// HM = 2 ("U4"): the same 16-byte pieces on the same w0-4 piece grid, straight from UNALIGNED rows -- any source (a
+// global_load_lds_dwordx4 takes any 4-byte aligned global address at full rate).  On that grid a piece never straddles the LEFT
+// image edge of a segment that starts at column 0; one that straddles a segment's right edge (W % 4 != 0: every level of the
+// U-Net) is loaded as it lies in memory -- the caller vouches for 4 readable floats around the tensor, gsd_src.slack -- and the
+// lane that moved it overwrites its outside floats with the padding value once its own fills have landed, in front of the chunk's
+// barrier (only lanes of blocks at that edge do anything).
+//
+// WM = 4 ("one wave per SIMD"): a wave owns all 64 channels of its 16 tiles -- 4 m-tiles x 24 frequencies = 384 accumulator registers
+// of the 512 a lone wave of a SIMD may hold -- and the block's four waves cover 512 pixels (NWP = 4): per MFMA half the weight-fill
+// bytes, half the halo reads and half the operand-transform instructions of the WM = 2 form (whose two channel halves each redo
+// the transform), at the price of no second wave to hide a wave's waits behind.
+template <bool PLAIN, int NWP, int HM = 0, int WM = 2>
+__global__ __launch_bounds__(WM == 4 ? 64 * NWP : 128 * NWP, WM == 4 ? 1 : 2) void conv3x3_w2d_kernel(const W2DParams P) {
+  constexpr bool X4 = HM == 1, U4 = HM == 2, PC = HM != 0;   // PC: the halo lies in LDS as 16-byte pieces
+  static_assert(WM == 2 || (WM == 4 && !U4), "m-tiles per wave: 2 or 4");
+  constexpr int W2D_NONE = -2147483647 - 1, W2D_PAD = -2147483647;   // lane offsets: no position / a padding position (prefilled)
+  static_assert(!X4 || PLAIN, "aligned 16-byte halo pieces: a plain, row-pitched source");
+  constexpr int BM = W2D_BM, WTILE = W2D_WTILE, NW = WM == 4 ? NWP : 2 * NWP, NT = 64 * NW;
+  constexpr int NPP = 4 * NWP / NW;   // 64-lane position groups (dword gathers) / fill units (16-byte pieces) per wave: 4 NWP in all
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PS = P.PS;
+  const int BUF = WTILE + 4 * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave8 % NWP, mh = WM == 4 ? 0 : wave8 / NWP;   // the wave's pixel group (16 of the block's 16 NWP tiles) and channel half
+  const int j = lane >> 4, l16 = lane & 15;
+
+  // the m-blocks of one pixel tile read the same halo: every XCD gets a contiguous range of logical ids (pixel tile major)
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int mbb = lid % P.mblocks;
+  const int pt = lid / P.mblocks;
+  const int m0 = mbb * BM;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = pt / tpi;
+  const int rt = pt - n * tpi;
+  const int ty = rt / P.tiles_x;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+
+  // ---- this lane's Winograd tile: 2 x 4 pixels (rows 2*tr2, 2*tr2+1; columns 4*tq .. 4*tq+3) of the block's TH x TW tile ------
+  const int q = ph * 16 + l16;
+  const bool q_ok = q < (P.TH >> 1) * P.TWq && q < 16 * NWP;
+  const int tr2 = q_ok ? q / P.TWq : 0;
+  const int tq = q_ok ? q - tr2 * P.TWq : 0;
+  const int baddr = WTILE + j * PS + (2 * tr2) * P.WCp + 4 * tq + (PC ? 4 : 0);   // halo columns 4*tq .. 4*tq+5 of halo rows 2*tr2 .. 2*tr2+3
+  int vmask = 0;   // bits 0..3: pixels of the tile's first row that exist in the image, bits 4..7: of its second row
+  if (q_ok) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      if (h0 + 2 * tr2 + a < P.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (w0 + 4 * tq + i < P.W) vmask |= 1 << (4 * a + i);
+      }
+  }
+
+  // ---- halo DMA lane geometry: the block's waves cover the (up to) 128 NW window positions once, dword gathers --------------------
+  int xo0[NPP], xo1[NPP];
+  bool p_on[NPP];
+  int pmask = 0;   // U4: floats of this lane's pieces that lie outside their row (bits 4 pp .. 4 pp + 3: first segment, + 8: second)
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) {
+    xo0[pp] = xo1[pp] = W2D_NONE;
+    if constexpr (PC) {
+      // unit u = (channel plane u / NI, instruction u % NI) of the chunk: its 64 lanes are 64 consecutive pieces of the plane
+      const int u = wave8 + NW * pp;
+      p_on[pp] = u < 4 * P.NI;
+      const int piece = (u % P.NI) * 64 + lane;
+      const int rr = piece / P.NP, pc = piece - rr * P.NP;
+      if (rr < P.WR) {
+        const int gh = h0 - 1 + rr, gw = w0 - 4 + 4 * pc;
+        if constexpr (X4) {
+          xo0[pp] = ((unsigned)gh < (unsigned)P.src0.H && gw >= 0 && gw + 4 <= P.src0.ws) ? gh * P.src0.ws + gw : W2D_PAD;
+        } else {
+          int hs = gh - P.src0.oh, c0 = gw - P.src0.ow;
+          xo0[pp] = W2D_PAD;
+          if ((unsigned)hs < (unsigned)P.src0.H && c0 + 3 >= 0 && c0 < P.src0.W) {
+            xo0[pp] = hs * P.src0.ws + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < 0 || c0 + e >= P.src0.W) pmask |= 1 << (4 * pp + e);
+          }
+          hs = gh - P.src1.oh;
+          c0 = gw - P.src1.ow;
+          xo1[pp] = W2D_PAD;
+          if (P.src1.C > 0 && (unsigned)hs < (unsigned)P.src1.H && c0 + 3 >= 0 && c0 < P.src1.W) {
+            xo1[pp] = hs * P.src1.ws + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < 0 || c0 + e >= P.src1.W) pmask |= 1 << (8 + 4 * pp + e);
+          }
+        }
+      }
+      continue;
+    }
+    p_on[pp] = wave8 + NW * pp < P.NPV;
+    const int pos = (wave8 + NW * pp) * 64 + lane;
+    const int rr = pos / P.WCp, cc = pos - rr * P.WCp;
+    if (rr < P.WR && cc < P.WC) {
+      const int gh = h0 - 1 + rr, gw = w0 - 1 + cc;
+      int hs = gh - P.src0.oh, ws = gw - P.src0.ow;
+      xo0[pp] = ((unsigned)hs < (unsigned)P.src0.H && (unsigned)ws < (unsigned)P.src0.W) ? hs * P.src0.ws + ws : W2D_PAD;
+      hs = gh - P.src1.oh;
+      ws = gw - P.src1.ow;
+      xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : W2D_PAD;
+    }
+  }
+  {
+    // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only); visible after the first barrier
+    const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+      if (p_on[pp] && xo0[pp] == W2D_PAD) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (PC) {   // the unit's own plane
+            const int u = wave8 + NW * pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) smem[b * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4 + e] = pad0;
+          } else {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) smem[b * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad0;
+          }
+        }
+      }
+  }
+  const float* d_base = P.src0.p + (long long)n * P.src0.ns;   // channel plane of the next halo slot
+  long long d_cs = P.src0.cs;
+  const int f_sw = P.src1.C > 0 ? P.src0.C / 4 : -1;           // first chunk of the second (concat) segment
+  // the current segment's lane offsets as 64-bit values (the address add is then a single instruction).  Four entries whatever NPP:
+  // the lambdas below capture it, and hipcc's host pass silently drops a kernel whose lambdas capture an array of dependent size
+  long long f_xl[4];
+#pragma unroll
+  for (int pp = 0; pp < NPP; ++pp) f_xl[pp] = xo0[pp];
+  // the switch to the second segment happens once per block, between two chunks: new plane pointer and lane offsets, and that
+  // segment's padding positions are written into each LDS image the first time it is filled from it
+  auto begin_fill = [&](int chunk, int buf) {
+    if (f_sw < 0 || (chunk != f_sw && chunk != f_sw + 1)) return;
+    if (chunk == f_sw) {
+      d_base = P.src1.p + (long long)n * P.src1.ns;
+      d_cs = P.src1.cs;
+#pragma unroll
+      for (int pp = 0; pp < NPP; ++pp) f_xl[pp] = xo1[pp];
+    }
+    const float pad1 = P.src1.relu ? __builtin_nanf("") : 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+      if (p_on[pp] && f_xl[pp] == W2D_PAD) {
+        if constexpr (PC) {
+          const int u = wave8 + NW * pp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) smem[buf * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4 + e] = pad1;
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) smem[buf * BUF + WTILE + ch * PS + (wave8 + NW * pp) * 64 + lane] = pad1;
+        }
+      }
+  };
+  auto halo_slot = [&](int ch, float* Xb) {   // input channel ch of the chunk: the lanes that have a pixel move it
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+      if (p_on[pp] && f_xl[pp] > W2D_PAD) __builtin_amdgcn_global_load_lds(d_base + f_xl[pp], Xb + ch * PS + (wave8 + NW * pp) * 64, 4, 0, 0);
+    d_base += d_cs;
+  };
+  // X4: unit pp of this wave (one instruction of one of the chunk's four planes); d_base stays at the chunk's first plane
+  auto halo_unit = [&](int pp, float* Xb) {
+    const int u = wave8 + NW * pp;
+    if (p_on[pp] && f_xl[pp] > W2D_PAD)
+      __builtin_amdgcn_global_load_lds(d_base + (u / P.NI) * d_cs + f_xl[pp], Xb + (u / P.NI) * PS + 1 + (u % P.NI) * 256, 16, 0, 0);
+    if (pp == NPP - 1) d_base += 4 * d_cs;
+  };
+  constexpr int WPW = 24 / NW;   // 1-KiB weight pieces per wave and chunk (6 or 3)
+  const float* const wsrc0 = P.wt + (size_t)mbb * P.nchunks * WTILE + wave8 * (WPW * 256) + lane * 4;
+  // the wave's pieces of the 24 are adjacent: they share LDS bases (M0) and differ in the instruction's immediate offset, which
+  // moves the global and the LDS address alike
+  auto weight_fill = [&](int chunk, float* Wn) {
+    const float* wg = wsrc0 + (size_t)chunk * WTILE;
+    float* wl = Wn + wave8 * (WPW * 256);
+    __builtin_amdgcn_global_load_lds(wg, wl, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(wg, wl, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(wg, wl, 16, 2048, 0);
+    if constexpr (WPW == 6) {
+      __builtin_amdgcn_global_load_lds(wg, wl, 16, 3072, 0);
+      __builtin_amdgcn_global_load_lds(wg + 1024, wl + 1024, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(wg + 1024, wl + 1024, 16, 1024, 0);
+    }
+  };
+
+  auto weight_piece = [&](int chunk, float* Wn, int i) {   // piece i of the wave's WPW (i is a constant after unrolling)
+    const float* wg = wsrc0 + (size_t)chunk * WTILE;
+    float* wl = Wn + wave8 * (WPW * 256);
+    if (i == 0) __builtin_amdgcn_global_load_lds(wg, wl, 16, 0, 0);
+    if (i == 1) __builtin_amdgcn_global_load_lds(wg, wl, 16, 1024, 0);
+    if (i == 2) __builtin_amdgcn_global_load_lds(wg, wl, 16, 2048, 0);
+    if (i == 3) __builtin_amdgcn_global_load_lds(wg, wl, 16, 3072, 0);
+    if (i == 4) __builtin_amdgcn_global_load_lds(wg + 1024, wl + 1024, 16, 0, 0);
+    if (i == 5) __builtin_amdgcn_global_load_lds(wg + 1024, wl + 1024, 16, 1024, 0);
+  };
+  auto halo_slot_one = [&](int ch, int pp, float* Xb) {   // position group pp of input channel ch (halo_slot, one instruction)
+    if (p_on[pp] && f_xl[pp] > W2D_PAD) __builtin_amdgcn_global_load_lds(d_base + f_xl[pp], Xb + ch * PS + (wave8 + NW * pp) * 64, 4, 0, 0);
+    if (pp == NPP - 1) d_base += d_cs;
+  };
+
+  const int Kpad = P.nchunks * 4;
+  float* sAff = smem + 2 * BUF;
+  for (int c = tid; c < Kpad; c += NT) {
+    const bool first = c < P.src0.C;
+    const SrcD& S = first ? P.src0 : P.src1;
+    const int cc = first ? c : c - P.src0.C;
+    float sc = 1.f, sh = 0.f;
+    if (c < P.Cin && cc < S.C && S.scale != nullptr) {
+      sc = S.scale[cc];
+      sh = S.shift[cc];
+    }
+    sAff[c] = sc;
+    sAff[Kpad + c] = sh;
+  }
+  float* sBw = sAff + 2 * Kpad;   // [4][64]: scale, shift, mean, invstd of the fused BatchNorm-backward epilogue
+  if (P.bw_raw != nullptr) {
+    for (int c = tid; c < BM; c += NT) {
+      const int co = m0 + c < P.Cout ? m0 + c : 0;
+      sBw[c] = P.bw_scale[co];
+      sBw[BM + c] = P.bw_shift[co];
+      sBw[2 * BM + c] = P.bw_mean[co];
+      sBw[3 * BM + c] = P.bw_invstd[co];
+    }
+  }
+  const float lo0 = P.src0.relu ? 0.f : -__builtin_inff(), lo1 = P.src1.relu ? 0.f : -__builtin_inff();
+
+  f32x4 acc[WM][24];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int f = 0; f < 24; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // V row = B4^T t of one frequency row: the 6 values of a (column-transformed) window row -> the 6 row frequencies
+  auto row_transform = [&](const float (&d)[6], float (&v)[6]) {
+    const float a = fmaf(-4.f, d[2], d[4]), b = fmaf(-4.f, d[1], d[3]);
+    const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    v[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+    v[1] = a + b;
+    v[2] = a - b;
+    v[3] = c + e;
+    v[4] = c - e;
+    v[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+  };
+
+  const int a_lane = mh * 64 + l16 * 4;   // this wave's (f, f+1) x two m-tiles of a frequency pair: 16 lanes read 256 contiguous bytes
+  begin_fill(0, 0);
+  weight_fill(0, smem);
+  if constexpr (PC) {
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp) halo_unit(pp, smem + WTILE);
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) halo_slot(ch, smem + WTILE);
+  }
+
+  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    if constexpr (U4) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the chunk have landed
+      // the outside floats of the straddling pieces this lane moved (the lane state still is the one the chunk was filled with)
+      const bool seg1 = f_sw >= 0 && chunk >= f_sw;
+      const int pm = seg1 ? pmask >> 8 : pmask & 0xff;
+      if (pm != 0) {
+        const float padv = (seg1 ? P.src1.relu : P.src0.relu) ? __builtin_nanf("") : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int u = wave8 + NW * pp;
+          float* pq = smem + cur * BUF + WTILE + (u / P.NI) * PS + 1 + (u % P.NI) * 256 + lane * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (pm >> (4 * pp + e) & 1) pq[e] = padv;
+        }
+      }
+      __syncthreads();
+    } else if ((W2D_ABL) & 32) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // diagnostic: own fills only, no barrier at all (racy: what the barrier itself costs)
+    } else if ((W2D_ABL) & 4) {
+      __syncthreads();
+    } else {
+      gsd_dma_barrier();   // the chunk's fills have landed; everyone has left the other image
+    }
+    const int kc = chunk * 4 + j;
+    float sc = 1.f, sh = 0.f, lo = 0.f;
+    if constexpr (!PLAIN) {
+      sc = sAff[kc], sh = sAff[Kpad + kc];
+      lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
+    }
+    const bool more = chunk + 1 < P.nchunks;
+    const float* Wc = smem + cur * BUF;
+    float d[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 ra = *reinterpret_cast<const f32x4*>(&Wc[baddr + i * P.WCp]);
+      const f32x2v rb = *reinterpret_cast<const f32x2v*>(&Wc[baddr + i * P.WCp + 4]);
+      d[i][0] = ra[0], d[i][1] = ra[1], d[i][2] = ra[2], d[i][3] = ra[3], d[i][4] = rb[0], d[i][5] = rb[1];
+    }
+    // A operands: one ds_read_b128 = this wave's two m-tiles of TWO consecutive frequencies (the weight image pairs them), read one
+    // pair (four MFMAs) ahead
+    f32x4 av[2][WM / 2];   // [pair buffer][channel half]
+#pragma unroll
+    for (int hh = 0; hh < WM / 2; ++hh) av[0][hh] = *reinterpret_cast<const f32x4*>(&Wc[(j * 12) * 128 + a_lane + 64 * hh]);
+    if constexpr (!PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[i][c] = fmaxf(fmaf(d[i][c], sc, sh), lo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // frequency rows in the order that retires window rows early: t0 = d0 - d2, t3 = d1 - d3, t1 = d1 + d2, t2 = d2 - d1.
+    // Software pipeline over the rows: the operand transform of row fi + 1 (about 19 vector instructions) is issued between the
+    // 12 MFMAs of row fi -- an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, three vector instructions fit its shadow.
+    constexpr int FR[4] = {0, 3, 1, 2};
+    auto freq_row = [&](int fr, float (&v)[6]) {
+      float t[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        t[c] = fr == 0 ? d[0][c] - d[2][c] : fr == 3 ? d[1][c] - d[3][c] : fr == 1 ? d[1][c] + d[2][c] : d[2][c] - d[1][c];
+#if (W2D_ABL) & 16
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] = t[c];
+#else
+      row_transform(t, v);
+#endif
+    };
+    float v[2][6];
+    freq_row(FR[0], v[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WM == 4) {
+      // one wave per SIMD: nothing overlaps this wave's work but itself, it issues in order, and the asm MFMAs are opaque to hipcc's
+      // scheduler -- so the stream is laid out by hand and pinned.  An MFMA holds the vector issue for 8 of its 32 cycles: each of
+      // the 96 gaps of a chunk takes at most {one A-operand read, one instruction of the next frequency row's operand transform,
+      // one LDS-DMA instruction of the next chunk's fills}.
+      float t[6], ta = 0.f, tb = 0.f, tc = 0.f, te = 0.f;
+      auto tr_piece = [&](int k, int fq, float(&vn)[6]) {   // k, fq: constants after unrolling
+        if (k < 6) t[k] = fq == 0 ? d[0][k] - d[2][k] : fq == 3 ? d[1][k] - d[3][k] : fq == 1 ? d[1][k] + d[2][k] : d[2][k] - d[1][k];
+        if (k == 6) ta = fmaf(-4.f, t[2], t[4]);
+        if (k == 7) tb = fmaf(-4.f, t[1], t[3]);
+        if (k == 8) tc = t[4] - t[2];
+        if (k == 9) te = 2.f * (t[3] - t[1]);
+        if (k == 10) vn[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));
+        if (k == 11) vn[1] = ta + tb;
+        if (k == 12) vn[2] = ta - tb;
+        if (k == 13) vn[3] = tc + te;
+        if (k == 14) vn[4] = tc - te;
+        if (k == 15) vn[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
+      };
+      auto fill_piece = [&](int k) {   // the k-th LDS-DMA instruction of this wave's share of the next chunk's fills
+        float* Wn = smem + (cur ^ 1) * BUF;
+        if (k == 0) begin_fill(chunk + 1, cur ^ 1);
+        if (k < WPW) {
+          if (!((W2D_ABL) & 1)) weight_piece(chunk + 1, Wn, k);
+        } else if (!((W2D_ABL) & 2)) {
+          const int q = k - WPW;
+          if constexpr (PC) {
+            if (q < NPP) halo_unit(q, Wn + WTILE);
+          } else {
+            if (q < 4 * NPP) halo_slot_one(q / NPP, q % NPP, Wn + WTILE);
+          }
+        }
+      };
+      asm volatile("s_nop 1");   // the first row's operands were written just now
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi) {
+        const int fr = FR[fi];
+        float(&vn)[6] = v[(fi + 1) & 1];
+#pragma unroll
+        for (int fc = 0; fc < 6; ++fc) {
+          const int s = fi * 6 + fc, f = fr * 6 + fc;
+          const int o = (s & 1) * 2;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float a = av[(s >> 1) & 1][m >> 1][o + (m & 1)];
+            // accumulators of m-tile 3, and of m-tile 2 for the first 8 frequencies, live in VGPRs (128 registers), the others in AGPRs
+#if (W2D_ABL) & 8
+            acc[m][f][0] += a * v[fi & 1][fc];
+#elif (W2D_ABL) & 64   // every accumulator in an AGPR quad that exists (diagnostic: what the VGPR-resident accumulators cost)
+            w2d_mfma1_a(acc[m & 1][f], a, v[fi & 1][fc]);
+#else
+            if (m == 3 || (m == 2 && f < 8)) w2d_mfma1_v(acc[m][f], a, v[fi & 1][fc]);
+            else w2d_mfma1_a(acc[m][f], a, v[fi & 1][fc]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // the A operands of the k-step pair after this one, BEHIND the pair's first MFMAs: hipcc waits for every outstanding LDS
+            // read (lgkmcnt(0)) in front of an asm statement that takes a loaded register
+            if ((s & 1) == 0 && s + 2 < 24 && m < 2) {
+              const int fn = FR[(s + 2) / 6] * 6 + (s + 2) % 6;
+              av[((s >> 1) + 1) & 1][m] = *reinterpret_cast<const f32x4*>(&Wc[(j * 12 + (fn >> 1)) * 128 + a_lane + 64 * m]);
+            }
+            if (fi + 1 < 4 && fc < 4) tr_piece(fc * 4 + m, FR[fi + 1], vn);
+            if (more && s * 4 + m >= 1) fill_piece(s * 4 + m - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+      const int fr = FR[fi];
+      if (fi + 1 < 4) freq_row(FR[fi + 1], v[(fi + 1) & 1]);
+#pragma unroll
+      for (int fc = 0; fc < 6; ++fc) {
+        const int s = fi * 6 + fc, f = fr * 6 + fc;
+        if ((s & 1) == 0 && s + 2 < 24) {
+          const int fn = FR[(s + 2) / 6] * 6 + (s + 2) % 6;
+#pragma unroll
+          for (int hh = 0; hh < WM / 2; ++hh)
+            av[((s >> 1) + 1) & 1][hh] = *reinterpret_cast<const f32x4*>(&Wc[(j * 12 + (fn >> 1)) * 128 + a_lane + 64 * hh]);
+        }
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          const float a = av[(s >> 1) & 1][m >> 1][(s & 1) * 2 + (m & 1)];
+#if (W2D_ABL) & 8
+          acc[m][f][0] += a * v[fi & 1][fc];
+#else
+          acc[m][f] = mfma16(a, v[fi & 1][fc], acc[m][f]);
+#endif
+        }
+        // the next chunk's fills ride in the first k-steps: the weights in one k-step (shared LDS bases), then the halo
+        if (more && s < 1 + (PC ? NPP : 2)) {
+          float* Wn = smem + (cur ^ 1) * BUF;
+          if (s == 0) {
+            begin_fill(chunk + 1, cur ^ 1);
+            if (!((W2D_ABL) & 1)) weight_fill(chunk + 1, Wn);
+          } else if (!((W2D_ABL) & 2)) {
+            if constexpr (PC) {
+              halo_unit(s - 1, Wn + WTILE);
+            } else {
+              halo_slot(2 * s - 2, Wn + WTILE);
+              halo_slot(2 * s - 1, Wn + WTILE);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#if W2D_PIPE
+      if (fi > 0 || !more) {   // (row 0 carries the fills: its k-steps are pinned above)
+#if W2D_PIPE == 2   // the next row's whole transform in ONE gap (a vector instruction in an MFMA gap costs ~12 cycles, each further one 4)
+        __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, WM / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
+#pragma unroll
+        for (int g = 1; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, WM / 2, 0);
+        }
+#else
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, WM, 0);       // the k-step's MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, WM / 2, 0);   // at most one LDS read per channel half
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four vector instructions of the next row's transform
+        }
+#endif
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if constexpr (WM == 4) {
+    __builtin_amdgcn_sched_barrier(0);
+    w2d_mfma_drain();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- epilogue: Y = A2^T M A4, NCHW stores (two destination segments with crop), BatchNorm partial sums -------------------------
+  // per destination and tile row: element offset of the row's first pixel inside a plane, and the mask of its pixels that are stored
+  int off0[2] = {0, 0}, off1[2] = {0, 0}, sm0[2] = {0, 0}, sm1[2] = {0, 0};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int h = h0 + 2 * tr2 + a, w = w0 + 4 * tq;
+    const int vm = (vmask >> (4 * a)) & 15;
+    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
+    if ((unsigned)hd < (unsigned)P.dst0.H) {
+      off0[a] = hd * P.dst0.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0[a] |= 1 << i;
+    }
+    hd = h - P.dst1.oh;
+    wd = w - P.dst1.ow;
+    if ((unsigned)hd < (unsigned)P.dst1.H) {
+      off1[a] = hd * P.dst1.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1[a] |= 1 << i;
+    }
+  }
+  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
+  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * NWP + ph) * (2 * P.Mpad) : nullptr;
+
+  // Y = A2^T M A4 of one channel's tile: down the columns first (24 -> 12 values), then along the rows (12 -> 2 x 4 outputs)
+  auto out_transform = [&](int m, int reg, float (&y)[2][4]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float R[6];
+#pragma unroll
+      for (int fc = 0; fc < 6; ++fc) {
+        const float M1 = acc[m][6 + fc][reg], M2 = acc[m][12 + fc][reg];
+        R[fc] = a == 0 ? acc[m][fc][reg] + M1 + M2 : M1 - M2 - acc[m][18 + fc][reg];
+      }
+      const float p12 = R[1] + R[2], m12 = R[1] - R[2], p34 = R[3] + R[4], m34 = R[3] - R[4];
+      y[a][0] = R[0] + p12 + p34;
+      y[a][1] = fmaf(2.f, m34, m12);
+      y[a][2] = fmaf(4.f, p34, p12);
+      y[a][3] = fmaf(8.f, m34, m12) + R[5];
+    }
+  };
+
+  if (P.bw_raw == nullptr) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
+        const bool first = co < P.dst0.C;
+        const int cd = first ? co : co - P.dst0.C;
+        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+        float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
+        float y[2][4];
+        out_transform(m, reg, y);
+        // statistics over the pixels that are STORED (for a cropped second destination -- the backward of F.pad -- the sums are
+        // those of the crop, e.g. the ConvT bias gradient)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int sm = co_ok ? (first ? sm0[a] : sm1[a]) : 0;
+          float* const px = plane + (first ? off0[a] : off1[a]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (sm >> i & 1) {
+              s1 += y[a][i];
+              s2 = fmaf(y[a][i], y[a][i], s2);
+            }
+          }
+          if (sm == 15) {
+            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (sm >> i & 1) px[i] = y[a][i];
+          }
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  } else {
+    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
+        const long long cplane = (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs;
+        float xr[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float* const rp = P.bw_raw + cplane + off0[a];
+          if (sm0[a] == 15) {
+            const f32x4 t = *reinterpret_cast<const f32x4v*>(rp);
+            xr[a][0] = t[0], xr[a][1] = t[1], xr[a][2] = t[2], xr[a][3] = t[3];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[a][i] = (sm0[a] >> i & 1) ? rp[i] : 0.f;
+          }
+        }
+        const int cl = mh * 32 + m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        float y[2][4];
+        out_transform(m, reg, y);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int sm = co < P.Cout ? sm0[a] : 0;
+          float* const px = d0 + (long long)co * P.dst0.cs + off0[a];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x = xr[a][i];
+            const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[a][i] : 0.f;
+            y[a][i] = dz;
+            s1 += dz;
+            s2 = fmaf(dz, (x - bmu) * bis, s2);
+          }
+          if (sm == 15) {
+            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (sm >> i & 1) px[i] = y[a][i];
+          }
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct W2DPlan {
+  int TH, TW, TWq, tiles_y, tiles_x, mblocks, WR, WC, WCp, PS, nwp, wm;   // wm: m-tiles per wave (2, or 4: one wave per SIMD)
+};
+
+// LDS bank cost of the consumers' halo reads (one ds_read_b128 + one ds_read_b64 per window row; a lane's tile rows are 2 apart):
+// sum over the two pixel halves of the LDS cycles per read pair.
+int w2d_read_cycles(int TWq, int LP, int PS, int nwp) {
+  static const int g128[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  int total = 0;
+  for (int ph = 0; ph < nwp; ++ph) {
+    int addr[64];
+    for (int lane = 0; lane < 64; ++lane) {
+      const int q = ph * 16 + (lane & 15);
+      addr[lane] = (lane >> 4) * PS + 2 * (q / TWq) * LP + 4 * (q % TWq);
+    }
+    for (int half = 0; half < 2; ++half) {
+      for (int g = 0; g < 2; ++g) {   // ds_read_b128: 16-lane groups, 16 slots of 16 B
+        int worst = 0;
+        for (int slot = 0; slot < 16; ++slot) {
+          int distinct = 0, seen[16];
+          for (int i = 0; i < 16; ++i) {
+            const int a = addr[g128[g][i] + 32 * half];
+            if ((a / 4) % 16 != slot) continue;
+            bool dup = false;
+            for (int k = 0; k < distinct; ++k) dup = dup || seen[k] == a;
+            if (!dup) seen[distinct++] = a;
+          }
+          worst = distinct > worst ? distinct : worst;
+        }
+        total += worst;
+      }
+      int worst = 0;   // ds_read_b64 at +4 floats: 32-lane halves, 32 slots of 8 B
+      for (int slot = 0; slot < 32; ++slot) {
+        int distinct = 0, seen[32];
+        for (int i = 0; i < 32; ++i) {
+          const int a = addr[i + 32 * half] + 4;
+          if ((a / 2) % 32 != slot) continue;
+          bool dup = false;
+          for (int k = 0; k < distinct; ++k) dup = dup || seen[k] == a;
+          if (!dup) seen[distinct++] = a;
+        }
+        worst = distinct > worst ? distinct : worst;
+      }
+      total += worst;
+    }
+  }
+  return total;
+}
+
+// TH x TW output tile of 16 nwp two-row Winograd tiles (256 or 512 pixels) whose padded halo window fits the 128 NW DMA positions:
+// fewest blocks; among equals 32-wide rows, then the widest.  The LDS row pitch and plane stride are the ones with the fewest
+// bank conflicts.  GSD_W2D_WAVES = 4 | 8 (tuning): the four-wave (two blocks per CU) or the eight-wave block.
+bool plan_w2d(int N, int H, int W, int M, W2DPlan* best) {
+  long best_cost = -1;
+  const int force_tw = gsd_env_int("GSD_W2D_TW", 0);   // tuning
+  // GSD_W2D_WAVES: 4 (two four-wave blocks per CU), 8 (one eight-wave block; measured slower: profiles/r05_w2d_vs_w43.txt),
+  // 1 (one wave per SIMD: four waves of 64 channels x 128 pixels)
+  const int waves = gsd_env_int("GSD_W2D_WAVES", 4);
+  const int nwp = waves == 4 ? 2 : 4;
+  best->nwp = nwp;
+  best->wm = waves == 1 ? 4 : 2;
+  const int maxpos = 256 * nwp;
+  static const int tws[4] = {32, 64, 16, 8};
+  for (int k = 0; k < 4; ++k) {
+    const int tw = tws[k];
+    if (force_tw && tw != force_tw) continue;
+    const int twq = tw / 4;
+    int th = 2 * (16 * nwp / twq);
+    const int wcp0 = round_up(tw + 2, 4);
+    if ((th + 2) * wcp0 > maxpos) continue;
+    const int ty = ceil_div(H, th);
+    th = round_up(ceil_div(H, ty), 2);
+    const long blocks = (long)ty * ceil_div(W, tw) * N;
+    // 8-pixel rows (32 x 8 tiles) save a few blocks on 213-pixel rows (135 against 140 per image) but their halo is 34 rows of 40
+    // bytes -- and too many pieces for the 16-byte fills: they have to save GSD_W2D_TW8_PCT percent (default 8) to be taken
+    // (measured: step 97.35 -> 96.66 ms; 8 x 32 instead of 16 x 16 tiles at 320 x 427, 560 against 540 per image: +0.2 ms, not taken)
+    const long cost = (blocks * 8 + (tw == 32 ? 0 : tw == 64 ? 1 : tw == 16 ? 2 : 3)) * (tw == 8 ? 100 + gsd_env_int("GSD_W2D_TW8_PCT", 8) : 100);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best->TH = th; best->TW = tw; best->TWq = twq;
+      best->tiles_y = ty; best->tiles_x = ceil_div(W, tw);
+      best->WR = th + 2; best->WC = tw + 2;
+    }
+  }
+  best->mblocks = ceil_div(M, W2D_BM);
+  if (best_cost < 0) return false;
+  // LDS row pitch and plane stride of the chosen tile: a search over 36 candidates of ~10^5 operations each, i.e. a fraction of a
+  // millisecond of HOST time -- per (tile, block form) it is done once and remembered (an idempotent cache like cu_count(): every
+  // thread computes the same value, the key is published last)
+  struct Memo { std::atomic<int> key{0}; int wcp = 0, ps = 0; };
+  static Memo memo[16];
+  const int th = best->TH, tw = best->TW, key = (th << 16) | (tw << 4) | nwp;
+  Memo& mm = memo[(th * 7 + tw + nwp) & 15];
+  if (mm.key.load(std::memory_order_acquire) == key) {
+    best->WCp = mm.wcp;
+    best->PS = mm.ps;
+    return true;
+  }
+  const int wcp0 = round_up(tw + 2, 4);
+  int bc = -1;
+  for (int c = wcp0; c <= wcp0 + 12 && (th + 2) * c <= maxpos; c += 4)
+    for (int ps = round_up((th + 2) * c, 4) + 4; ps < round_up((th + 2) * c, 4) + 4 + 36; ps += 4) {
+      const int cyc = w2d_read_cycles(best->TWq, c, ps, nwp);
+      if (bc < 0 || cyc < bc) {
+        bc = cyc;
+        best->WCp = c;
+        best->PS = ps;
+      }
+    }
+  if (mm.key.exchange(0, std::memory_order_acq_rel) == 0) {   // (a concurrent writer of another key simply loses its slot)
+    mm.wcp = best->WCp;
+    mm.ps = best->PS;
+    mm.key.store(key, std::memory_order_release);
+  }
+  return true;
+}
+
+// X4: plane stride of the shifted planes (row pitch 4 NP floats) with the fewest bank conflicts of the consumers' reads
+int w2d_x4_plane_stride(int TWq, int WCp, int WR, int nwp) {
+  struct Memo { std::atomic<int> key{0}; int ps = 0; };
+  static Memo memo[8];
+  const int key = (TWq << 20) | (WCp << 8) | (WR << 1) | (nwp == 4);
+  Memo& mm = memo[(TWq + WR + nwp) & 7];
+  if (mm.key.load(std::memory_order_acquire) == key) return mm.ps;
+  int best = -1, ps_best = WR * WCp + 4;
+  for (int ps = WR * WCp + 4; ps < WR * WCp + 4 + 68; ps += 4) {
+    const int c = w2d_read_cycles(TWq, WCp, ps, nwp);
+    if (best < 0 || c < best) {
+      best = c;
+      ps_best = ps;
+    }
+  }
+  if (mm.key.exchange(0, std::memory_order_acq_rel) == 0) {
+    mm.ps = ps_best;
+    mm.key.store(key, std::memory_order_release);
+  }
+  return ps_best;
+}
+
+template <bool PLAIN, int NWP, int HM = 0, int WM = 2>
+int launch_w2d(const W2DParams& P, int grid, size_t lds, hipStream_t st) {
+  static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, HM, WM>);
+  if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
+    gsd_set_error("gsd_conv3x3_w2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return GSD_ERR_HIP;
+  }
+  GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: LDS image %zu B too large", lds);
+  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, HM, WM>), dim3(grid), dim3(WM == 4 ? 64 * NWP : 128 * NWP), lds, st, P);
+  GSD_LAUNCH_CHECK("gsd_conv3x3_w2d");
+  return GSD_OK;
+}
+
+}  // namespace
+
+// 1: the shape and its operands fit the two-dimensional form (every 4-channel chunk inside one source segment)
+extern "C" int gsd_conv3x3_w2d_supported(int Cin, int C0) {
+  return (Cin > 0 && Cin % 4 == 0 && C0 > 0 && C0 <= Cin && C0 % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int gsd_conv3x3_w2d_partial_rows(int N, int H, int W, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  W2DPlan p;
+  if (!plan_w2d(N, H, W, Cout, &p)) return 0;
+  return N * p.tiles_y * p.tiles_x * p.nwp;
+}
+
+// MFMA instructions of one launch (all blocks, padding included)
+extern "C" int64_t gsd_conv3x3_w2d_mfma_count(int N, int H, int W, int Cin, int Cout) {
+  W2DPlan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w2d(N, H, W, Cout, &p)) return 0;
+  return (int64_t)N * p.tiles_y * p.tiles_x * p.mblocks * ceil_div(Cin, 4) * (2 * p.nwp * 48);
+}
+
+// Modelled run time of the launch in microseconds, as gsd_conv3x3_w43_estimate_us: a CU with k = ceil(blocks / 256) blocks runs
+// pairs at 2.17 us per chunk and block (+ 5 us per block) and an odd last block at 0.66 of that (fitted to
+// profiles/r05_w2d_vs_w43.txt: the 20 x 26 and 40 x 53 layers at batch 8, where k is 1-3).
+extern "C" double gsd_conv3x3_w2d_estimate_us(int N, int H, int W, int Cin, int Cout) {
+  W2DPlan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w2d(N, H, W, Cout, &p)) return 0.0;
+  const long blocks = (long)N * p.tiles_y * p.tiles_x * p.mblocks;
+  const long k = (blocks + 255) / 256;
+  const double per = p.nwp == 2 ? 2.17 : 4.6;   // (the eight-wave block: one per CU, twice the pixels)
+  const double cu = p.nwp == 2 ? (double)(k / 2) + (k & 1 ? 0.66 : 0.0) : (double)k;
+  return cu * (per * ceil_div(Cin, 4) + 5.0);
+}
+
+extern "C" double gsd_conv3x3_w43_estimate_us(int N, int H, int W, int Cin, int Cout, int slabs);
+
+// 1: a caller that has both forms' weight layouts at hand should run this launch through gsd_conv3x3_w2d instead of
+// gsd_conv3x3_w43.  train == 0 (eval-mode inference): always -- the two-dimensional form neither folds rows across images nor
+// cuts K slabs, so image i of a batch gets the bits the image alone gets, whatever the batch.  train != 0: the modelled times
+// decide (the deep levels at small batches stay with the row form's K slabs).  GSD_CONV_W2D = 0 never, 1 always.
+extern "C" int gsd_conv3x3_prefers_w2d(int N, int H, int W, int Cin, int Cout, int train) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin < 16 || Cin % 4 != 0 || Cout <= 0) return 0;
+  const int forced = gsd_env_int("GSD_CONV_W2D", -1);
+  if (forced == 0 || forced == 1) return forced;
+  if (!train) return 1;
+  const double a = gsd_conv3x3_w2d_estimate_us(N, H, W, Cin, Cout), b = gsd_conv3x3_w43_estimate_us(N, H, W, Cin, Cout, 1);
+  return a > 0.0 && b > 0.0 && a < b ? 1 : 0;
+}
+
+static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst, float* partials,
+                    const float* bw_raw, const float* bw_scale, const float* bw_shift, const float* bw_mean, const float* bw_invstd,
+                    int N, int H, int W, void* stream) {
+  GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: null argument");
+  GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: nsrc/ndst must be 1 or 2");
+  GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: bad sizes");
+  GSD_REQUIRE(H < 32768 && W < 32768, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: H, W must be < 32768");
+  GSD_REQUIRE(((uintptr_t)wt & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: weight layout must be 16-byte aligned");
+  GSD_REQUIRE(gsd_conv3x3_w2d_supported(Cin, src[0].C), GSD_ERR_UNSUPPORTED,
+              "gsd_conv3x3_w2d: Cin=%d and the first segment's %d channels must be multiples of 4 (use gsd_conv3x3_w43)", Cin, src[0].C);
+  int csum = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (int e = gsd_check_src(src[i], "gsd_conv3x3_w2d src", true)) return e;
+    GSD_REQUIRE(src[i].scale == nullptr || src[i].relu != 0, GSD_ERR_UNSUPPORTED,
+                "gsd_conv3x3_w2d: an affine source segment must also have relu (zero padding uses a NaN sentinel)");
+    GSD_REQUIRE((int64_t)src[i].H * src[i].w_stride < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: plane too large");
+    csum += src[i].C;
+  }
+  GSD_REQUIRE(csum == Cin, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: source segments hold %d channels, Cin=%d", csum, Cin);
+  csum = 0;
+  for (int i = 0; i < ndst; ++i) {
+    if (int e = gsd_check_dst(dst[i], "gsd_conv3x3_w2d dst", true)) return e;
+    GSD_REQUIRE((int64_t)dst[i].H * dst[i].w_stride < (1LL << 31), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: plane too large");
+    csum += dst[i].C;
+  }
+  GSD_REQUIRE(csum == Cout, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: destination segments hold %d channels, Cout=%d", csum, Cout);
+
+  W2DPlan pl;
+  GSD_REQUIRE(plan_w2d(N, H, W, Cout, &pl), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: no tile shape");
+  W2DParams P;
+  P.src0 = to_srcd(src[0]);
+  P.src1 = nsrc > 1 ? to_srcd(src[1]) : null_srcd();
+  P.dst0 = to_dstd(dst[0]);
+  P.dst1 = ndst > 1 ? to_dstd(dst[1]) : null_dstd();
+  P.wt = wt;
+  P.partials = partials;
+  P.bw_raw = bw_raw; P.bw_scale = bw_scale; P.bw_shift = bw_shift; P.bw_mean = bw_mean; P.bw_invstd = bw_invstd;
+  P.Cin = Cin; P.Cout = Cout;
+  P.Mpad = round_up(Cout, 64);
+  P.nchunks = Cin / 4;
+  P.mblocks = pl.mblocks;
+  P.N = N; P.H = H; P.W = W;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWq = pl.TWq; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp; P.PS = pl.PS;
+  P.NPV = ceil_div(P.WR * P.WCp, 64);
+  GSD_REQUIRE(P.NPV <= 4 * pl.nwp, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: halo window too large");
+  const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
+  GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: grid too large");
+  bool plain = true;
+  for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
+  // 16-byte halo pieces: one plain source whose rows start 16-byte aligned (pitch, plane and image strides multiples of 4 floats);
+  // its pad columns must hold zeros -- the engine's row-pitched d_raw buffer does (GSD_W2D_X4=0: dword gathers, A/B runs)
+  P.NP = pl.TW / 4 + 2;
+  P.NI = ceil_div(P.WR * P.NP, 64);
+  const bool big = pl.wm == 4;
+  const bool x4 = plain && nsrc == 1 && (pl.nwp == 2 || big) && 4 * P.NI <= (big ? 16 : 8) && gsd_env_int("GSD_W2D_X4", 1) != 0 &&
+                  ((uintptr_t)src[0].ptr & 15) == 0 && src[0].w_stride % 4 == 0 && src[0].c_stride % 4 == 0 && src[0].n_stride % 4 == 0 &&
+                  src[0].off_h == 0 && src[0].off_w == 0 && src[0].w_stride >= round_up(src[0].W, 4);
+  // unaligned 16-byte pieces for every other source: each segment vouches for 4 readable floats around its tensor (slack), lane
+  // offsets stay 32-bit.  GSD_W2D_U4=1 selects it; default 0: measured neutral over the train step (97.7-97.9 ms either way,
+  // bit-identical) -- the aligned form's gain on the dX launches does not carry over to unaligned rows with the patch step
+  bool u4 = !x4 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_U4", 0) != 0;   // (not with one wave per SIMD)
+  for (int i = 0; i < nsrc && u4; ++i) u4 = src[i].slack >= 4;
+  if (x4 || u4) {
+    P.WCp = 4 * P.NP;
+    P.PS = w2d_x4_plane_stride(pl.TWq, P.WCp, P.WR, pl.nwp);
+  }
+  const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
+  if (gsd_env_set("GSD_W2D_TRACE"))
+    fprintf(stderr, "w2d M%d K%d %dx%d N%d nsrc %d ndst %d plain %d x4 %d u4 %d | ptr&15 %d ws %d cs%%4 %d ns%%4 %d NI %d tile %dx%d wm %d\n", Cout, Cin, H, W, N,
+            nsrc, ndst, (int)plain, (int)x4, (int)u4, (int)((uintptr_t)src[0].ptr & 15), src[0].w_stride, (int)(src[0].c_stride % 4),
+            (int)(src[0].n_stride % 4), P.NI, pl.TH, pl.TW, pl.wm);
+  if (big) {
+    if (x4) return launch_w2d<true, 4, 1, 4>(P, (int)grid, lds, (hipStream_t)stream);
+    return plain ? launch_w2d<true, 4, 0, 4>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 4, 0, 4>(P, (int)grid, lds, (hipStream_t)stream);
+  }
+  if (x4) return launch_w2d<true, 2, 1>(P, (int)grid, lds, (hipStream_t)stream);
+  if (u4) return plain ? launch_w2d<true, 2, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 2>(P, (int)grid, lds, (hipStream_t)stream);
+  if (pl.nwp == 2)
+    return plain ? launch_w2d<true, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2>(P, (int)grid, lds, (hipStream_t)stream);
+  return plain ? launch_w2d<true, 4>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 4>(P, (int)grid, lds, (hipStream_t)stream);
+}
+
+extern "C" int gsd_conv3x3_w2d(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                               float* partials, int N, int H, int W, void* stream) {
+  return w2d_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, stream);
+}
+
+extern "C" int gsd_conv3x3_w2d_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                            const float* raw, const float* scale, const float* shift, const float* mean,
+                                            const float* invstd, float* partials, int N, int H, int W, void* stream) {
+  GSD_REQUIRE(dst && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w2d_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w2d_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
+  return w2d_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream);
+}
