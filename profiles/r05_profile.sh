@@ -11,6 +11,10 @@ if [ "$part" = all ] || [ "$part" = stats ]; then
   bash profiles/run_prof.sh ${tag}_fp32 --no-extra --steps 5 --warmup 2 > gpurun_out/${tag}_fp32_prof.log 2>&1
   echo "fp32 stats done"; head -8 gpurun_out/${tag}_fp32_stats.txt
   bash profiles/run_prof.sh ${tag}_fp32_b8 --no-extra --batch 8 --steps 5 --warmup 2 > gpurun_out/${tag}_fp32_b8_prof.log 2>&1
+  # the same two with the weight gradients on the main stream (GSD_SIDE_DW=0): kernels one after the other, so that a kernel's
+  # duration is its own (with the side stream a small launch of the chain can wait 0.3-0.8 ms for a CU and its duration says so)
+  GSD_SIDE_DW=0 bash profiles/run_prof.sh ${tag}_fp32_one_stream --no-extra --steps 5 --warmup 2 > gpurun_out/${tag}_fp32_one_stream_prof.log 2>&1
+  GSD_SIDE_DW=0 bash profiles/run_prof.sh ${tag}_fp32_b8_one_stream --no-extra --batch 8 --steps 5 --warmup 2 > gpurun_out/${tag}_fp32_b8_one_stream_prof.log 2>&1
   echo "fp32 batch-8 stats done"; head -8 gpurun_out/${tag}_fp32_b8_stats.txt
   bash profiles/run_prof.sh ${tag}_bf16 --no-extra --dtype bf16 --steps 5 --warmup 2 > gpurun_out/${tag}_bf16_prof.log 2>&1
   echo "bf16 stats done"; head -6 gpurun_out/${tag}_bf16_stats.txt
@@ -26,6 +30,9 @@ if [ "$part" = all ] || [ "$part" = inc ]; then
   bash profiles/run_pmc_script.sh ${tag}_inc_bf16_fetch "FETCH_SIZE" profiles/inc_block.py bf16 32 3 > /dev/null 2>&1; echo inc fetch done
   bash profiles/run_pmc_script.sh ${tag}_inc_bf16_write "WRITE_SIZE" profiles/inc_block.py bf16 32 3 > /dev/null 2>&1; echo inc write done
   python3 profiles/make_inc_traffic.py ${tag} bf16 3
+  bash profiles/run_pmc_script.sh ${tag}_inc_fp32_fetch "FETCH_SIZE" profiles/inc_block.py fp32 32 3 > /dev/null 2>&1; echo inc fp32 fetch done
+  bash profiles/run_pmc_script.sh ${tag}_inc_fp32_write "WRITE_SIZE" profiles/inc_block.py fp32 32 3 > /dev/null 2>&1; echo inc fp32 write done
+  python3 profiles/make_inc_traffic.py ${tag} fp32 3
   cp profiles/inc_traffic.json gpurun_out/${tag}_inc_traffic.json
   python3 profiles/inc_block.py bf16 32 10 > gpurun_out/${tag}_inc_bf16_time.txt 2>&1; cat gpurun_out/${tag}_inc_bf16_time.txt
 fi
