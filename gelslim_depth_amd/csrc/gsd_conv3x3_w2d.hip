@@ -50,6 +50,9 @@ struct W2DParams {
 #ifndef W2D_PIPE   // 1: pin the interleave of a frequency row's MFMAs with the next row's transform (sched_group_barrier)
 #define W2D_PIPE 1
 #endif
+#ifndef W2D_PK   // 1: the operand transform on pairs of floats (v_pk_add_f32 / v_pk_fma_f32): same operations in the same order on
+#define W2D_PK 1  // every element -- bit-identical -- in about half the vector instructions
+#endif
 #ifndef W2D_ABL   // diagnostic builds only (profiles/build_diag_one.sh; results are then garbage): 1 no weight fills after a block's first,
 #define W2D_ABL 0 // 2 no halo fills after the first, 4 barrier without the wait for the fills, 8 no MFMAs, 16 no operand transform,
                   // 32 no barrier (own fills only)
@@ -363,6 +366,27 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     // 12 MFMAs of row fi -- an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, three vector instructions fit its shadow.
     constexpr int FR[4] = {0, 3, 1, 2};
     auto freq_row = [&](int fr, float (&v)[6]) {
+#if (W2D_PK) && !((W2D_ABL) & 16)
+      // pairs (t0,t1), (t2,t3), (t4,t5) of the column-transformed row, then
+      //   (a, c) = t4 + (-4,-1) t2      (b, e) = t3 + (-4,-1) t1      (v1, v2) = a + (1,-1) b      (v3, v4) = c + (2,-2) e
+      //   (v0, v5) = 4 (t0,t1) + ((t4,t5) - 5 (t2,t3))
+      // -- element for element the fused multiply-adds of row_transform (a multiplication by 1, 2 or -1 is exact)
+      f32x2v tp[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f32x2v r0 = {d[0][2 * k], d[0][2 * k + 1]}, r1 = {d[1][2 * k], d[1][2 * k + 1]};
+        const f32x2v r2 = {d[2][2 * k], d[2][2 * k + 1]}, r3 = {d[3][2 * k], d[3][2 * k + 1]};
+        tp[k] = fr == 0 ? r0 - r2 : fr == 3 ? r1 - r3 : fr == 1 ? r1 + r2 : r2 - r1;
+      }
+      const f32x2v m41 = {-4.f, -1.f}, p1m1 = {1.f, -1.f}, p2m2 = {2.f, -2.f}, m5 = {-5.f, -5.f}, p4 = {4.f, 4.f};
+      const f32x2v ac = __builtin_elementwise_fma(f32x2v{tp[1][0], tp[1][0]}, m41, f32x2v{tp[2][0], tp[2][0]});
+      const f32x2v be = __builtin_elementwise_fma(f32x2v{tp[0][1], tp[0][1]}, m41, f32x2v{tp[1][1], tp[1][1]});
+      const f32x2v v12 = __builtin_elementwise_fma(f32x2v{be[0], be[0]}, p1m1, f32x2v{ac[0], ac[0]});
+      const f32x2v v34 = __builtin_elementwise_fma(f32x2v{be[1], be[1]}, p2m2, f32x2v{ac[1], ac[1]});
+      const f32x2v v05 = __builtin_elementwise_fma(tp[0], p4, __builtin_elementwise_fma(tp[1], m5, tp[2]));
+      v[0] = v05[0], v[1] = v12[0], v[2] = v12[1], v[3] = v34[0], v[4] = v34[1], v[5] = v05[1];
+      return;
+#endif
       float t[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c)
