@@ -355,10 +355,22 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     f32x4 av[2];
     av[0] = *reinterpret_cast<const f32x4*>(&Wc[(j * 12) * 128 + a_lane]);
     if constexpr (!PLAIN) {
+#if W2D_PK
+      const f32x2v sc2 = {sc, sc}, sh2 = {sh, sh};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {   // (the fused multiply-add on pairs; there is no packed fp32 max)
+          const f32x2v y = __builtin_elementwise_fma(f32x2v{d[i][c], d[i][c + 1]}, sc2, sh2);
+          d[i][c] = fmaxf(y[0], lo);
+          d[i][c + 1] = fmaxf(y[1], lo);
+        }
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 6; ++c) d[i][c] = fmaxf(fmaf(d[i][c], sc, sh), lo);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     // frequency rows in the order that retires window rows early: t0 = d0 - d2, t3 = d1 - d3, t1 = d1 + d2, t2 = d2 - d1.
