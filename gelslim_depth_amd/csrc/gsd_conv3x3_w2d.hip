@@ -492,6 +492,28 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 
   // Y = A2^T M A4 of one channel's tile: down the columns first (24 -> 12 values), then along the rows (12 -> 2 x 4 outputs)
   auto out_transform = [&](int m, int reg, float (&y)[2][4]) {
+#if W2D_PK
+    // two channels at once: accumulator registers (2 rp, 2 rp + 1) of a quad are an aligned pair, so the same additions and fused
+    // multiply-adds run as v_pk_add_f32 / v_pk_fma_f32; an odd reg takes the second halves of what its even neighbour computed
+    // (the compiler merges the two calls' identical packed instructions)
+    const int r0 = reg & ~1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x2v R[6];
+#pragma unroll
+      for (int fc = 0; fc < 6; ++fc) {
+        const f32x2v M0 = {acc[m][fc][r0], acc[m][fc][r0 + 1]}, M1 = {acc[m][6 + fc][r0], acc[m][6 + fc][r0 + 1]};
+        const f32x2v M2 = {acc[m][12 + fc][r0], acc[m][12 + fc][r0 + 1]}, M3 = {acc[m][18 + fc][r0], acc[m][18 + fc][r0 + 1]};
+        R[fc] = a == 0 ? M0 + M1 + M2 : M1 - M2 - M3;
+      }
+      const f32x2v p12 = R[1] + R[2], m12 = R[1] - R[2], p34 = R[3] + R[4], m34 = R[3] - R[4];
+      const f32x2v c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+      const f32x2v y0 = R[0] + p12 + p34, y1 = __builtin_elementwise_fma(c2, m34, m12), y2 = __builtin_elementwise_fma(c4, p34, p12);
+      const f32x2v y3 = __builtin_elementwise_fma(c8, m34, m12) + R[5];
+      y[a][0] = y0[reg & 1], y[a][1] = y1[reg & 1], y[a][2] = y2[reg & 1], y[a][3] = y3[reg & 1];
+    }
+    return;
+#endif
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       float R[6];
