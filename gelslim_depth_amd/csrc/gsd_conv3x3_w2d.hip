@@ -25,6 +25,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 __device__ const float gsd_pad_w2d[2] = {0.f, __builtin_nanf("")};
 
@@ -309,8 +310,10 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     for (int ch = 0; ch < 4; ++ch) halo_slot(ch, smem + WTILE);
   }
 
-  for (int chunk = 0; chunk < P.nchunks; ++chunk) {
-    const int cur = chunk & 1;
+  // the chunk loop, unrolled by two: the LDS image a chunk reads (`cur`) is then a constant of each copy, and the image offsets
+  // fold into the instructions' immediate fields instead of costing an address addition per base register and chunk
+  auto run_chunk = [&](const int chunk, auto cur_c) {
+    constexpr int cur = decltype(cur_c)::value;
     if constexpr (U4) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the chunk have landed
       // the outside floats of the straddling pieces this lane moved (the lane state still is the one the chunk was filled with)
@@ -461,6 +464,10 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  for (int chunk = 0; chunk < P.nchunks; chunk += 2) {
+    run_chunk(chunk, std::integral_constant<int, 0>{});
+    if (chunk + 1 < P.nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue: Y = A2^T M A4, NCHW stores (two destination segments with crop), BatchNorm partial sums -------------------------
