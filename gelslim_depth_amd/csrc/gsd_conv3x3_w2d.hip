@@ -901,9 +901,10 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
                   ((uintptr_t)src[0].ptr & 15) == 0 && src[0].w_stride % 4 == 0 && src[0].c_stride % 4 == 0 && src[0].n_stride % 4 == 0 &&
                   src[0].off_h == 0 && src[0].off_w == 0 && src[0].w_stride >= round_up(src[0].W, 4);
   // unaligned 16-byte pieces for every other source: each segment vouches for 4 readable floats around its tensor (slack), lane
-  // offsets stay 32-bit.  GSD_W2D_U4=1 selects it; default 0: measured neutral over the train step (97.7-97.9 ms either way,
-  // bit-identical) -- the aligned form's gain on the dX launches does not carry over to unaligned rows with the patch step
-  bool u4 = !x4 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_U4", 0) != 0;
+  // offsets stay 32-bit.  GSD_W2D_U4=0 keeps the dword gathers.  Default 1 since the loop's other vector work was halved (packed
+  // transforms, constant image offsets): forward layer set 21.9 -> 21.2 ms, step -0.4 ms, bit-identical (when first built, against
+  // the scalar transforms, it measured neutral: 97.7-97.9 ms either way)
+  bool u4 = !x4 && pl.nwp == 2 && 4 * P.NI <= 8 && gsd_env_int("GSD_W2D_U4", 1) != 0;
   for (int i = 0; i < nsrc && u4; ++i) u4 = src[i].slack >= 4;
   if (x4 || u4) {
     P.WCp = 4 * P.NP;
