@@ -12,7 +12,7 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, int iters, float 
   float a = a0 + threadIdx.x, b = b0, x = a0, y = b0;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 xx = {a0, b0}, bb = {b0, a0};
-  int sc = iters;
+  int sc = 7;
   f32x4 ld = {0.f, 0.f, 0.f, 0.f};
   __shared__ float lds[4096];
   lds[threadIdx.x] = a0;
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, int iters, float 
       if constexpr (MODE & 2) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
       if constexpr (MODE & 8) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %2, %2, %1, %1" : "+v"(x), "+v"(y) : "v"(b));
       if constexpr (MODE & 16) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(xx) : "v"(bb));
-      if constexpr (MODE & 32) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+      if constexpr (MODE & 32) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) : : "scc");
+      if constexpr (MODE & 512) asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(sc) : : "scc");
+      if constexpr (MODE & 1024) asm volatile("s_nop 0");
+      if constexpr (MODE & 2048) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %2, %2, %1, %1\n\tv_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %2, %2, %1, %1" : "+v"(x), "+v"(y) : "v"(b));
       if constexpr (MODE & 64) asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"(laddr));
       if constexpr (MODE & 128) asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(b));
     }
@@ -91,6 +94,12 @@ int main() {
   run<8, 32>("AGPR acc + 2 v_fma per gap, 1 wave/SIMD", 256);
   run<16, 32>("AGPR acc + v_pk_fma per gap, 1 wave/SIMD", 256);
   run<32, 32>("AGPR acc + s_add per gap, 1 wave/SIMD", 256);
+  run<512, 32>("AGPR acc + 4 s_add per gap, 1 wave/SIMD", 256);
+  run<512, 32>("AGPR acc + 4 s_add per gap, 2 waves/SIMD", 512);
+  run<1024, 32>("AGPR acc + s_nop 0 per gap, 1 wave/SIMD", 256);
+  run<2048, 32>("AGPR acc + 4 v_fma per gap, 1 wave/SIMD", 256);
+  run<2048, 32>("AGPR acc + 4 v_fma per gap, 2 waves/SIMD", 512);
+  run<2, 32>("AGPR acc + v_fma per gap, 2 waves/SIMD (again)", 512);
   run<64, 32>("AGPR acc + ds_read_b128 per gap, 1 wave/SIMD", 256);
   run<128, 32>("AGPR acc + v_mov per gap, 1 wave/SIMD", 256);
   run<256, 32>("MFMA waves 0-3 + v_fma-only waves 4-7 (8-wave blocks)", 256, 512);
