@@ -93,6 +93,10 @@ SIGNATURES = {
     "gsd_conv3x3_w2d_mfma_count": (C.c_int64, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_w2d": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _I, _I, _I, _P]),
     "gsd_conv3x3_w2d_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "gsd_conv3x3_w2d_estimate_slabs_us": (C.c_double, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_w2d_workspace": (_L, [_I, _I, _I, _I, _I]),
+    "gsd_conv3x3_w2d_ws": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "gsd_conv3x3_w2d_dgrad_bnrelu_ws": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_conv3x3_w43_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_w43_ws": (_I, [_SRC, _I, _P, _I, _I, _DST, _I, _P, _P, _L, _I, _I, _I, _P]),
     "gsd_conv3x3_w43_dgrad_bnrelu_ws": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

@@ -46,6 +46,8 @@ struct W2DParams {
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
   int NP, NI;   // X4: 16-byte pieces per window row (TW / 4 + 2), DMA instructions per channel plane
+  int nslab;    // K slabs (SPLIT): block (tile, slab k, m-block) runs chunks [k n / S, (k + 1) n / S) and stores its un-reduced
+  float* slabs; // 2 x 4 outputs per channel and Winograd tile to [tile][slab][m-block][64 channels][16 NWP tiles][8] floats
 };
 
 #ifndef W2D_PIPE   // 1: pin the interleave of a frequency row's MFMAs with the next row's transform (sched_group_barrier)
@@ -62,6 +64,148 @@ namespace {
 constexpr int W2D_BM = 64;
 constexpr int W2D_WTILE = 96 * W2D_BM;   // floats per weight chunk (24 KiB)
 }  // namespace
+
+// ---- epilogue (shared by the conv kernel and the K-slab reducer): a lane holds, per (m-tile, register) = channel, the 2 x 4 outputs
+// of its Winograd tile (get_y); NCHW stores (two destination segments with crop), BatchNorm partial sums, or the fused
+// BatchNorm-backward form.  sBw: the block's [4][64] coefficients of that form in LDS.
+template <int NWP, class GetY>
+__device__ __forceinline__ void w2d_epilogue(const W2DParams& P, const float* sBw, const int n, const int h0, const int w0, const int tr2,
+                                             const int tq, const int vmask, const int m0, const int mh, const int ph, const int j,
+                                             const int l16, const int pt, GetY get_y) {
+  constexpr int BM = 64;
+  // ---- epilogue: Y = A2^T M A4, NCHW stores (two destination segments with crop), BatchNorm partial sums -------------------------
+  // per destination and tile row: element offset of the row's first pixel inside a plane, and the mask of its pixels that are stored
+  // (scalars, not arrays: `first ? off0(a) : off1(a)` on arrays makes hipcc select between two ADDRESSES and keep the arrays in scratch)
+  int off0_0 = 0, off0_1 = 0, off1_0 = 0, off1_1 = 0, sm0_0 = 0, sm0_1 = 0, sm1_0 = 0, sm1_1 = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int h = h0 + 2 * tr2 + a, w = w0 + 4 * tq;
+    const int vm = (vmask >> (4 * a)) & 15;
+    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
+    if ((unsigned)hd < (unsigned)P.dst0.H) {
+      (a == 0 ? off0_0 : off0_1) = hd * P.dst0.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) (a == 0 ? sm0_0 : sm0_1) |= 1 << i;
+    }
+    hd = h - P.dst1.oh;
+    wd = w - P.dst1.ow;
+    if ((unsigned)hd < (unsigned)P.dst1.H) {
+      (a == 0 ? off1_0 : off1_1) = hd * P.dst1.ws + wd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) (a == 0 ? sm1_0 : sm1_1) |= 1 << i;
+    }
+  }
+  auto OFF0 = [&](int a) { return a == 0 ? off0_0 : off0_1; };   // (a is a constant of the unrolled loops)
+  auto OFF1 = [&](int a) { return a == 0 ? off1_0 : off1_1; };
+  auto SM0 = [&](int a) { return a == 0 ? sm0_0 : sm0_1; };
+  auto SM1 = [&](int a) { return a == 0 ? sm1_0 : sm1_1; };
+  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
+  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
+  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * NWP + ph) * (2 * P.Mpad) : nullptr;
+
+  if (P.bw_raw == nullptr) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
+        const bool first = co < P.dst0.C;
+        const int cd = first ? co : co - P.dst0.C;
+        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
+        float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
+        float y[2][4];
+        get_y(m, reg, y);
+        // statistics over the pixels that are STORED (for a cropped second destination -- the backward of F.pad -- the sums are
+        // those of the crop, e.g. the ConvT bias gradient)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int sm = co_ok ? (first ? SM0(a) : SM1(a)) : 0;
+          float* const px = plane + (first ? OFF0(a) : OFF1(a));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (sm >> i & 1) {
+              s1 += y[a][i];
+              s2 = fmaf(y[a][i], y[a][i], s2);
+            }
+          }
+          if (sm == 15) {
+            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (sm >> i & 1) px[i] = y[a][i];
+          }
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  } else {
+    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
+        const long long cplane = (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs;
+        float xr[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float* const rp = P.bw_raw + cplane + OFF0(a);
+          if (SM0(a) == 15) {
+            const f32x4 t = *reinterpret_cast<const f32x4v*>(rp);
+            xr[a][0] = t[0], xr[a][1] = t[1], xr[a][2] = t[2], xr[a][3] = t[3];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[a][i] = (SM0(a) >> i & 1) ? rp[i] : 0.f;
+          }
+        }
+        const int cl = mh * 32 + m * 16 + j * 4 + reg;
+        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
+        float y[2][4];
+        get_y(m, reg, y);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int sm = co < P.Cout ? SM0(a) : 0;
+          float* const px = d0 + (long long)co * P.dst0.cs + OFF0(a);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x = xr[a][i];
+            const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[a][i] : 0.f;
+            y[a][i] = dz;
+            s1 += dz;
+            s2 = fmaf(dz, (x - bmu) * bis, s2);
+          }
+          if (sm == 15) {
+            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (sm >> i & 1) px[i] = y[a][i];
+          }
+        }
+        if (prow != nullptr) {
+          s1 = reduce16_to_lane15(s1);
+          s2 = reduce16_to_lane15(s2);
+          if (l16 == 15 && co < P.Mpad) {
+            prow[co] = s1;
+            prow[P.Mpad + co] = s2;
+          }
+        }
+      }
+    }
+  }
+}
 
 // PLAIN: no source segment carries a deferred BatchNorm or ReLU (every dX launch; the pooled / up-sampled sources of the forward)
 // NWP: pixel groups of 16 tiles (128 pixels) per block.  2: four waves, 64 channels x 256 pixels, two blocks per CU.  4: eight
@@ -82,7 +226,12 @@ constexpr int W2D_WTILE = 96 * W2D_BM;   // floats per weight chunk (24 KiB)
 // U-Net) is loaded as it lies in memory -- the caller vouches for 4 readable floats around the tensor, gsd_src.slack -- and the
 // lane that moved it overwrites its outside floats with the padding value once its own fills have landed, in front of the chunk's
 // barrier (only lanes of blocks at that edge do anything).
-template <bool PLAIN, int NWP, int HM = 0>
+//
+// SPLIT (K slabs, as gsd_conv3x3_w43.hip): a launch whose tile grid leaves most of the chip's 512 block slots empty (the 40 x 53 and
+// 20 x 26 levels at small batches) is cut along the input channels; the output transform is linear, so each slab stores its own
+// Y = A2^T M A4 and w2d_slab_reduce_kernel adds the slabs in slab order and runs the epilogue.  A slab that starts inside the
+// second (concat) segment starts its fills there.
+template <bool PLAIN, int NWP, int HM = 0, bool SPLIT = false>
 __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DParams P) {
   constexpr bool X4 = HM == 1, U4 = HM == 2, PC = HM != 0;   // PC: the halo lies in LDS as 16-byte pieces
   constexpr int W2D_NONE = -2147483647 - 1, W2D_PAD = -2147483647;   // lane offsets: no position / a padding position (prefilled)
@@ -100,7 +249,10 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   // the m-blocks of one pixel tile read the same halo: every XCD gets a contiguous range of logical ids (pixel tile major)
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int mbb = lid % P.mblocks;
-  const int pt = lid / P.mblocks;
+  const int slab = SPLIT ? (lid / P.mblocks) % P.nslab : 0;
+  const int pt = SPLIT ? lid / P.mblocks / P.nslab : lid / P.mblocks;
+  const int c_lo = SPLIT ? (int)((long)slab * P.nchunks / P.nslab) : 0;
+  const int c_hi = SPLIT ? (int)((long)(slab + 1) * P.nchunks / P.nslab) : P.nchunks;
   const int m0 = mbb * BM;
   const int tpi = P.tiles_y * P.tiles_x;
   const int n = pt / tpi;
@@ -176,12 +328,14 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
       xo1[pp] = ((unsigned)hs < (unsigned)P.src1.H && (unsigned)ws < (unsigned)P.src1.W) ? hs * P.src1.ws + ws : W2D_PAD;
     }
   }
+  const int f_sw = P.src1.C > 0 ? P.src0.C / 4 : -1;           // first chunk of the second (concat) segment
+  const bool start1 = SPLIT && f_sw >= 0 && c_lo >= f_sw;      // this slab's chunks all lie in the second segment
   {
-    // padding positions of the first segment, once, in all 2 x 4 channel planes (own positions only); visible after the first barrier
-    const float pad0 = P.src0.relu ? __builtin_nanf("") : 0.f;
+    // padding positions of the block's first segment, once, in all 2 x 4 channel planes (own positions only); visible after the first barrier
+    const float pad0 = (start1 ? P.src1.relu : P.src0.relu) ? __builtin_nanf("") : 0.f;
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
-      if (p_on[pp] && xo0[pp] == W2D_PAD) {
+      if (p_on[pp] && (start1 ? xo1[pp] : xo0[pp]) == W2D_PAD) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           if constexpr (PC) {   // the unit's own plane
@@ -195,16 +349,17 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
         }
       }
   }
-  const float* d_base = P.src0.p + (long long)n * P.src0.ns;   // channel plane of the next halo slot
-  long long d_cs = P.src0.cs;
-  const int f_sw = P.src1.C > 0 ? P.src0.C / 4 : -1;           // first chunk of the second (concat) segment
+  long long d_cs = start1 ? P.src1.cs : P.src0.cs;
+  // channel plane of the next halo slot: the slab's first channel inside its segment
+  const float* d_base = (start1 ? P.src1.p + (long long)n * P.src1.ns : P.src0.p + (long long)n * P.src0.ns) +
+                        (long long)(c_lo - (start1 ? f_sw : 0)) * 4 * d_cs;
   long long f_xl[2];   // the current segment's lane offsets as 64-bit values (the address add is then a single instruction)
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp) f_xl[pp] = xo0[pp];
+  for (int pp = 0; pp < 2; ++pp) f_xl[pp] = start1 ? xo1[pp] : xo0[pp];
   // the switch to the second segment happens once per block, between two chunks: new plane pointer and lane offsets, and that
   // segment's padding positions are written into each LDS image the first time it is filled from it
   auto begin_fill = [&](int chunk, int buf) {
-    if (f_sw < 0 || (chunk != f_sw && chunk != f_sw + 1)) return;
+    if (f_sw < 0 || start1 || (chunk != f_sw && chunk != f_sw + 1)) return;
     if (chunk == f_sw) {
       d_base = P.src1.p + (long long)n * P.src1.ns;
       d_cs = P.src1.cs;
@@ -300,8 +455,8 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
   };
 
   const int a_lane = mh * 64 + l16 * 4;   // this wave's (f, f+1) x two m-tiles of a frequency pair: 16 lanes read 256 contiguous bytes
-  begin_fill(0, 0);
-  weight_fill(0, smem);
+  begin_fill(c_lo, 0);
+  weight_fill(c_lo, smem);
   if constexpr (PC) {
     halo_unit(0, smem + WTILE);
     halo_unit(1, smem + WTILE);
@@ -344,7 +499,7 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
       sc = sAff[kc], sh = sAff[Kpad + kc];
       lo = kc < P.src0.C ? lo0 : (kc < P.Cin ? lo1 : -__builtin_inff());
     }
-    const bool more = chunk + 1 < P.nchunks;
+    const bool more = chunk + 1 < c_hi;
     const float* Wc = smem + cur * BUF;
     float d[4][6];
 #pragma unroll
@@ -465,40 +620,13 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  for (int chunk = 0; chunk < P.nchunks; chunk += 2) {
+  for (int chunk = c_lo; chunk < c_hi; chunk += 2) {
     run_chunk(chunk, std::integral_constant<int, 0>{});
-    if (chunk + 1 < P.nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
+    if (chunk + 1 < c_hi) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
   }
-
-  // ---- epilogue: Y = A2^T M A4, NCHW stores (two destination segments with crop), BatchNorm partial sums -------------------------
-  // per destination and tile row: element offset of the row's first pixel inside a plane, and the mask of its pixels that are stored
-  int off0[2] = {0, 0}, off1[2] = {0, 0}, sm0[2] = {0, 0}, sm1[2] = {0, 0};
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int h = h0 + 2 * tr2 + a, w = w0 + 4 * tq;
-    const int vm = (vmask >> (4 * a)) & 15;
-    int hd = h - P.dst0.oh, wd = w - P.dst0.ow;
-    if ((unsigned)hd < (unsigned)P.dst0.H) {
-      off0[a] = hd * P.dst0.ws + wd;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst0.W) sm0[a] |= 1 << i;
-    }
-    hd = h - P.dst1.oh;
-    wd = w - P.dst1.ow;
-    if ((unsigned)hd < (unsigned)P.dst1.H) {
-      off1[a] = hd * P.dst1.ws + wd;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((vm >> i & 1) && (unsigned)(wd + i) < (unsigned)P.dst1.W) sm1[a] |= 1 << i;
-    }
-  }
-  float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
-  float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
-  float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * NWP + ph) * (2 * P.Mpad) : nullptr;
 
   // Y = A2^T M A4 of one channel's tile: down the columns first (24 -> 12 values), then along the rows (12 -> 2 x 4 outputs)
-  auto out_transform = [&](int m, int reg, float (&y)[2][4]) {
+  auto out_transform = [&](int m, int reg, float (&y)[2][4]) __attribute__((always_inline)) {
 #if W2D_PK
     // two channels at once: accumulator registers (2 rp, 2 rp + 1) of a quad are an aligned pair, so the same additions and fused
     // multiply-adds run as v_pk_add_f32 / v_pk_fma_f32; an odd reg takes the second halves of what its even neighbour computed
@@ -537,106 +665,81 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
     }
   };
 
-  if (P.bw_raw == nullptr) {
+  if constexpr (SPLIT) {
+    // the un-reduced outputs of this slab: 32 bytes per lane and channel, 512-byte runs per 16 lanes
+    float* const sl = P.slabs + ((size_t)((size_t)pt * P.nslab + slab) * P.mblocks + mbb) * (size_t)(BM * 128 * NWP);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
-        const bool first = co < P.dst0.C;
-        const int cd = first ? co : co - P.dst0.C;
-        const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
-        float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
-        float y[2][4];
-        out_transform(m, reg, y);
-        // statistics over the pixels that are STORED (for a cropped second destination -- the backward of F.pad -- the sums are
-        // those of the crop, e.g. the ConvT bias gradient)
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int sm = co_ok ? (first ? sm0[a] : sm1[a]) : 0;
-          float* const px = plane + (first ? off0[a] : off1[a]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (sm >> i & 1) {
-              s1 += y[a][i];
-              s2 = fmaf(y[a][i], y[a][i], s2);
-            }
-          }
-          if (sm == 15) {
-            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (sm >> i & 1) px[i] = y[a][i];
-          }
-        }
-        if (prow != nullptr) {
-          s1 = reduce16_to_lane15(s1);
-          s2 = reduce16_to_lane15(s2);
-          if (l16 == 15 && co < P.Mpad) {
-            prow[co] = s1;
-            prow[P.Mpad + co] = s2;
-          }
-        }
-      }
-    }
-  } else {
-    // dst0 is the gradient buffer of a conv+BN+ReLU unit whose raw output has the same geometry: dz = relu'(bn(raw)) * dX
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
-        const long long cplane = (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs;
-        float xr[2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const float* const rp = P.bw_raw + cplane + off0[a];
-          if (sm0[a] == 15) {
-            const f32x4 t = *reinterpret_cast<const f32x4v*>(rp);
-            xr[a][0] = t[0], xr[a][1] = t[1], xr[a][2] = t[2], xr[a][3] = t[3];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xr[a][i] = (sm0[a] >> i & 1) ? rp[i] : 0.f;
-          }
-        }
-        const int cl = mh * 32 + m * 16 + j * 4 + reg;
-        const float bsc = sBw[cl], bsh = sBw[BM + cl], bmu = sBw[2 * BM + cl], bis = sBw[3 * BM + cl];
         float y[2][4];
         out_transform(m, reg, y);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int sm = co < P.Cout ? sm0[a] : 0;
-          float* const px = d0 + (long long)co * P.dst0.cs + off0[a];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float x = xr[a][i];
-            const float dz = ((sm >> i & 1) && fmaf(x, bsc, bsh) > 0.f) ? y[a][i] : 0.f;
-            y[a][i] = dz;
-            s1 += dz;
-            s2 = fmaf(dz, (x - bmu) * bis, s2);
-          }
-          if (sm == 15) {
-            *reinterpret_cast<f32x4v*>(px) = f32x4{y[a][0], y[a][1], y[a][2], y[a][3]};
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (sm >> i & 1) px[i] = y[a][i];
-          }
-        }
-        if (prow != nullptr) {
-          s1 = reduce16_to_lane15(s1);
-          s2 = reduce16_to_lane15(s2);
-          if (l16 == 15 && co < P.Mpad) {
-            prow[co] = s1;
-            prow[P.Mpad + co] = s2;
-          }
-        }
+        float* const o = sl + ((size_t)(mh * 32 + m * 16 + j * 4 + reg) * (16 * NWP) + q) * 8;
+        *reinterpret_cast<f32x4*>(o) = f32x4{y[0][0], y[0][1], y[0][2], y[0][3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{y[1][0], y[1][1], y[1][2], y[1][3]};
       }
-    }
+    return;
   }
+  w2d_epilogue<NWP>(P, sBw, n, h0, w0, tr2, tq, vmask, m0, mh, ph, j, l16, pt, out_transform);
+}
+
+// The second half of a K-slab launch: one block per (pixel tile, m-block) with the conv kernel's thread -> (tile, channel) map adds
+// the slabs IN SLAB ORDER (run-to-run bitwise) and runs the conv kernel's epilogue on the sums.
+template <int NWP>
+__global__ __launch_bounds__(128 * NWP) void w2d_slab_reduce_kernel(const W2DParams P) {
+  constexpr int BM = W2D_BM;
+  __shared__ float sBw[4 * BM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave8 % NWP, mh = wave8 / NWP;
+  const int j = lane >> 4, l16 = lane & 15;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int mbb = lid % P.mblocks;
+  const int pt = lid / P.mblocks;
+  const int m0 = mbb * BM;
+  const int tpi = P.tiles_y * P.tiles_x;
+  const int n = pt / tpi;
+  const int rt = pt - n * tpi;
+  const int ty = rt / P.tiles_x;
+  const int h0 = ty * P.TH, w0 = (rt - ty * P.tiles_x) * P.TW;
+  const int q = ph * 16 + l16;
+  const bool q_ok = q < (P.TH >> 1) * P.TWq && q < 16 * NWP;
+  const int tr2 = q_ok ? q / P.TWq : 0;
+  const int tq = q_ok ? q - tr2 * P.TWq : 0;
+  int vmask = 0;
+  if (q_ok) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      if (h0 + 2 * tr2 + a < P.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (w0 + 4 * tq + i < P.W) vmask |= 1 << (4 * a + i);
+      }
+  }
+  if (P.bw_raw != nullptr) {
+    for (int c = tid; c < BM; c += 128 * NWP) {
+      const int co = m0 + c < P.Cout ? m0 + c : 0;
+      sBw[c] = P.bw_scale[co];
+      sBw[BM + c] = P.bw_shift[co];
+      sBw[2 * BM + c] = P.bw_mean[co];
+      sBw[3 * BM + c] = P.bw_invstd[co];
+    }
+    __syncthreads();
+  }
+  const size_t tile_elems = (size_t)(BM * 128 * NWP);
+  const float* const s0 = P.slabs + ((size_t)pt * P.nslab * P.mblocks + mbb) * tile_elems;
+  auto get_y = [&](int m, int reg, float (&y)[2][4]) __attribute__((always_inline)) {
+    const float* o = s0 + ((size_t)(mh * 32 + m * 16 + j * 4 + reg) * (16 * NWP) + q) * 8;
+    f32x4 a = *reinterpret_cast<const f32x4*>(o), b = *reinterpret_cast<const f32x4*>(o + 4);
+    for (int s = 1; s < P.nslab; ++s) {
+      o += (size_t)P.mblocks * tile_elems;
+      a += *reinterpret_cast<const f32x4*>(o);
+      b += *reinterpret_cast<const f32x4*>(o + 4);
+    }
+    y[0][0] = a[0], y[0][1] = a[1], y[0][2] = a[2], y[0][3] = a[3];
+    y[1][0] = b[0], y[1][1] = b[1], y[1][2] = b[2], y[1][3] = b[3];
+  };
+  w2d_epilogue<NWP>(P, sBw, n, h0, w0, tr2, tq, vmask, m0, mh, ph, j, l16, pt, get_y);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -780,18 +883,50 @@ int w2d_x4_plane_stride(int TWq, int WCp, int WR) {
   return ps_best;
 }
 
-template <bool PLAIN, int NWP, int HM = 0>
+template <bool PLAIN, int NWP, int HM = 0, bool SPLIT = false>
 int launch_w2d(const W2DParams& P, int grid, size_t lds, hipStream_t st) {
   static gsd_attr_once big_lds;   // per-device cache of an idempotent launch attribute (gsd_common.h)
-  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, HM>);
+  const void* fn = reinterpret_cast<const void*>(&conv3x3_w2d_kernel<PLAIN, NWP, HM, SPLIT>);
   if (hipError_t e = gsd_allow_big_lds(big_lds, fn); e != hipSuccess) {
     gsd_set_error("gsd_conv3x3_w2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return GSD_ERR_HIP;
   }
   GSD_REQUIRE(lds <= 160 * 1024, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: LDS image %zu B too large", lds);
-  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, HM>), dim3(grid), dim3(128 * NWP), lds, st, P);
+  hipLaunchKernelGGL((conv3x3_w2d_kernel<PLAIN, NWP, HM, SPLIT>), dim3(grid), dim3(128 * NWP), lds, st, P);
   GSD_LAUNCH_CHECK("gsd_conv3x3_w2d");
+  if constexpr (SPLIT) {
+    hipLaunchKernelGGL((w2d_slab_reduce_kernel<NWP>), dim3(grid / P.nslab), dim3(128 * NWP), 0, st, P);
+    GSD_LAUNCH_CHECK("gsd_conv3x3_w2d (slab sums)");
+  }
   return GSD_OK;
+}
+
+// Modelled run time in microseconds of a launch of `base` (tile, m-block) blocks of `nchunks` chunks cut into S slabs: a CU with
+// k = ceil(blocks / 256) blocks runs pairs at 2.07 us per chunk and block (+ 5 us per block) and an odd last block at 0.66 of that;
+// the slab sums cost 12 us + the slabs' bytes at 6 TB/s (the constants of gsd_conv3x3_w43.hip's model, the kernel's own rate).
+double w2d_time_us(long base, int nchunks, int S, bool bw) {
+  const long k = (base * S + 255) / 256;
+  const double cu = (double)(k / 2) + (k & 1 ? 0.66 : 0.0);
+  double t = cu * (2.07 * nchunks / S + 5.0);
+  if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
+  return t;
+}
+
+// GSD_W2D_SPLIT: 0 / 1 never, S >= 2 that many slabs (tuning); default: what the model picks (a split has to buy 3 %)
+int w2d_pick_slabs(long base, int nchunks, bool bw) {
+  const int forced = gsd_env_int("GSD_W2D_SPLIT", -1);
+  if (forced == 0 || forced == 1) return 1;
+  int best = 1;
+  double tb = w2d_time_us(base, nchunks, 1, bw) * (forced > 1 ? 1e9 : 0.97);
+  for (int S = 2; S <= 8 && nchunks / S >= 8; ++S) {
+    if (forced > 1 && S != forced) continue;
+    const double t = w2d_time_us(base, nchunks, S, bw);
+    if (t < tb) {
+      tb = t;
+      best = S;
+    }
+  }
+  return best;
 }
 
 }  // namespace
@@ -822,10 +957,27 @@ extern "C" double gsd_conv3x3_w2d_estimate_us(int N, int H, int W, int Cin, int 
   W2DPlan p;
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w2d(N, H, W, Cout, &p)) return 0.0;
   const long blocks = (long)N * p.tiles_y * p.tiles_x * p.mblocks;
-  const long k = (blocks + 255) / 256;
-  const double per = p.nwp == 2 ? 2.17 : 4.6;   // (the eight-wave block: one per CU, twice the pixels)
-  const double cu = p.nwp == 2 ? (double)(k / 2) + (k & 1 ? 0.66 : 0.0) : (double)k;
-  return cu * (per * ceil_div(Cin, 4) + 5.0);
+  if (p.nwp != 2) return (double)((blocks + 255) / 256) * (4.6 * ceil_div(Cin, 4) + 5.0);   // (the eight-wave block: one per CU, twice the pixels)
+  return w2d_time_us(blocks, ceil_div(Cin, 4), 1, false);
+}
+
+// ... with the K-slab form where it pays (train mode with a workspace: what the engine's launches run)
+extern "C" double gsd_conv3x3_w2d_estimate_slabs_us(int N, int H, int W, int Cin, int Cout) {
+  W2DPlan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w2d(N, H, W, Cout, &p)) return 0.0;
+  if (p.nwp != 2) return gsd_conv3x3_w2d_estimate_us(N, H, W, Cin, Cout);
+  const long blocks = (long)N * p.tiles_y * p.tiles_x * p.mblocks;
+  return w2d_time_us(blocks, ceil_div(Cin, 4), w2d_pick_slabs(blocks, ceil_div(Cin, 4), false), false);
+}
+
+// Floats of K-slab scratch a train-mode launch of this shape wants (0: it runs unsplit); the launcher takes the capacity and
+// shrinks S to what fits.
+extern "C" int64_t gsd_conv3x3_w2d_workspace(int N, int H, int W, int Cin, int Cout) {
+  W2DPlan p;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 != 0 || !plan_w2d(N, H, W, Cout, &p) || p.nwp != 2) return 0;
+  const long blocks = (long)N * p.tiles_y * p.tiles_x * p.mblocks;
+  const int S = std::max(w2d_pick_slabs(blocks, Cin / 4, false), w2d_pick_slabs(blocks, Cin / 4, true));
+  return S > 1 ? (int64_t)blocks * S * (W2D_BM * 256) : 0;
 }
 
 extern "C" double gsd_conv3x3_w43_estimate_us(int N, int H, int W, int Cin, int Cout, int slabs);
@@ -839,13 +991,13 @@ extern "C" int gsd_conv3x3_prefers_w2d(int N, int H, int W, int Cin, int Cout, i
   const int forced = gsd_env_int("GSD_CONV_W2D", -1);
   if (forced == 0 || forced == 1) return forced;
   if (!train) return 1;
-  const double a = gsd_conv3x3_w2d_estimate_us(N, H, W, Cin, Cout), b = gsd_conv3x3_w43_estimate_us(N, H, W, Cin, Cout, 1);
+  const double a = gsd_conv3x3_w2d_estimate_slabs_us(N, H, W, Cin, Cout), b = gsd_conv3x3_w43_estimate_us(N, H, W, Cin, Cout, 1);
   return a > 0.0 && b > 0.0 && a < b ? 1 : 0;
 }
 
 static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst, float* partials,
                     const float* bw_raw, const float* bw_scale, const float* bw_shift, const float* bw_mean, const float* bw_invstd,
-                    int N, int H, int W, void* stream) {
+                    int N, int H, int W, void* stream, float* ws = nullptr, int64_t ws_elems = 0) {
   GSD_REQUIRE(src && dst && wt, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: null argument");
   GSD_REQUIRE(nsrc >= 1 && nsrc <= 2 && ndst >= 1 && ndst <= 2, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: nsrc/ndst must be 1 or 2");
   GSD_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: bad sizes");
@@ -889,7 +1041,15 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp; P.PS = pl.PS;
   P.NPV = ceil_div(P.WR * P.WCp, 64);
   GSD_REQUIRE(P.NPV <= 4 * pl.nwp, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: halo window too large");
-  const long grid = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
+  const long base = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
+  // K slabs: only with a workspace (the engine lends one in train mode), only in the four-wave form, and never more than fit
+  int S = (ws != nullptr && pl.nwp == 2) ? w2d_pick_slabs(base, P.nchunks, bw_raw != nullptr) : 1;
+  while (S > 1 && (int64_t)base * S * (W2D_BM * 256) > ws_elems) --S;
+  if (S > 1 && P.nchunks / S < 2) S = 1;
+  P.nslab = S;
+  P.slabs = S > 1 ? ws : nullptr;
+  if (S > 1) GSD_REQUIRE(((uintptr_t)ws & 15) == 0, GSD_ERR_BAD_ARG, "gsd_conv3x3_w2d: the K-slab workspace must be 16-byte aligned");
+  const long grid = base * S;
   GSD_REQUIRE(grid < 2147483647L, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: grid too large");
   bool plain = true;
   for (int i = 0; i < nsrc; ++i) plain = plain && src[i].scale == nullptr && src[i].relu == 0;
@@ -912,9 +1072,14 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   }
   const size_t lds = (size_t)(2 * (W2D_WTILE + 4 * P.PS) + 2 * 4 * P.nchunks + 4 * W2D_BM) * sizeof(float);
   if (gsd_env_set("GSD_W2D_TRACE"))
-    fprintf(stderr, "w2d M%d K%d %dx%d N%d nsrc %d ndst %d plain %d x4 %d u4 %d | ptr&15 %d ws %d cs%%4 %d ns%%4 %d NI %d tile %dx%d\n", Cout, Cin, H, W, N,
+    fprintf(stderr, "w2d M%d K%d %dx%d N%d nsrc %d ndst %d plain %d x4 %d u4 %d | ptr&15 %d ws %d cs%%4 %d ns%%4 %d NI %d tile %dx%d slabs %d\n", Cout, Cin, H, W, N,
             nsrc, ndst, (int)plain, (int)x4, (int)u4, (int)((uintptr_t)src[0].ptr & 15), src[0].w_stride, (int)(src[0].c_stride % 4),
-            (int)(src[0].n_stride % 4), P.NI, pl.TH, pl.TW);
+            (int)(src[0].n_stride % 4), P.NI, pl.TH, pl.TW, S);
+  if (S > 1) {
+    if (x4) return launch_w2d<true, 2, 1, true>(P, (int)grid, lds, (hipStream_t)stream);
+    if (u4) return plain ? launch_w2d<true, 2, 2, true>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 2, true>(P, (int)grid, lds, (hipStream_t)stream);
+    return plain ? launch_w2d<true, 2, 0, true>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 0, true>(P, (int)grid, lds, (hipStream_t)stream);
+  }
   if (x4) return launch_w2d<true, 2, 1>(P, (int)grid, lds, (hipStream_t)stream);
   if (u4) return plain ? launch_w2d<true, 2, 2>(P, (int)grid, lds, (hipStream_t)stream) : launch_w2d<false, 2, 2>(P, (int)grid, lds, (hipStream_t)stream);
   if (pl.nwp == 2)
@@ -935,4 +1100,24 @@ extern "C" int gsd_conv3x3_w2d_dgrad_bnrelu(const gsd_src* src, const float* wt,
   GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
               "gsd_conv3x3_w2d_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
   return w2d_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream);
+}
+
+// The same two with K-slab scratch lent by the caller (gsd_conv3x3_w2d_workspace floats; any capacity is safe: the launcher shrinks
+// the slab count to what fits, 0 or a null pointer runs unsplit): what a train-mode schedule calls.  The sum over the input
+// channels is then taken slab by slab in a fixed order -- run-to-run bitwise, not bit-equal to the unsplit launch.
+extern "C" int gsd_conv3x3_w2d_ws(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                                  float* partials, float* workspace, int64_t workspace_elems, int N, int H, int W, void* stream) {
+  return w2d_impl(src, nsrc, wt, Cin, Cout, dst, ndst, partials, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, stream, workspace,
+                  workspace_elems);
+}
+
+extern "C" int gsd_conv3x3_w2d_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                               const float* raw, const float* scale, const float* shift, const float* mean,
+                                               const float* invstd, float* partials, float* workspace, int64_t workspace_elems, int N,
+                                               int H, int W, void* stream) {
+  GSD_REQUIRE(dst && raw && scale && shift && mean && invstd && partials, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w2d_dgrad_bnrelu: null argument");
+  GSD_REQUIRE(dst->C == Cout && dst->H == H && dst->W == W && dst->off_h == 0 && dst->off_w == 0, GSD_ERR_BAD_ARG,
+              "gsd_conv3x3_w2d_dgrad_bnrelu: dst must be the full (Cout,H,W) gradient buffer (raw shares its strides)");
+  return w2d_impl(src, 1, wt, Cin, Cout, dst, 1, partials, raw, scale, shift, mean, invstd, N, H, W, stream, workspace, workspace_elems);
 }

@@ -47,8 +47,8 @@ class _ConvForm:
         self.dgrad_bnrelu = (lib.gsd_conv3x3_dgrad_bnrelu, lib.gsd_conv3x3_w43_dgrad_bnrelu, lib.gsd_conv3x3_w2d_dgrad_bnrelu)[algo]
         self.partial_rows = (lib.gsd_conv3x3_partial_rows, lib.gsd_conv3x3_w43_partial_rows, lib.gsd_conv3x3_w2d_partial_rows)[algo]
         self.mode_f, self.mode_d = ((0, 1), (4, 5), (8, 9))[algo]
-        # K-slab scratch the form would like for a shape (the row form only; 0: the shape runs unsplit)
-        self.workspace = lib.gsd_conv3x3_w43_workspace if algo == 1 else (lambda *a: 0)
+        # K-slab scratch the form would like for a shape (the two Winograd forms; 0: the shape runs unsplit)
+        self.workspace = (lambda *a: 0, lib.gsd_conv3x3_w43_workspace, lib.gsd_conv3x3_w2d_workspace)[algo]
 
     @staticmethod
     def choose(n: int, h: int, w: int, cin: int, c0: int, cout: int, train: bool) -> "_ConvForm":
@@ -61,14 +61,15 @@ class _ConvForm:
 
     def run(self, ws, src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st):
         """conv3x3 forward / dX; `ws`: the engine's K-slab scratch (train mode) or None."""
-        if self.algo == 1 and ws is not None:
-            return lib.gsd_conv3x3_w43_ws(src, nsrc, wt, cin, cout, dst, ndst, part, ws.data_ptr(), ws.numel(), n, h, w, st)
+        if self.algo >= 1 and ws is not None:
+            fn = lib.gsd_conv3x3_w43_ws if self.algo == 1 else lib.gsd_conv3x3_w2d_ws
+            return fn(src, nsrc, wt, cin, cout, dst, ndst, part, ws.data_ptr(), ws.numel(), n, h, w, st)
         return self.conv(src, nsrc, wt, cin, cout, dst, ndst, part, n, h, w, st)
 
     def run_bnrelu(self, ws, src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st):
-        if self.algo == 1 and ws is not None:
-            return lib.gsd_conv3x3_w43_dgrad_bnrelu_ws(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part,
-                                                       ws.data_ptr(), ws.numel(), n, h, w, st)
+        if self.algo >= 1 and ws is not None:
+            fn = lib.gsd_conv3x3_w43_dgrad_bnrelu_ws if self.algo == 1 else lib.gsd_conv3x3_w2d_dgrad_bnrelu_ws
+            return fn(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, ws.data_ptr(), ws.numel(), n, h, w, st)
         return self.dgrad_bnrelu(src, wt, cin, cout, dst, raw, scale, shift, mean, invstd, part, n, h, w, st)
 
 

@@ -181,8 +181,12 @@ int gsd_conv3x3_w43_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin
  * down the columns -- 24 products per 2x4 outputs and input channel, a third of the direct form's and two thirds of the
  * row-only form's MFMA work; same fp32 storage and accumulation.  Weights from gsd_weight_layout modes 8 (forward) / 9 (dX):
  * [m-block of 64][k row = ci*24 + fr*6 + fc][64], U = G2 g G4^T.  Needs Cin % 4 == 0 and a first source segment of a multiple
- * of 4 channels (gsd_conv3x3_w2d_supported); no K-slab form and no row folding: the caller keeps gsd_conv3x3_w43 for the small
- * deep levels.  Partial-row layout as gsd_conv3x3, its own row count (two rows per pixel tile). */
+ * of 4 channels (gsd_conv3x3_w2d_supported); no row folding (an eval-mode forward in this form gives image i of a batch the bits
+ * the image alone gets).  Partial-row layout as gsd_conv3x3, its own row count (two rows per pixel tile).
+ * K slabs (the _ws entries, as gsd_conv3x3_w43_ws): with scratch lent by the caller a launch whose tile grid leaves most of the
+ * chip idle is cut along the input channels, the slabs summed in a fixed order by a second kernel that also runs the epilogue
+ * (run-to-run bitwise; not bit-equal to the unsplit launch).  gsd_conv3x3_w2d_workspace: the floats such a launch wants (0: it runs
+ * unsplit); any capacity is safe -- the launcher shrinks the slab count to what fits. */
 int gsd_conv3x3_w2d_supported(int Cin, int C0);
 int gsd_conv3x3_prefers_w2d(int N, int H, int W, int Cin, int Cout, int train);   /* 1: run this Winograd launch in the 2-D form */
 double gsd_conv3x3_w2d_estimate_us(int N, int H, int W, int Cin, int Cout);          /* the planner's run-time models */
@@ -194,6 +198,14 @@ int gsd_conv3x3_w2d(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
 int gsd_conv3x3_w2d_dgrad_bnrelu(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
                                  const float* raw, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, float* partials, int N, int H, int W, void* stream);
+double gsd_conv3x3_w2d_estimate_slabs_us(int N, int H, int W, int Cin, int Cout);    /* ... with the K-slab form where it pays */
+int64_t gsd_conv3x3_w2d_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_conv3x3_w2d_ws(const gsd_src* src, int nsrc, const float* wt, int Cin, int Cout, const gsd_dst* dst, int ndst,
+                       float* partials, float* workspace, int64_t workspace_elems, int N, int H, int W, void* stream);
+int gsd_conv3x3_w2d_dgrad_bnrelu_ws(const gsd_src* src, const float* wt, int Cin, int Cout, const gsd_dst* dst,
+                                    const float* raw, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, float* partials, float* workspace, int64_t workspace_elems,
+                                    int N, int H, int W, void* stream);
 
 /* ConvTranspose2d(k=2,s=2)+bias. Replaces aten::convolution(transposed) at unet.py:36,41.
  * src is the (h,w) input (deferred BN allowed), dst the (2h,2w) output. weights: mode 6. */

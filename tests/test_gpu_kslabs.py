@@ -1,4 +1,5 @@
-"""K-slab form of the Winograd conv3x3 (gsd_conv3x3_w43_ws / gsd_conv3x3_w43_dgrad_bnrelu_ws, include/gsd.h): the launches of
+"""K-slab form of the two Winograd conv3x3 kernels (gsd_conv3x3_w43_ws / gsd_conv3x3_w43_dgrad_bnrelu_ws and their
+gsd_conv3x3_w2d_* twins, include/gsd.h): the launches of
 the 40x53 / 20x26 levels at small per-GPU batches cut their input channels into S slabs and a second launch adds the slabs and
 runs the epilogue.  Same operator as /root/reference/gelslim_depth/models/unet.py:11,14 (forward) and its dX.
 
@@ -80,21 +81,34 @@ def close(a, b, tol=1e-5):
     return float((a64 - b64).abs().sum() / b64.abs().sum().clamp_min(1e-30)) < tol
 
 
+class _Form:
+    """The entry points of one Winograd form by name: row form (w43, weight layouts 4 / 5) or two-dimensional form (w2d, 8 / 9)."""
+
+    def __init__(self, L, name):
+        self.name = name
+        self.env = "GSD_W43_SPLIT" if name == "w43" else "GSD_W2D_SPLIT"
+        self.mode_f, self.mode_d = (4, 5) if name == "w43" else (8, 9)
+        for f in ("", "_ws", "_dgrad_bnrelu", "_dgrad_bnrelu_ws", "_workspace", "_partial_rows"):
+            setattr(self, "conv" + f, getattr(L, f"gsd_conv3x3_{name}{f}"))
+
+
+@pytest.mark.parametrize("form", ["w43", "w2d"])
 @pytest.mark.parametrize("unit,split", CASES, ids=[f"{u[0]}-S{s}" for u, s in CASES])
-def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
+def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split, form):
     from oracle import unet_numpy as on
     name, lvl, c0, c1, co, pooled = unit
     h, w = HS[lvl], WS[lvl]
     ci = c0 + c1
     L = gsd.lib
+    F = _Form(L, form)
     n = N
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + 77)
-    monkeypatch.delenv("GSD_W43_SPLIT", raising=False)
+    monkeypatch.delenv(F.env, raising=False)
     if split != "auto":
-        monkeypatch.setenv("GSD_W43_SPLIT", split)
-    need_f = L.gsd_conv3x3_w43_workspace(n, h, w, ci, co)
-    need_d = L.gsd_conv3x3_w43_workspace(n, h, w, co, ci)
-    if split == "auto" and lvl >= 3:
+        monkeypatch.setenv(F.env, split)
+    need_f = F.conv_workspace(n, h, w, ci, co)
+    need_d = F.conv_workspace(n, h, w, co, ci)
+    if split == "auto" and lvl >= 3 and form == "w43":
         assert need_f > 0 or need_d > 0, "the planner splits the deep levels at batch 8"
     if split != "auto":
         assert need_f > 0 and need_d > 0, "a forced slab count applies wherever the shape admits it"
@@ -128,18 +142,17 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
     mpad_o, mpad_i = (co + 63) // 64 * 64, (ci + 63) // 64 * 64
 
     # ---- forward + statistics: unsplit, split, split again
-    wl_f = layout(gsd, 4, wd, co, ci)
-    rows = L.gsd_conv3x3_w43_partial_rows(n, h, w, co)
+    wl_f = layout(gsd, F.mode_f, wd, co, ci)
+    rows = F.conv_partial_rows(n, h, w, co)
 
     def fwd(use_ws):
         y = torch.full((n, co, h, w), float("nan"), device="cuda")
         part = torch.zeros(rows * 2 * mpad_o, device="cuda")
         dst = gsd.dst_array([gsd.make_dst(y)])
         if use_ws:
-            gsd.check(L.gsd_conv3x3_w43_ws(src, len(segs), wl_f.data_ptr(), ci, co, dst, 1, part.data_ptr(), ws.data_ptr(), need_f,
-                                           n, h, w, st))
+            gsd.check(F.conv_ws(src, len(segs), wl_f.data_ptr(), ci, co, dst, 1, part.data_ptr(), ws.data_ptr(), need_f, n, h, w, st))
         else:
-            gsd.check(L.gsd_conv3x3_w43(src, len(segs), wl_f.data_ptr(), ci, co, dst, 1, part.data_ptr(), n, h, w, st))
+            gsd.check(F.conv(src, len(segs), wl_f.data_ptr(), ci, co, dst, 1, part.data_ptr(), n, h, w, st))
         return y, part
     y0, p0 = fwd(False)
     y1, p1 = fwd(True)
@@ -160,9 +173,9 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
     # ---- dX in the engine's form for this unit
     dy = rnd(rng, n, co, h, w)
     dyp = pitched(dev(dy))
-    wl_d = layout(gsd, 5, wd, co, ci)
+    wl_d = layout(gsd, F.mode_d, wd, co, ci)
     dsrc = gsd.src_array([gsd.make_src(dyp)])
-    rows_d = L.gsd_conv3x3_w43_partial_rows(n, h, w, ci)
+    rows_d = F.conv_partial_rows(n, h, w, ci)
     dxr, _ = on.conv3x3_bwd(a_img0, wt_, dy[:1])
     if c1:
         def dx(use_ws):
@@ -171,10 +184,9 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
             part = torch.zeros(rows_d * 2 * mpad_i, device="cuda")
             dst = gsd.dst_array([gsd.make_dst(g_skip), gsd.make_dst(g_up, off=(top, left))])
             if use_ws:
-                gsd.check(L.gsd_conv3x3_w43_ws(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 2, part.data_ptr(), ws.data_ptr(), need_d,
-                                               n, h, w, st))
+                gsd.check(F.conv_ws(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 2, part.data_ptr(), ws.data_ptr(), need_d, n, h, w, st))
             else:
-                gsd.check(L.gsd_conv3x3_w43(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 2, part.data_ptr(), n, h, w, st))
+                gsd.check(F.conv(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 2, part.data_ptr(), n, h, w, st))
             return g_skip, g_up, part
         a_, b_, p_ = dx(False)
         a1, b1, p1 = dx(True)
@@ -191,9 +203,9 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
             g = torch.full((n, ci, h, w), float("nan"), device="cuda")
             dst = gsd.dst_array([gsd.make_dst(g)])
             if use_ws:
-                gsd.check(L.gsd_conv3x3_w43_ws(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 1, None, ws.data_ptr(), need_d, n, h, w, st))
+                gsd.check(F.conv_ws(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 1, None, ws.data_ptr(), need_d, n, h, w, st))
             else:
-                gsd.check(L.gsd_conv3x3_w43(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 1, None, n, h, w, st))
+                gsd.check(F.conv(dsrc, 1, wl_d.data_ptr(), co, ci, dst, 1, None, n, h, w, st))
             return g
         g0, g1, g2 = dx(False), dx(True), dx(True)
         assert close(g1, g0) and torch.equal(g1, g2)
@@ -208,12 +220,11 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
             part = torch.zeros(rows_d * 2 * mpad_i, device="cuda")
             d = gsd.make_dst(dz)
             if use_ws:
-                gsd.check(L.gsd_conv3x3_w43_dgrad_bnrelu_ws(C.byref(s_), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
-                                                            *[v.data_ptr() for v in vecs], part.data_ptr(), ws.data_ptr(), need_d,
-                                                            n, h, w, st))
+                gsd.check(F.conv_dgrad_bnrelu_ws(C.byref(s_), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
+                                                 *[v.data_ptr() for v in vecs], part.data_ptr(), ws.data_ptr(), need_d, n, h, w, st))
             else:
-                gsd.check(L.gsd_conv3x3_w43_dgrad_bnrelu(C.byref(s_), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
-                                                         *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, st))
+                gsd.check(F.conv_dgrad_bnrelu(C.byref(s_), wl_d.data_ptr(), co, ci, C.byref(d), r0d.data_ptr(),
+                                              *[v.data_ptr() for v in vecs], part.data_ptr(), n, h, w, st))
             return dz, part
         z0, q0 = dx(False)
         z1, q1 = dx(True)
@@ -229,33 +240,35 @@ def test_kslab_launches_match_unsplit_and_oracle(gsd, monkeypatch, unit, split):
     assert bool(torch.isnan(guard).all()), "nothing was written behind the scratch the library asked for"
 
 
-def test_kslab_scratch_too_small_falls_back(gsd, monkeypatch):
+@pytest.mark.parametrize("form", ["w43", "w2d"])
+def test_kslab_scratch_too_small_falls_back(gsd, monkeypatch, form):
     """The launcher takes the scratch capacity and shrinks the slab count to what fits (down to the plain launch): a tuning
     switch changed between allocation and launch can never overrun the buffer."""
     L = gsd.lib
+    F = _Form(L, form)
     n, h, w, ci, co = 8, 20, 26, 1024, 1024
-    monkeypatch.setenv("GSD_W43_SPLIT", "2")
-    need2 = L.gsd_conv3x3_w43_workspace(n, h, w, ci, co)
-    monkeypatch.setenv("GSD_W43_SPLIT", "5")
-    need5 = L.gsd_conv3x3_w43_workspace(n, h, w, ci, co)
+    monkeypatch.setenv(F.env, "2")
+    need2 = F.conv_workspace(n, h, w, ci, co)
+    monkeypatch.setenv(F.env, "5")
+    need5 = F.conv_workspace(n, h, w, ci, co)
     assert need5 * 2 == need2 * 5 and need2 > 0
     rng = np.random.default_rng(5)
     x = slack_dev(gsd, rnd(rng, n, ci, h, w))
     wd = dev(rnd(rng, co, ci, 3, 3, scale=0.01))
-    wl = layout(gsd, 4, wd, co, ci)
+    wl = layout(gsd, F.mode_f, wd, co, ci)
     src = gsd.src_array([gsd.make_src(x, slack=gsd.SLACK)])
     outs = []
     for cap in (need5, need2 + 8, need2 - 4, 0):        # 5 slabs, 2 slabs (all that fits), none, none
         ws = torch.full((need5 + 64,), float("nan"), device="cuda")
         y = torch.full((n, co, h, w), float("nan"), device="cuda")
-        gsd.check(L.gsd_conv3x3_w43_ws(src, 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None,
-                                       ws.data_ptr() if cap else None, cap, n, h, w, gsd.stream_ptr()))
+        gsd.check(F.conv_ws(src, 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None,
+                            ws.data_ptr() if cap else None, cap, n, h, w, gsd.stream_ptr()))
         assert bool(torch.isfinite(y).all())
         assert bool(torch.isnan(ws[cap:]).all()), "no write behind the stated capacity"
         outs.append(y)
-    monkeypatch.setenv("GSD_W43_SPLIT", "0")
+    monkeypatch.setenv(F.env, "0")
     y = torch.empty_like(outs[0])
-    gsd.check(L.gsd_conv3x3_w43(src, 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
+    gsd.check(F.conv(src, 1, wl.data_ptr(), ci, co, gsd.dst_array([gsd.make_dst(y)]), 1, None, n, h, w, gsd.stream_ptr()))
     assert torch.equal(outs[2], y) and torch.equal(outs[3], y), "no room for two slabs: the plain launch"
     assert close(outs[0], y) and close(outs[1], y) and not torch.equal(outs[0], outs[1])
 
@@ -284,10 +297,11 @@ def test_eval_forward_never_splits_and_train_step_is_reproducible(gsd):
     assert torch.equal(yb[5:6], y1)
     res = []
     for env in (None, None, "0"):
-        if env is None:
-            os.environ.pop("GSD_W43_SPLIT", None)
-        else:
-            os.environ["GSD_W43_SPLIT"] = env
+        for key in ("GSD_W43_SPLIT", "GSD_W2D_SPLIT"):
+            if env is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = env
         try:
             m = model().train()
             step = TrainStep(m)
@@ -296,6 +310,7 @@ def test_eval_forward_never_splits_and_train_step_is_reproducible(gsd):
             res.append((loss, step.g_flat.clone(), m._engine.conv_ws is not None))
         finally:
             os.environ.pop("GSD_W43_SPLIT", None)
+            os.environ.pop("GSD_W2D_SPLIT", None)
     assert res[0][2] and not res[2][2], "slab scratch exists exactly when the planner splits some launch"
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
     assert abs(res[0][0] - res[2][0]) < 1e-5 * abs(res[2][0])
