@@ -151,7 +151,7 @@ def test_eval_forms_do_not_depend_on_the_batch_and_slab_scratch_is_consistent(mo
     the row form asks for is S x (tile blocks) x 64 x 256 floats with 2 <= S <= 8, and only the small deep levels ask."""
     from gelslim_depth_amd import _lib
     lib = _lib.lib
-    for k in ("GSD_CONV_ALGO", "GSD_CONV_W2D", "GSD_W43_SPLIT"):
+    for k in ("GSD_CONV_ALGO", "GSD_CONV_W2D", "GSD_W43_SPLIT", "GSD_W2D_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     dims = [64, 128, 256, 512, 1024]
     units = []          # (level, cin, first-segment channels, cout)
@@ -169,7 +169,7 @@ def test_eval_forms_do_not_depend_on_the_batch_and_slab_scratch_is_consistent(mo
                 algo = 2
             forms.add(algo)
         assert forms == ({0} if cin < 16 else {2}), (lvl, cin, cout, forms)
-    asked = 0
+    asked = asked2 = 0
     for lvl, cin, c0, cout in units:
         for n in (1, 4, 8, 16, 32):
             for ci, co in ((cin, cout), (cout, cin)):          # forward and dX launches
@@ -182,7 +182,17 @@ def test_eval_forms_do_not_depend_on_the_batch_and_slab_scratch_is_consistent(mo
                 if need:
                     asked += 1
                     assert base < 3 * 512, ("only launches of less than three rounds of the chip's 512 block slots are cut", lvl, n, base)
-    assert asked > 0
+                # the two-dimensional form: two partial rows per pixel tile; same scratch formula; an eval-mode launch is never cut
+                # (gsd_conv3x3_w2d takes no scratch at all), and a cut launch has at least 8 chunks per slab
+                if lib.gsd_conv3x3_w2d_supported(ci, ci):
+                    need2 = lib.gsd_conv3x3_w2d_workspace(n, hs[lvl], ws[lvl], ci, co)
+                    base2 = lib.gsd_conv3x3_w2d_partial_rows(n, hs[lvl], ws[lvl], co) // 2 * (-(-co // 64))
+                    s2 = need2 // (base2 * 64 * 256)
+                    assert need2 % (base2 * 64 * 256) == 0 and s2 in (0, 2, 3, 4, 5, 6, 7, 8), (lvl, n, ci, co, need2)
+                    if need2:
+                        asked2 += 1
+                        assert base2 < 3 * 512 and ci // 4 // s2 >= 8, (lvl, n, ci, co, base2, s2)
+    assert asked > 0 and asked2 > 0
 
 
 def test_guard_struct_and_bench_self_launch_refuses_cleanly():
