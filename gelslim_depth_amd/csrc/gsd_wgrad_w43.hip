@@ -21,6 +21,7 @@
 // fixed), then B^T; A dy needs 9 VALU operations per 4 values.  Split-K over stages with ordered slab reduction as in
 // gsd_wgrad.hip: bitwise reproducible.
 #include "gsd_common.h"
+#include <type_traits>
 
 #include <cstdio>
 #include <cstdlib>
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     st_ty = rs / P.tiles_x;
     st_tx = rs - st_ty * P.tiles_x;
   }
-  auto issue_dma = [&](int stage, int buf) {
+  auto issue_dma = [&](int stage, int buf) __attribute__((always_inline)) {
     const int n = st_n, h0 = st_ty * P.TH, w0 = st_tx * P.TW;
     if (++st_tx == P.tiles_x) {
       st_tx = 0;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
     v[4] = c - e;
     v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
   };
-  auto compute = [&](int cur, bool late, int next_stage, bool more) {
+  auto compute = [&](int cur, bool late, int next_stage, bool more) __attribute__((always_inline)) {
     const float* Sb = smem + cur * BUF;
     if constexpr (RR == 1) {
       // b_off[0] = this lane's channel plane + 4 j: window row w of tile column j is at + w * WCp
@@ -682,8 +683,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
   } else {
     if (nst > 0) issue_dma(s_begin, 0);
     WG43_STAMP(3)   // prologue
-    for (int it = 0; it < nst; ++it) {
-      const int cur = it & 1;
+    // the stage loop, unrolled by two: which of the two LDS images a stage reads is a constant of each copy, so the image offsets
+    // fold into the instructions' immediate fields (as in gsd_conv3x3_w2d.hip)
+    auto run_stage = [&](const int it, auto cur_c) {
+      constexpr int cur = decltype(cur_c)::value;
       if constexpr (BX4) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's fills of the stage have landed
         const int fx = cur ? fix1 : fix0;
@@ -722,6 +725,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void wgrad3
       if (!late && it + 1 < nst) issue_dma(s_begin + it + 1, cur ^ 1);
       WG43_STAMP(1)   // this wave's share of the next stage's DMA
       compute(cur, late, s_begin + it + 1, it + 1 < nst);
+    };
+    for (int it = 0; it < nst; it += 2) {
+      run_stage(it, std::integral_constant<int, 0>{});
+      if (it + 1 < nst) run_stage(it + 1, std::integral_constant<int, 1>{});
     }
   }
 
