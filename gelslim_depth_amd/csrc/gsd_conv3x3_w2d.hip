@@ -101,6 +101,7 @@ __device__ __forceinline__ void w2d_epilogue(const W2DParams& P, const float* sB
   auto OFF1 = [&](int a) { return a == 0 ? off1_0 : off1_1; };
   auto SM0 = [&](int a) { return a == 0 ? sm0_0 : sm0_1; };
   auto SM1 = [&](int a) { return a == 0 ? sm1_0 : sm1_1; };
+  const long long lane0 = (long long)(j * 4) * P.dst0.cs, lane1 = (long long)(j * 4) * P.dst1.cs;
   float* const d0 = P.dst0.p + (long long)n * P.dst0.ns;
   float* const d1 = P.dst1.p + (long long)n * P.dst1.ns;
   float* const prow = P.partials != nullptr ? P.partials + (size_t)(pt * NWP + ph) * (2 * P.Mpad) : nullptr;
@@ -110,11 +111,13 @@ __device__ __forceinline__ void w2d_epilogue(const W2DParams& P, const float* sB
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
+        // channel = wave-uniform part cu + the lane's 4 j: the plane offset of cu is scalar arithmetic, the lane's share (lane0 / lane1)
+        // is multiplied once -- a 64-bit vector multiply per channel otherwise
+        const int cu = m0 + mh * 32 + m * 16 + reg, co = cu + j * 4;
         const bool first = co < P.dst0.C;
         const int cd = first ? co : co - P.dst0.C;
         const bool co_ok = co < P.Cout && (first || cd < P.dst1.C);
-        float* const plane = first ? d0 + (long long)cd * P.dst0.cs : d1 + (long long)cd * P.dst1.cs;
+        float* const plane = first ? d0 + (long long)cu * P.dst0.cs + lane0 : d1 + (long long)(cu - P.dst0.C) * P.dst1.cs + lane1;
         float y[2][4];
         get_y(m, reg, y);
         // statistics over the pixels that are STORED (for a cropped second destination -- the backward of F.pad -- the sums are
@@ -155,8 +158,8 @@ __device__ __forceinline__ void w2d_epilogue(const W2DParams& P, const float* sB
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int co = m0 + mh * 32 + m * 16 + j * 4 + reg;
-        const long long cplane = (long long)n * P.dst0.ns + (long long)(co < P.Cout ? co : 0) * P.dst0.cs;
+        const int cu = m0 + mh * 32 + m * 16 + reg, co = cu + j * 4;
+        const long long cplane = (long long)n * P.dst0.ns + (co < P.Cout ? (long long)cu * P.dst0.cs + lane0 : 0);
         float xr[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -177,7 +180,7 @@ __device__ __forceinline__ void w2d_epilogue(const W2DParams& P, const float* sB
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const int sm = co < P.Cout ? SM0(a) : 0;
-          float* const px = d0 + (long long)co * P.dst0.cs + OFF0(a);
+          float* const px = d0 + ((long long)cu * P.dst0.cs + lane0) + OFF0(a);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float x = xr[a][i];
