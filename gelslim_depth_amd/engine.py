@@ -150,7 +150,8 @@ class UNetEngine:
         # partial-row count up to which BatchNorm's column sums and finalize run as ONE launch (gsd_bn_[bwd_]reduce_finalize)
         self.one_launch_rows = int(os.environ.get("GSD_BN_ONE_LAUNCH_ROWS", "4096"))
         # weight gradients on a side stream: dW of a unit runs beside its dX and the BatchNorm backward of the unit below (they only
-        # share d_raw as an input) -- one dW block and one dX block fit a CU together (LDS 96 + 60 KiB, 256 + 256 registers per SIMD lane)
+        # share d_raw as an input).  A dW block owns its CU (8 waves x 240 registers, 96 KiB of LDS), so the two streams interleave CU
+        # by CU: dX keeps its stand-alone speed and dW fills the CUs dX's tails and the chain's small launches leave idle
         self.side_dw = os.environ.get("GSD_SIDE_DW", "1") != "0"
         self.side: Optional[torch.cuda.Stream] = None
         self.convt_dg_bn = os.environ.get("GSD_CONVT_DG_BN", "1") != "0"   # ConvT dX + pass 1 of the BatchNorm backward below it
