@@ -19,8 +19,14 @@
 // 128 pixels where the row-only kernel issues 72 for 64.  The weight image of a chunk is 96 x 64 floats = 24 KiB (U = G2 g G4^T,
 // laid out once per optimiser step by gsd_weight_layout modes 8 / 9); the (TH + 2) x (TW + 2) halo window, the LDS-DMA fills, the
 // deferred BatchNorm + ReLU of the sources (NaN-sentinel padding), the two source segments (concat), the two cropped destinations,
-// the BatchNorm partial sums and the fused BatchNorm-backward dX epilogue are those of gsd_conv3x3_w43.hip (its straight-fill,
-// dword-gather form: every 4-channel chunk lies inside one source segment -- always true in the U-Net).
+// the BatchNorm partial sums and the fused BatchNorm-backward dX epilogue are those of gsd_conv3x3_w43.hip (its straight-fill
+// form: every 4-channel chunk lies inside one source segment -- always true in the U-Net).
+//
+// What sets this kernel's rate is its vector-to-MFMA instruction ratio (an fp32 MFMA stream hides LDS reads and scalar instructions
+// but not vector instructions: profiles/r05_mfma_f32_issue_ubench.txt), hence: the operand transform, the deferred-BatchNorm affine
+// and the output transform on PAIRS of floats (packed fp32 instructions, bit-identical to the scalar form); the chunk loop unrolled
+// by two so that the LDS image offsets are instruction immediates; 16-byte halo pieces wherever the source admits them (HM);
+// plane offsets of the epilogue as scalar arithmetic.  K slabs (SPLIT) for the launches that would leave the chip idle.
 #include "gsd_common.h"
 
 #include <cstdio>
