@@ -108,6 +108,8 @@ SIGNATURES = {
     "gsd_convT2x2_dgrad_bnrelu": (_I, [_SRC, _P, _I, _I, _DST, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "gsd_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad": (_I, [_SRC, _I, _SRC, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "gsd_conv3x3_wgrad_form": (_I, [_SRC, _I, _SRC, _I, _I, _I, _I, _I]),
+    "gsd_conv3x3_wgrad_mfma_count": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad_takes_pitched_dy": (_I, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad_bn_supported": (_I, [_I, _I, _I, _I, _I]),
     "gsd_conv3x3_wgrad_bn_workspace": (_L, [_I, _I, _I, _I, _I]),

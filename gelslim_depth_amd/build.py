@@ -18,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["gsd_conv3x3.hip", "gsd_conv3x3_w43.hip", "gsd_conv3x3_w2d.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_wgrad_w43.hip", "gsd_wgrad_first.hip", "gsd_pointwise.hip", "gsd_dataset.hip", "gsd_bf16_conv.hip", "gsd_bf16_pointwise.hip", "gsd_bf16_wgrad.hip", "gsd_bf16_first.hip", "gsd_bf16_inc.hip", "gsd_bf16_c64.hip", "gsd_bf16_ctgemm.hip"]
+SOURCES = ["gsd_conv3x3.hip", "gsd_conv3x3_w43.hip", "gsd_conv3x3_w2d.hip", "gsd_convT.hip", "gsd_wgrad.hip", "gsd_wgrad_w43.hip", "gsd_wgrad_w2d.hip", "gsd_wgrad_first.hip", "gsd_pointwise.hip", "gsd_dataset.hip", "gsd_bf16_conv.hip", "gsd_bf16_pointwise.hip", "gsd_bf16_wgrad.hip", "gsd_bf16_first.hip", "gsd_bf16_inc.hip", "gsd_bf16_c64.hip", "gsd_bf16_ctgemm.hip"]
 OUT = os.path.join(CSRC, "libgsd.so")
 STAMP = OUT + ".stamp"      # sha256 of everything the .so was built from (git-ignored, travels with the .so)
 OBJ = os.path.join(CSRC, "obj")

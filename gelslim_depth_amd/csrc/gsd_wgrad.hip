@@ -768,11 +768,36 @@ int gsd_wgrad_w43_use(int N, int H, int W, int Cin, int Cout);
 int64_t gsd_wgrad_w43_workspace(int N, int H, int W, int Cin, int Cout);
 int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw, float* workspace,
                       int64_t workspace_elems, int N, int H, int W, void* stream);
+int gsd_wgrad_w43_reduce_run(const float* workspace, float* dw, int splits, int Cout, int Cin, void* stream);
+// two-dimensional Winograd F(2x4,3x3) form (gsd_wgrad_w2d.hip): chosen per CALL (it needs the row-pitched dy, slack around the
+// activation segments and channel counts that are multiples of its block); same slab layout and reducer as the row form
+int gsd_wgrad_w2d_use(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, int N, int H, int W);
+int64_t gsd_wgrad_w2d_workspace(int N, int H, int W, int Cin, int Cout);
+int gsd_wgrad_w2d_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* workspace, int64_t workspace_elems,
+                      int N, int H, int W, int* splits_out, void* stream);
 
 extern "C" int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const int64_t direct = plan_wgrad(0, N, H, W, Cout, Cin).slab_elems, wino = gsd_wgrad_w43_workspace(N, H, W, Cin, Cout);
-  return direct > wino ? direct : wino;   // either form may serve the call (GSD_WGRAD_ALGO)
+  const int64_t w2d = gsd_wgrad_w2d_workspace(N, H, W, Cin, Cout);
+  const int64_t m = direct > wino ? direct : wino;   // any form may serve the call (GSD_WGRAD_ALGO, GSD_WGRAD_W2D, the operands)
+  return m > w2d ? m : w2d;
+}
+
+int64_t gsd_wgrad_w43_mfma_count(int N, int H, int W, int Cin, int Cout);
+int64_t gsd_wgrad_w2d_mfma_count(int N, int H, int W, int Cin, int Cout);
+
+extern "C" int gsd_conv3x3_wgrad_form(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, int N, int H, int W) {
+  if (!a || !dy || nsrc < 1 || nsrc > 2 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if (!gsd_wgrad_w43_use(N, H, W, Cin, Cout)) return 0;
+  return gsd_wgrad_w2d_use(a, nsrc, dy, Cin, Cout, N, H, W) ? 2 : 1;
+}
+
+extern "C" int64_t gsd_conv3x3_wgrad_mfma_count(int form, int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if (form == 2) return gsd_wgrad_w2d_mfma_count(N, H, W, Cin, Cout);
+  if (form == 1) return gsd_wgrad_w43_mfma_count(N, H, W, Cin, Cout);
+  return 0;
 }
 
 extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw,
@@ -802,8 +827,14 @@ extern "C" int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, 
   GSD_REQUIRE(workspace_elems >= gsd_conv3x3_wgrad_workspace(N, H, W, Cin, Cout), GSD_ERR_WORKSPACE,
               "gsd_conv3x3_wgrad: workspace %lld < %lld elements", (long long)workspace_elems,
               (long long)gsd_conv3x3_wgrad_workspace(N, H, W, Cin, Cout));
-  if (gsd_wgrad_w43_use(N, H, W, Cin, Cout))
+  if (gsd_wgrad_w43_use(N, H, W, Cin, Cout)) {
+    if (gsd_wgrad_w2d_use(a, nsrc, dy, Cin, Cout, N, H, W)) {
+      int splits = 0;
+      if (int e = gsd_wgrad_w2d_run(a, nsrc, dy, Cin, Cout, workspace, workspace_elems, N, H, W, &splits, stream)) return e;
+      return gsd_wgrad_w43_reduce_run(workspace, dw, splits, Cout, Cin, stream);
+    }
     return gsd_wgrad_w43_run(a, nsrc, dy, Cin, Cout, dw, workspace, workspace_elems, N, H, W, stream);
+  }
   WgradPlan pl = plan_wgrad(0, N, H, W, Cout, Cin);
   GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_conv3x3_wgrad: workspace %lld < %lld elements",
               (long long)workspace_elems, (long long)pl.slab_elems);

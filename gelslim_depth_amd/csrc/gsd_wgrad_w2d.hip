@@ -1,0 +1,509 @@
+// gsd_wgrad_w2d.hip -- dW of conv3x3 with the transposed TWO-dimensional Winograd identity F(2x4, 3x3) (gfx950).
+//
+//   dW[co][ci][r][s] = sum_{n,h,w} dy[n,co,h,w] * a[n,ci,h+r-1,w+s-1]
+//
+// (the dW half of aten::convolution_backward for /root/reference/gelslim_depth/models/unet.py:11,14).  The forward identity of
+// gsd_conv3x3_w2d.hip, Y = A2^T[(G2 g G4^T) .* (B2^T d B4)]A4, is linear in g, so for every tile of 2 x 4 outputs
+//
+//   dg = G2^T [ (A2 dY A4^T) .* (B2^T d B4) ] G4
+//
+// with the forward's input transform of the 4 x 6 window d, dY (2 x 4) transformed to 4 x 6, and G2^T . G4 applied once at the
+// very end: 24 products per (co, ci) and 8 pixels instead of 36 in the row form (gsd_wgrad_w43.hip) and 72 in the direct one.
+//
+//   D_f[co][ci] = sum_tiles U_f[co][tile] * V_f[tile][ci]      f = (fr, fc), 24 frequencies
+//
+// GEMM view: M = co, N = ci, K = tiles (4 per v_mfma_f32_16x16x4_f32).  What made this form lose when every wave transformed its
+// own operands (7 vector instructions per MFMA at a 16 x 16 wave tile, 264 registers at 32 x 16) is the
+// transform work, so here it is done ONCE PER BLOCK and shared through LDS:
+//
+//   * a block of 8 waves owns BM x BN = 128 co x 32 ci (or 64 x 64 for the 64-channel layers); a k-step is 4 tiles (32 pixels);
+//   * per k-step every thread takes one or two small transform TASKS on raw values it loaded from global memory into registers
+//     a k-step earlier -- "U" (one (co, tile): two aligned 16-byte pieces of the row-pitched dy -> 24 values, 30 instructions)
+//     and "V row" (one window row of a (ci, tile): 6 floats -> deferred BatchNorm+ReLU -> B4^T row transform; the B2^T column
+//     transform takes the other three rows from the lane's quad by DPP: 36 instructions for 6 values) -- and stores the results
+//     as [tile][channel][24 frequencies] images;
+//   * the MFMA phase of a wave (tile 32 co x 16 ci x 24 frequencies = 192 accumulator registers) reads its operands
+//     frequency-major: one ds_read_b128 is four frequencies of (channel l16, tile j), 18 reads per 48 MFMAs, no vector work;
+//   * two images: the transforms of k-step i+1 are written while k-step i is multiplied, one barrier per k-step.
+//
+// Vector instructions per MFMA: ~1.4 (128 x 32) / ~2 (64 x 64) against 2.7-3.3 in the row form, on two thirds of its MFMAs.
+// Split-K over k-steps with ordered slab reduction (the row form's reducer and slab layout): bitwise reproducible.
+//
+// Conventions: U row 3 is +dY row 1 and V row 3 is d3 - d1 (both signs of the textbook F(2,3) flipped: same products).
+#include "gsd_common.h"
+#include <type_traits>
+
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x2d __attribute__((ext_vector_type(2)));
+
+struct WgW2dParams {
+  SrcD a0, a1;   // activation (B operand), up to two concatenated segments
+  SrcD dy;       // gradient w.r.t. the raw conv output (plain, row pitch % 4 == 0, 16-byte aligned)
+  float* slabs;  // [split][9 = r*3+s][M][Ncols]: G2^T . G4 applied per split
+  int M, Ncols;
+  int N, H, W;
+  int KY, KX, kx_log2;   // tiles of a k-step: KY x KX == 4
+  int tiles_y, tiles_x, sy_n, sx_n;
+  int ksteps_total, splits, mblocks, nblocks;
+};
+
+__device__ __forceinline__ float w2d_dpp(float v, const int ctrl_is_pair) {
+  // quad_perm [2,2,1,1] (0x5A): V column transform partners; quad_perm [1,0,3,2] (0xB1): the other row of a dy pair
+  return ctrl_is_pair ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true))
+                      : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
+}
+
+// NWM x NWN waves of 32 co x 16 ci.  (4,2): 128 co x 32 ci -- U tasks: one (co, tile) per thread, V row tasks: one per thread.
+// (2,4): 64 co x 64 ci -- U tasks split by dy row (the A2 column transform takes the other row by DPP), two V row tasks per thread.
+// PLAIN: no activation segment carries a deferred BatchNorm / ReLU.
+template <int NWM, int NWN, bool PLAIN>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams P) {
+  static_assert(NWM * NWN == 8, "8-wave blocks");
+  constexpr int BM = 32 * NWM, BN = 16 * NWN;
+  constexpr bool UROW = BM == 64;
+  constexpr int NV = BN / 32;
+  constexpr int TSU = BM * 24 + 4, TSV = BN * 24 + 4;   // tile strides: an odd number of 16-byte slots (conflict-free b128 reads)
+  constexpr int BUF = 4 * TSU + 4 * TSV;
+  constexpr int NPC = (UROW ? 1 : 2) + 2 * NV;   // raw 16-byte pieces per thread and k-step
+  constexpr int RAWSZ = NPC * 8 * 256;            // raw staging area in front of the two images: [piece][wave][64 lanes x 4 floats]
+  constexpr int IMG = RAWSZ;                      // first float of image 0
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int j = lane >> 4, l16 = lane & 15;
+
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int per_split = P.mblocks * P.nblocks;
+  const int split = lid / per_split;
+  const int rem = lid - split * per_split;
+  const int mb = rem % P.mblocks, nb = rem / P.mblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+  const int s_begin = (int)((long long)split * P.ksteps_total / P.splits);
+  const int s_end = (int)((long long)(split + 1) * P.ksteps_total / P.splits);
+  const int nst = s_end - s_begin;
+
+  // ---- the block's activation segment (the host guarantees that its BN channels lie in one) ---------------------------------
+  const bool seg1 = P.a1.C > 0 && n0 >= P.a0.C;
+  const float* const S_p = seg1 ? P.a1.p : P.a0.p;
+  const long long S_ns = seg1 ? P.a1.ns : P.a0.ns, S_cs = seg1 ? P.a1.cs : P.a0.cs;
+  const int S_H = seg1 ? P.a1.H : P.a0.H, S_W = seg1 ? P.a1.W : P.a0.W, S_ws = seg1 ? P.a1.ws : P.a0.ws;
+  const int S_oh = seg1 ? P.a1.oh : P.a0.oh, S_ow = seg1 ? P.a1.ow : P.a0.ow;
+  const int S_c0 = n0 - (seg1 ? P.a0.C : 0);   // first channel of the block inside the segment
+
+  // ---- transform tasks of this thread -----------------------------------------------------------------------------------------
+  // (the tile coordinates inside the k-step are needed again in border k-steps only: packed into one register there)
+  const int kxm = P.KX - 1;
+  // U: (co, tile[, dy row])
+  const int u_t = UROW ? (tid >> 1) & 3 : tid & 3;
+  const int u_r = UROW ? tid & 1 : 0;
+  const int u_co = UROW ? tid >> 3 : tid >> 2;
+  const int u_tyl = u_t >> P.kx_log2, u_txl = u_t & kxm;
+  const unsigned u_voff = (unsigned)((long long)u_co * P.dy.cs + (long long)(2 * u_tyl + u_r) * P.dy.ws + 4 * u_txl) * 4u;
+  const unsigned u_wr = (unsigned)(IMG + u_t * TSU + u_co * 24) * 4u;                // byte offsets of the thread's results in image 0
+  // V rows: (ci, tile, window row kr); lane quad = the four rows of one (ci, tile)
+  const int v_kr = tid & 3, v_t = (tid >> 2) & 3, v_ci = tid >> 4;
+  const int v_tyl = v_t >> P.kx_log2, v_txl = v_t & kxm;
+  const unsigned v_voff = (unsigned)((long long)v_ci * S_cs + (long long)(2 * v_tyl + v_kr) * S_ws + 4 * v_txl) * 4u;
+  const unsigned v_wr = (unsigned)(IMG + 4 * TSU + v_t * TSV + v_ci * 24 + v_kr * 6) * 4u;
+  int geo = u_tyl | u_txl << 3 | v_tyl << 6 | v_txl << 9 | v_kr << 12 | u_r << 15;
+  asm volatile("" : "+v"(geo));   // opaque: otherwise hipcc keeps the six fields in six registers for the whole kernel
+  const float v_sgn = (tid & 3) == 1 ? 1.f : -1.f;   // kr0: r0 - r2, kr1: r1 + r2, kr2: r2 - r1, kr3: r3 - r1
+  const float u_sgn = (UROW && (tid & 1)) ? -1.f : 1.f;    // UROW: row 0 forms r0 + r1, row 1 forms r0 - r1
+  float sc[NV], sh[NV];
+  float lo = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    sc[i] = 1.f;
+    sh[i] = 0.f;
+  }
+  if constexpr (!PLAIN) {
+    const SrcD& S = seg1 ? P.a1 : P.a0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cc = S_c0 + v_ci + 32 * i;
+      if (S.scale != nullptr) {
+        sc[i] = S.scale[cc];
+        sh[i] = S.shift[cc];
+      }
+    }
+    if (S.relu) lo = 0.f;
+  }
+
+  // ---- coordinates of the next k-step to LOAD, carried incrementally ---------------------------------------------------------
+  int st_n, st_sy, st_sx;
+  {
+    const int per = P.sy_n * P.sx_n;
+    st_n = s_begin / per;
+    const int rs = s_begin - st_n * per;
+    st_sy = rs / P.sx_n;
+    st_sx = rs - st_sy * P.sx_n;
+  }
+
+  // Raw operands of one k-step: every thread moves ITS OWN pieces (two dy rows of 16 bytes, the 6-float window row as two overlapping
+  // 16-byte pieces: floats 0..3 and 2..5) by LDS-DMA into a private slot -- piece p of wave w occupies 1 KiB at (p * 8 + w) * 256
+  // floats, lane l its bytes [16 l, 16 l + 16) -- and reads them back itself a k-step later: staging through LDS instead of 14
+  // registers held across the MFMA phase (with them the kernel did not fit 256 registers).  Same thread writes and reads: the
+  // only ordering needed is the thread's own vmcnt(0) before the read and the program order read -> next fill.
+  int r_mask = 0;            // edge k-steps: bit 0/1 dy row ok, bits 2..7: window columns of the V tasks ok
+  bool r_edge = false;       // wave-uniform: the masks apply
+  float* const raw_w = smem + wave * 256;                       // this wave's slot of piece 0 (wave-uniform: the DMA's LDS base)
+  const float* const raw_r = smem + wave * 256 + lane * 4;  // this lane's 16 bytes of piece 0
+
+  // Addresses: a wave-uniform 64-bit base that depends on the IMAGE only (the block's first channel plane) plus an unsigned 32-bit
+  // byte offset per lane = (k-step origin, scalar) + (task constant).  A lane whose piece must not be read where it lies takes
+  // offset 0 instead.  (The first form of this code selected between 64-bit pointers per lane and held 14 raw registers across
+  // the MFMA phase; at 256 registers hipcc then spilled the zero-extended offsets on some paths of the branchy prologue only and
+  // reloaded them on all -- wild addresses, a memory fault at the 160x213 level.  No 64-bit vector address selects here, the raw
+  // values wait in LDS, and tests/test_abi.py checks that these kernels use no scratch.)
+  auto load = [&]() __attribute__((always_inline)) {
+    const int n = st_n, ty0 = st_sy * P.KY, tx0 = st_sx * P.KX;
+    if (++st_sx == P.sx_n) {
+      st_sx = 0;
+      if (++st_sy == P.sy_n) {
+        st_sy = 0;
+        ++st_n;
+      }
+    }
+    const char* const dblk = reinterpret_cast<const char*>(P.dy.p + (long long)n * P.dy.ns + (long long)m0 * P.dy.cs);
+    // (the activation base is 4 floats IN FRONT of the plane, inside the slack the caller vouches for: the piece that starts at
+    //  column -1 of row 0 of the block's first channel has offset -4 bytes from the plane, and the offsets are UNSIGNED 32-bit --
+    //  a zero-extended -4 is 4 GiB away: the memory fault of this kernel's first LDS-DMA builds)
+    const char* const vblk = reinterpret_cast<const char*>(S_p + (long long)n * S_ns + (long long)S_c0 * S_cs) - 16;
+    const int hs = 2 * ty0 - 1 - S_oh, wsx = 4 * tx0 - 1 - S_ow;
+    const unsigned d_org = (unsigned)(2 * ty0 * P.dy.ws + 4 * tx0) * 4u;   // k-step origin inside a dy plane, bytes
+    const int v_org = (hs * S_ws + wsx) * 4 + 16;                          // ... from vblk (< 0 only where every lane is masked)
+    const bool tiles_in = ty0 + P.KY <= P.tiles_y && tx0 + P.KX <= P.tiles_x;
+    const bool inside = tiles_in && 2 * (ty0 + P.KY) <= P.H && hs >= 0 && hs + 2 * P.KY + 2 <= S_H && wsx >= 0 &&
+                        wsx + 4 * P.KX + 2 <= S_W;
+    r_edge = !inside;
+    unsigned o_y0 = d_org + u_voff, o_y1 = o_y0 + (unsigned)P.dy.ws * 4u;
+    unsigned o_va = (unsigned)v_org + v_voff;
+    if (!inside) {
+      int m = 0;
+      {
+        const int ty = ty0 + (geo & 7), tx = tx0 + (geo >> 3 & 7);
+        const bool t_ok = ty < P.tiles_y && tx < P.tiles_x;
+        const int h = 2 * ty + (geo >> 15 & 1);
+        const bool ok0 = t_ok && h < P.H, ok1 = t_ok && h + 1 < P.H;
+        o_y0 = ok0 ? o_y0 : 0u;
+        o_y1 = ok1 ? o_y1 : 0u;
+        m = (ok0 ? 1 : 0) | (ok1 ? 2 : 0);
+      }
+      {
+        const int vy = geo >> 6 & 7, vx = geo >> 9 & 7;
+        const int ty = ty0 + vy, tx = tx0 + vx;
+        const bool t_ok = ty < P.tiles_y && tx < P.tiles_x;
+        const int row = hs + 2 * vy + (geo >> 12 & 3), c0 = wsx + 4 * vx;
+        const bool r_ok = t_ok && (unsigned)row < (unsigned)S_H;
+        int cm = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cm |= (r_ok && (unsigned)(c0 + c) < (unsigned)S_W) ? 1 << c : 0;
+        // a 16-byte piece (floats 0..3 / 2..5 of the row) with a valid column lies within 3 floats of the row's ends (slack >= 4);
+        // a piece without one is not read where it lies at all (below)
+        m |= cm << 2;
+      }
+      r_mask = m;
+    }
+    const unsigned o_vc = (r_edge && !(r_mask >> 4 & 15)) ? 0u : o_va + 8u;   // piece of floats 2..5
+    o_va = (r_edge && !(r_mask >> 2 & 15)) ? 0u : o_va;                        // piece of floats 0..3
+    auto fill = [&](const char* base, unsigned off, float* dst) __attribute__((always_inline)) {
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + off), dst, 16, 0, 0);
+    };
+    fill(dblk, o_y0, raw_w);
+    if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const char* const vb2 = vblk + (long long)(32 * i) * S_cs * 4;
+      constexpr int p0 = UROW ? 1 : 2;
+      fill(vb2, o_va, raw_w + (p0 + 2 * i) * 8 * 256);
+      fill(vb2, o_vc, raw_w + (p0 + 2 * i + 1) * 8 * 256);
+    }
+  };
+
+  // transform this thread's raw pieces into LDS image `buf` (compile-time constant)
+  auto transform = [&](auto buf_c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_c)::value;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's fills of the k-step have landed (written out: gsd_common.h)
+    // ---- U ----
+    {
+      f32x4 y0 = *reinterpret_cast<const f32x4*>(raw_r), y1 = y0;
+      if constexpr (!UROW) y1 = *reinterpret_cast<const f32x4*>(raw_r + 8 * 256);
+      if (r_edge) {
+        if (!(r_mask & 1)) y0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!UROW)
+          if (!(r_mask & 2)) y1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float p0[6];
+      {
+        const float p = y0[0] + y0[2], q = y0[1] + y0[3];
+        const float a = fmaf(4.f, y0[2], y0[0]), b = 2.f * fmaf(4.f, y0[3], y0[1]);
+        p0[0] = y0[0]; p0[1] = p + q; p0[2] = p - q; p0[3] = a + b; p0[4] = a - b; p0[5] = y0[3];
+      }
+      if constexpr (UROW) {
+        // this lane holds A4 of ONE dy row; rows kr of U = [r0, r0 + r1, r0 - r1, r1]: lane r = 0 stores (own, own + x) at
+        // frequencies 0..11, lane r = 1 stores (x - own, own) at 12..23
+        float t1[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t1[c] = fmaf(p0[c], u_sgn, w2d_dpp(p0[c], 1));
+        float* const o_own = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF + ((tid & 1) ? 18 : 0);
+        float* const o_t1 = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF + ((tid & 1) ? 12 : 6);
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          *reinterpret_cast<f32x2d*>(o_own + c) = f32x2d{p0[c], p0[c + 1]};
+          *reinterpret_cast<f32x2d*>(o_t1 + c) = f32x2d{t1[c], t1[c + 1]};
+        }
+      } else {
+        float p1[6];
+        {
+          const float p = y1[0] + y1[2], q = y1[1] + y1[3];
+          const float a = fmaf(4.f, y1[2], y1[0]), b = 2.f * fmaf(4.f, y1[3], y1[1]);
+          p1[0] = y1[0]; p1[1] = p + q; p1[2] = p - q; p1[3] = a + b; p1[4] = a - b; p1[5] = y1[3];
+        }
+        // rows fr of U = [r0, r0 + r1, r0 - r1, r1], stored as the six 16-byte groups of 24 consecutive frequencies
+        float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF;
+        *reinterpret_cast<f32x4*>(op) = f32x4{p0[0], p0[1], p0[2], p0[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{p0[4], p0[5], p0[0] + p1[0], p0[1] + p1[1]};
+        *reinterpret_cast<f32x4*>(op + 8) = f32x4{p0[2] + p1[2], p0[3] + p1[3], p0[4] + p1[4], p0[5] + p1[5]};
+        *reinterpret_cast<f32x4*>(op + 12) = f32x4{p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2], p0[3] - p1[3]};
+        *reinterpret_cast<f32x4*>(op + 16) = f32x4{p0[4] - p1[4], p0[5] - p1[5], p1[0], p1[1]};
+        *reinterpret_cast<f32x4*>(op + 20) = f32x4{p1[2], p1[3], p1[4], p1[5]};
+      }
+    }
+    // ---- V rows ----
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      constexpr int p0 = UROW ? 1 : 2;
+      const f32x4 ra = *reinterpret_cast<const f32x4*>(raw_r + (p0 + 2 * i) * 8 * 256);
+      const f32x2d rb = *reinterpret_cast<const f32x2d*>(raw_r + (p0 + 2 * i + 1) * 8 * 256 + 2);
+      float d[6] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1]};
+      if constexpr (!PLAIN) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[c] = fmaxf(fmaf(d[c], sc[i], sh[i]), lo);
+      }
+      if (r_edge) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if (!(r_mask >> (2 + c) & 1)) d[c] = 0.f;
+      }
+      float v[6];
+      {
+        const float a = fmaf(-4.f, d[2], d[4]), b = fmaf(-4.f, d[1], d[3]);
+        const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+        v[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+        v[1] = a + b;
+        v[2] = a - b;
+        v[3] = c + e;
+        v[4] = c - e;
+        v[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+      }
+      float o[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) o[c] = fmaf(v_sgn, w2d_dpp(v[c], 0), v[c]);
+      float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + v_wr) + buf * BUF + i * (32 * 24);
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) *reinterpret_cast<f32x2d*>(op + c) = f32x2d{o[c], o[c + 1]};
+    }
+  };
+
+  f32x4 acc[2][24];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int f = 0; f < 24; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_rd = IMG + j * TSU + (wm * 32 + l16) * 24;
+  const int b_rd = IMG + 4 * TSU + j * TSV + (wn * 16 + l16) * 24;
+
+  // One operand group = four frequencies of (channel l16, tile j) per ds_read_b128: 3 reads feed 8 MFMAs.  The groups are NOT
+  // double-buffered in the source: 12 operand registers instead of 24 keep the kernel inside 256 registers without scratch, and the
+  // SIMD's other wave multiplies while this one waits for its reads.
+  auto multiply = [&](auto buf_c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(buf_c)::value;
+    const float* const Sb = smem + buf * BUF;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 4 * g);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 16 * 24 + 4 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Sb + b_rd + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0][4 * g + e] = mfma16(a0[e], b[e], acc[0][4 * g + e]);
+        acc[1][4 * g + e] = mfma16(a1[e], b[e], acc[1][4 * g + e]);
+      }
+    }
+  };
+
+  // ---- pipeline: image (it & 1) holds the transforms of k-step `it`; the raw registers hold k-step it + 1 ---------------------
+  if (nst > 0) {
+    load();
+    transform(std::integral_constant<int, 0>{});
+    if (nst > 1) load();
+    __syncthreads();
+    auto step = [&](const int it, auto cur_c) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_c)::value;
+      if (it + 1 < nst) transform(std::integral_constant<int, cur ^ 1>{});
+      __builtin_amdgcn_sched_barrier(0);   // (phases in program order: the register budget is 192 accumulators + one phase's values)
+      if (it + 2 < nst) load();
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(cur_c);
+      __syncthreads();
+    };
+    for (int it = 0; it < nst; it += 2) {
+      step(it, std::integral_constant<int, 0>{});
+      if (it + 1 < nst) step(it + 1, std::integral_constant<int, 1>{});
+    }
+  }
+
+  // ---- epilogue: G4 along fc, G2^T along fr, per split (linear: the slab reduction only adds) ---------------------------------
+  const size_t pl = (size_t)P.M * P.Ncols;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int mr = m0 + wm * 32 + m * 16 + j * 4 + reg;
+      const int col = n0 + wn * 16 + l16;
+      float E[4][3];
+#pragma unroll
+      for (int fr = 0; fr < 4; ++fr) {
+        const float D0 = acc[m][fr * 6 + 0][reg], D1 = acc[m][fr * 6 + 1][reg], D2 = acc[m][fr * 6 + 2][reg];
+        const float D3 = acc[m][fr * 6 + 3][reg], D4 = acc[m][fr * 6 + 4][reg], D5 = acc[m][fr * 6 + 5][reg];
+        E[fr][0] = 0.25f * D0 - (1.f / 6.f) * (D1 + D2) + (1.f / 24.f) * (D3 + D4);
+        E[fr][1] = (1.f / 6.f) * (D2 - D1) + (1.f / 12.f) * (D3 - D4);
+        E[fr][2] = (1.f / 6.f) * (D3 + D4 - D1 - D2) + D5;
+      }
+      float* const o = P.slabs + ((size_t)split * 9 * P.M + mr) * P.Ncols + col;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const float h = 0.5f * (E[1][s] + E[2][s]);
+        o[(0 * 3 + s) * pl] = E[0][s] + h;
+        o[(1 * 3 + s) * pl] = 0.5f * (E[1][s] - E[2][s]);
+        o[(2 * 3 + s) * pl] = h + E[3][s];
+      }
+    }
+}
+
+namespace {
+
+struct WgW2dPlan {
+  int KY, KX, kx_log2, tiles_y, tiles_x, sy_n, sx_n, BM, BN, mblocks, nblocks, ksteps_total, splits;
+  int64_t slab_elems;
+  bool ok;
+};
+
+WgW2dPlan plan_wg2d(int N, int H, int W, int M, int Ncols) {
+  WgW2dPlan p;
+  p.tiles_y = ceil_div(H, 2);
+  p.tiles_x = ceil_div(W, 4);
+  long best = -1;
+  const int force_kx = gsd_env_int("GSD_WG2D_KX", 0);   // tuning
+  for (int kx = 4; kx >= 1; kx /= 2) {                  // ties go to the wider k-step (longer contiguous runs)
+    if (force_kx && kx != force_kx) continue;
+    const int ky = 4 / kx;
+    const long steps = (long)ceil_div(p.tiles_y, ky) * ceil_div(p.tiles_x, kx);
+    if (best < 0 || steps < best) {
+      best = steps;
+      p.KY = ky; p.KX = kx;
+    }
+  }
+  p.kx_log2 = p.KX == 4 ? 2 : p.KX == 2 ? 1 : 0;
+  p.sy_n = ceil_div(p.tiles_y, p.KY);
+  p.sx_n = ceil_div(p.tiles_x, p.KX);
+  p.BM = M >= 128 ? 128 : 64;
+  p.BN = p.BM == 128 ? 32 : 64;
+  p.ok = M % p.BM == 0 && Ncols % p.BN == 0;
+  p.mblocks = ceil_div(M, p.BM);
+  p.nblocks = ceil_div(Ncols, p.BN);
+  p.ksteps_total = N * p.sy_n * p.sx_n;
+  const int target = gsd_env_int("GSD_WG2D_BLOCKS", 256);   // one block per CU
+  int splits = ceil_div(target, p.mblocks * p.nblocks);
+  if (splits > p.ksteps_total) splits = p.ksteps_total;
+  if (splits > 2048) splits = 2048;
+  if (splits < 1) splits = 1;
+  p.splits = splits;
+  p.slab_elems = (int64_t)splits * 9 * M * Ncols;
+  return p;
+}
+
+}  // namespace
+
+// floats of slab scratch the 2-D form wants for a shape (0: the shape is not served)
+int64_t gsd_wgrad_w2d_workspace(int N, int H, int W, int Cin, int Cout) {
+  const WgW2dPlan p = plan_wg2d(N, H, W, Cout, Cin);
+  return p.ok ? p.slab_elems : 0;
+}
+
+// MFMA instructions of one launch: k-steps x 24 frequencies per (16 co x 16 ci) pair
+int64_t gsd_wgrad_w2d_mfma_count(int N, int H, int W, int Cin, int Cout) {
+  const WgW2dPlan p = plan_wg2d(N, H, W, Cout, Cin);
+  return p.ok ? (int64_t)p.ksteps_total * 24 * (Cout / 16) * (Cin / 16) : 0;
+}
+
+// 1: the arguments admit the 2-D form (shape, segment geometry, alignment, slack); GSD_WGRAD_W2D=0 switches it off
+int gsd_wgrad_w2d_use(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, int N, int H, int W) {
+  if (gsd_env_int("GSD_WGRAD_W2D", 1) == 0) return 0;
+  const WgW2dPlan p = plan_wg2d(N, H, W, Cout, Cin);
+  if (!p.ok) return 0;
+  if (dy->w_stride % 4 != 0 || ((uintptr_t)dy->ptr & 15) != 0 || dy->c_stride % 4 != 0 || dy->n_stride % 4 != 0) return 0;
+  if (dy->w_stride < 4 * p.tiles_x) return 0;
+  if ((int64_t)p.BM * dy->c_stride * 4 >= (1LL << 31)) return 0;
+  if (nsrc == 2 && a[0].C % p.BN != 0) return 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (a[i].slack < 4) return 0;
+    if ((int64_t)p.BN * a[i].c_stride * 4 >= (1LL << 31)) return 0;
+  }
+  return 1;
+}
+
+// arguments already validated by gsd_conv3x3_wgrad and gsd_wgrad_w2d_use
+int gsd_wgrad_w2d_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* workspace, int64_t workspace_elems,
+                      int N, int H, int W, int* splits_out, void* stream) {
+  const WgW2dPlan pl = plan_wg2d(N, H, W, Cout, Cin);
+  GSD_REQUIRE(pl.ok, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad (w2d): shape not served");
+  GSD_REQUIRE(workspace_elems >= pl.slab_elems, GSD_ERR_WORKSPACE, "gsd_conv3x3_wgrad: workspace %lld < %lld elements",
+              (long long)workspace_elems, (long long)pl.slab_elems);
+  WgW2dParams P;
+  P.a0 = to_srcd(a[0]);
+  P.a1 = nsrc > 1 ? to_srcd(a[1]) : null_srcd();
+  P.dy = to_srcd(*dy);
+  P.slabs = workspace;
+  P.M = Cout; P.Ncols = Cin;
+  P.N = N; P.H = H; P.W = W;
+  P.KY = pl.KY; P.KX = pl.KX; P.kx_log2 = pl.kx_log2;
+  P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.sy_n = pl.sy_n; P.sx_n = pl.sx_n;
+  P.ksteps_total = pl.ksteps_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
+  bool plain = true;
+  for (int i = 0; i < nsrc; ++i) plain = plain && a[i].scale == nullptr && a[i].relu == 0;
+  const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
+  const int npc = (pl.BM == 64 ? 1 : 2) + 2 * (pl.BN / 32);   // raw pieces per thread (kernel: NPC)
+  const size_t lds = ((size_t)2 * (4 * (pl.BM * 24 + 4) + 4 * (pl.BN * 24 + 4)) + (size_t)npc * 8 * 256) * sizeof(float);
+  if (gsd_env_set("GSD_WG43_TRACE"))   // tuning: one line per launch
+    fprintf(stderr, "wg2d M%d N%d %dx%d B%d kstep %dx%d ksteps %d splits %d blocks %ld BM %d BN %d plain %d lds %zu\n", Cout, Cin, H, W,
+            N, pl.KY, pl.KX, pl.ksteps_total, pl.splits, grid, pl.BM, pl.BN, (int)plain, lds);
+  const dim3 g((int)grid);
+  const hipStream_t st = (hipStream_t)stream;
+#define WG2D_LAUNCH(NWM_, NWN_, PL_)                                                                              \
+  do {                                                                                                            \
+    static gsd_attr_once once;                                                                                    \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w2d_kernel<NWM_, NWN_, PL_>);                        \
+    if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                            \
+      gsd_set_error("gsd_conv3x3_wgrad (w2d): hipFuncSetAttribute: %s", hipGetErrorString(e));                    \
+      return GSD_ERR_HIP;                                                                                         \
+    }                                                                                                             \
+    hipLaunchKernelGGL((wgrad3x3_w2d_kernel<NWM_, NWN_, PL_>), g, dim3(512), lds, st, P);                         \
+  } while (0)
+  if (pl.BM == 128) {
+    if (plain) WG2D_LAUNCH(4, 2, true);
+    else WG2D_LAUNCH(4, 2, false);
+  } else {
+    if (plain) WG2D_LAUNCH(2, 4, true);
+    else WG2D_LAUNCH(2, 4, false);
+  }
+#undef WG2D_LAUNCH
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w2d)");
+  *splits_out = pl.splits;
+  return GSD_OK;
+}

@@ -865,7 +865,30 @@ extern "C" int gsd_conv3x3_wgrad_takes_pitched_dy(int N, int H, int W, int Cin, 
   return gsd_wgrad_w43_use(N, H, W, Cin, Cout);
 }
 
+// MFMA instructions of one launch: stages x 18 frequencies-rows x 16 tiles / 4 per (16 co x 16 ci) pair of the padded blocks
+int64_t gsd_wgrad_w43_mfma_count(int N, int H, int W, int Cin, int Cout) {
+  const WgW43Plan p = plan_wg43(N, H, W, Cout, Cin);
+  return (int64_t)p.stages_total * 72 * (p.mblocks * p.BM / 16) * (p.nblocks * p.BN / 16);
+}
+
 int64_t gsd_wgrad_w43_workspace(int N, int H, int W, int Cin, int Cout) { return plan_wg43(N, H, W, Cout, Cin).slab_elems; }
+
+// slab[split][9][Cout][Cin] -> dW (Cout,Cin,3,3): the ordered split sum, shared with the 2-D form (gsd_wgrad_w2d.hip)
+int gsd_wgrad_w43_reduce_run(const float* workspace, float* dw, int splits, int Cout, int Cin, void* stream) {
+  const long long per = 3LL * Cout * Cin;
+  if (splits >= 64) {
+    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<16>, dim3(rgrid), dim3(1024), 0, (hipStream_t)stream, workspace, dw, splits, Cout, Cin);
+  } else if (splits >= 8) {
+    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<4>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, splits, Cout, Cin);
+  } else {
+    const int rgrid = (int)(ceil_div64(per, 256) < 8192 ? ceil_div64(per, 256) : 8192);
+    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<1>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, splits, Cout, Cin);
+  }
+  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43) reduce");
+  return GSD_OK;
+}
 
 // arguments already validated by gsd_conv3x3_wgrad
 int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, float* dw, float* workspace,
@@ -971,17 +994,5 @@ int gsd_wgrad_w43_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   }
 #undef WG43_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43)");
-  const long long per = 3LL * Cout * Cin;
-  if (pl.splits >= 64) {
-    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
-    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<16>, dim3(rgrid), dim3(1024), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
-  } else if (pl.splits >= 8) {
-    const int rgrid = (int)(ceil_div64(per, 64) < 8192 ? ceil_div64(per, 64) : 8192);
-    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<4>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
-  } else {
-    const int rgrid = (int)(ceil_div64(per, 256) < 8192 ? ceil_div64(per, 256) : 8192);
-    hipLaunchKernelGGL(wgrad_w43_reduce_kernel<1>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, workspace, dw, pl.splits, Cout, Cin);
-  }
-  GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w43) reduce");
-  return GSD_OK;
+  return gsd_wgrad_w43_reduce_run(workspace, dw, pl.splits, Cout, Cin, stream);
 }

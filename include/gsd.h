@@ -244,6 +244,13 @@ int64_t gsd_conv3x3_wgrad_workspace(int N, int H, int W, int Cin, int Cout);
 int gsd_conv3x3_wgrad(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout,
                       float* dw, float* workspace, int64_t workspace_elems,
                       int N, int H, int W, void* stream);
+/* Which arithmetic form gsd_conv3x3_wgrad takes for exactly these operands: 0 direct taps, 1 Winograd F(4,3) along rows,
+ * 2 the two-dimensional F(2x4,3x3) form dg = G2^T[(A2 dY A4^T).(B2^T d B4)]G4 (a third of the direct form's MFMA work; it needs
+ * Cout % 128 == 0 or Cout == 64, Cin a multiple of its 32/64-channel block, a dy with 16-byte aligned rows (w_stride % 4 == 0,
+ * pad columns 0) and slack >= 4 around every activation segment; GSD_WGRAD_W2D=0 switches it off).  Reads no device memory.
+ * gsd_conv3x3_wgrad_mfma_count: v_mfma_f32_16x16x4_f32 instructions that form executes (tile padding included). */
+int gsd_conv3x3_wgrad_form(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, int Cout, int N, int H, int W);
+int64_t gsd_conv3x3_wgrad_mfma_count(int form, int N, int H, int W, int Cin, int Cout);
 /* 1 when gsd_conv3x3_wgrad serves this shape with a kernel that takes a pitched dy (dy->w_stride > W, see gsd_src). */
 int gsd_conv3x3_wgrad_takes_pitched_dy(int N, int H, int W, int Cin, int Cout);
 /* dW of a conv3x3 with FEW input channels (Cin * 9 <= 32: the network's first layer, unet.py:15) with the BatchNorm

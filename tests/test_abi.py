@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import REPO
 
 
@@ -210,3 +212,23 @@ def test_guard_struct_and_bench_self_launch_refuses_cleanly():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "one per GPU" in r.stderr and "Traceback" not in r.stderr and r.stdout.strip() == ""
+
+
+def test_wgrad_w2d_kernels_use_no_scratch():
+    """gsd_wgrad_w2d.hip lives at the 256-register limit of two waves per SIMD.  Its first form spilled, and hipcc stored two spill
+    slots on some paths of a branchy prologue only while reloading them on every path (wild global addresses, a memory fault at
+    the 160x213 level).  The kernels are written to need no scratch; this keeps it that way (device-only compile, ~6 s)."""
+    import re
+    import shutil
+    import subprocess
+    from gelslim_depth_amd import build as b
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this machine")
+    r = subprocess.run([hipcc] + b.CFLAGS + [f"-I{b.INCLUDE}", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c",
+                        os.path.join(b.CSRC, "gsd_wgrad_w2d.hip"), "-o", os.devnull], capture_output=True, text=True, check=True)
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    kernels = {n: s for n, s in zip(names, scratch) if "wgrad3x3_w2d_kernel" in n}
+    assert len(kernels) >= 4, r.stderr[-2000:]
+    assert all(v == 0 for v in kernels.values()), kernels
