@@ -38,6 +38,13 @@
 
 typedef float f32x2d __attribute__((ext_vector_type(2)));
 
+// Diagnostic builds only (-DWG2D_ABL=mask via profiles/build_diag_one.sh; never in the product library; results are then garbage):
+// 1 no MFMAs, 2 no LDS-DMA fills after the first two k-steps, 4 no transform after the first two, 8 no operand reads, 16 no barrier,
+// 32 no dy fills, 64 no window fills, 128 every fill reads offset 0 (issue cost without the memory system's)
+#ifndef WG2D_ABL
+#define WG2D_ABL 0
+#endif
+
 struct WgW2dParams {
   SrcD a0, a1;   // activation (B operand), up to two concatenated segments
   SrcD dy;       // gradient w.r.t. the raw conv output (plain, row pitch % 4 == 0, 16-byte aligned)
@@ -46,6 +53,7 @@ struct WgW2dParams {
   int N, H, W;
   int KY, KX, kx_log2;   // tiles of a k-step: KY x KX == 4
   int tiles_y, tiles_x, sy_n, sx_n;
+  int WR, NP, NI;        // window of a k-step: 2 KY + 2 rows x KX + 1 pieces of 4 floats per channel; NI 64-piece fills per block
   int ksteps_total, splits, mblocks, nblocks;
 };
 
@@ -66,9 +74,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
   constexpr int NV = BN / 32;
   constexpr int TSU = BM * 24 + 4, TSV = BN * 24 + 4;   // tile strides: an odd number of 16-byte slots (conflict-free b128 reads)
   constexpr int BUF = 4 * TSU + 4 * TSV;
-  constexpr int NPC = (UROW ? 1 : 2) + 2 * NV;   // raw 16-byte pieces per thread and k-step
-  constexpr int RAWSZ = NPC * 8 * 256;            // raw staging area in front of the two images: [piece][wave][64 lanes x 4 floats]
-  constexpr int IMG = RAWSZ;                      // first float of image 0
+  constexpr int NPD = UROW ? 1 : 2;               // dy pieces per thread and k-step (private slots: [piece][wave][64 lanes x 4 floats])
+  constexpr int WINI = BN == 32 ? 10 : 20;        // window image of the block's BN channels: at most BN * 20 pieces = WINI fills of 1 KiB
+  constexpr int KB = BN == 32 ? 2 : 3;            // window fills per wave at most
+  constexpr int WIN = NPD * 8 * 256;              // first float of the window image
+  constexpr int IMG = WIN + 2 * WINI * 256;       // first float of image 0 (two window images: k-step parity, like the images)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -107,30 +117,25 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
   // V rows: (ci, tile, window row kr); lane quad = the four rows of one (ci, tile)
   const int v_kr = tid & 3, v_t = (tid >> 2) & 3, v_ci = tid >> 4;
   const int v_tyl = v_t >> P.kx_log2, v_txl = v_t & kxm;
-  const unsigned v_voff = (unsigned)((long long)v_ci * S_cs + (long long)(2 * v_tyl + v_kr) * S_ws + 4 * v_txl) * 4u;
+  const unsigned v_rd = (unsigned)(WIN + ((v_ci * P.WR + 2 * v_tyl + v_kr) * P.NP + v_txl) * 4) * 4u;   // its 6 floats in the window image
   const unsigned v_wr = (unsigned)(IMG + 4 * TSU + v_t * TSV + v_ci * 24 + v_kr * 6) * 4u;
-  int geo = u_tyl | u_txl << 3 | v_tyl << 6 | v_txl << 9 | v_kr << 12 | u_r << 15;
-  asm volatile("" : "+v"(geo));   // opaque: otherwise hipcc keeps the six fields in six registers for the whole kernel
+  int geo_packed = u_tyl | u_txl << 3 | v_tyl << 6 | v_txl << 9 | v_kr << 12 | u_r << 15;
+  asm volatile("" : "+v"(geo_packed));   // opaque: otherwise hipcc keeps the six fields in six registers for the whole kernel
   const float v_sgn = (tid & 3) == 1 ? 1.f : -1.f;   // kr0: r0 - r2, kr1: r1 + r2, kr2: r2 - r1, kr3: r3 - r1
   const float u_sgn = (UROW && (tid & 1)) ? -1.f : 1.f;    // UROW: row 0 forms r0 + r1, row 1 forms r0 - r1
-  float sc[NV], sh[NV];
+  // deferred BatchNorm of the block's BN channels: (scale, shift) pairs in LDS behind the images, read per task and k-step (one
+  // ds_read_b64 instead of two registers per task held for the whole kernel; the kernel lives at the register limit)
+  constexpr int SCS = IMG + 2 * BUF;
   float lo = -__builtin_inff();
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    sc[i] = 1.f;
-    sh[i] = 0.f;
-  }
   if constexpr (!PLAIN) {
     const SrcD& S = seg1 ? P.a1 : P.a0;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cc = S_c0 + v_ci + 32 * i;
-      if (S.scale != nullptr) {
-        sc[i] = S.scale[cc];
-        sh[i] = S.shift[cc];
-      }
+    if (tid < BN) {
+      f32x2d v = f32x2d{1.f, 0.f};
+      if (S.scale != nullptr) v = f32x2d{S.scale[S_c0 + tid], S.shift[S_c0 + tid]};
+      *reinterpret_cast<f32x2d*>(smem + SCS + 2 * tid) = v;
     }
     if (S.relu) lo = 0.f;
+    // (published by the first barrier of the pipeline below)
   }
 
   // ---- coordinates of the next k-step to LOAD, carried incrementally ---------------------------------------------------------
@@ -143,15 +148,35 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     st_sx = rs - st_sy * P.sx_n;
   }
 
-  // Raw operands of one k-step: every thread moves ITS OWN pieces (two dy rows of 16 bytes, the 6-float window row as two overlapping
-  // 16-byte pieces: floats 0..3 and 2..5) by LDS-DMA into a private slot -- piece p of wave w occupies 1 KiB at (p * 8 + w) * 256
-  // floats, lane l its bytes [16 l, 16 l + 16) -- and reads them back itself a k-step later: staging through LDS instead of 14
-  // registers held across the MFMA phase (with them the kernel did not fit 256 registers).  Same thread writes and reads: the
-  // only ordering needed is the thread's own vmcnt(0) before the read and the program order read -> next fill.
+  // Raw operands of one k-step wait in LDS (by LDS-DMA), not in registers (14 of them held across the MFMA phase did not fit 256):
+  //   * dy: every thread moves ITS OWN pieces (one or two rows of 16 bytes) into a private slot -- piece p of wave w occupies 1 KiB
+  //     at (p * 8 + w) * 256 floats, lane l its bytes [16 l, 16 l + 16) -- and reads them back itself a k-step later: the only
+  //     ordering needed is the thread's own vmcnt(0) before the read, and program order read -> next fill;
+  //   * activation windows: ONE image per block and k-step, [channel][window row][piece of 4 floats], the halo shared by the tiles
+  //     of the k-step (80 instead of 128 bytes per row at 1 x 4 tiles) and moved as runs of consecutive pieces by consecutive lanes
+  //     (fill i = pieces 64 i .. 64 i + 63 of the image, wave w issues fills w, w + 8, ...).  Another wave's pieces are read, so
+  //     there are two window images (k-step parity) and the fills are published by the k-step's barrier (vmcnt(0) in front of it).
   int r_mask = 0;            // edge k-steps: bit 0/1 dy row ok, bits 2..7: window columns of the V tasks ok
   bool r_edge = false;       // wave-uniform: the masks apply
   float* const raw_w = smem + wave * 256;                       // this wave's slot of piece 0 (wave-uniform: the DMA's LDS base)
   const float* const raw_r = smem + wave * 256 + lane * 4;  // this lane's 16 bytes of piece 0
+  // window fills of this wave: piece 64 (wave + 8 k) + lane = (channel, window row, piece) -> byte offset from the k-step's window
+  // origin in the first channel's plane; row and piece packed for border k-steps (-1: a dummy lane behind the image)
+  unsigned x_off[KB];
+  int x_meta = 0;   // 8 bits per fill: window row | piece << 4 | dummy << 7
+  {
+    const int per_ch = P.WR * P.NP;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int pid = 64 * (wave + 8 * k) + lane;
+      const int ch = pid / per_ch, rem = pid - ch * per_ch;
+      const int wr = rem / P.NP, pp = rem - wr * P.NP;
+      const bool dummy = ch >= BN;
+      x_off[k] = dummy ? 0u : (unsigned)((long long)ch * S_cs + (long long)wr * S_ws + 4 * pp) * 4u;
+      x_meta |= (dummy ? 128 : (wr | pp << 4)) << (8 * k);
+    }
+    asm volatile("" : "+v"(x_meta));
+  }
 
   // Addresses: a wave-uniform 64-bit base that depends on the IMAGE only (the block's first channel plane) plus an unsigned 32-bit
   // byte offset per lane = (k-step origin, scalar) + (task constant).  A lane whose piece must not be read where it lies takes
@@ -159,7 +184,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
   // the MFMA phase; at 256 registers hipcc then spilled the zero-extended offsets on some paths of the branchy prologue only and
   // reloaded them on all -- wild addresses, a memory fault at the 160x213 level.  No 64-bit vector address selects here, the raw
   // values wait in LDS, and tests/test_abi.py checks that these kernels use no scratch.)
-  auto load = [&]() __attribute__((always_inline)) {
+  auto load = [&](auto wb_c) __attribute__((always_inline)) {
+    constexpr int wb = decltype(wb_c)::value;   // window image of the k-step (its parity inside the block's range)
     const int n = st_n, ty0 = st_sy * P.KY, tx0 = st_sx * P.KX;
     if (++st_sx == P.sx_n) {
       st_sx = 0;
@@ -181,9 +207,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
                         wsx + 4 * P.KX + 2 <= S_W;
     r_edge = !inside;
     unsigned o_y0 = d_org + u_voff, o_y1 = o_y0 + (unsigned)P.dy.ws * 4u;
-    unsigned o_va = (unsigned)v_org + v_voff;
     if (!inside) {
       int m = 0;
+      int geo = geo_packed;
+      asm volatile("" : "+v"(geo));   // (as x_meta below)
       {
         const int ty = ty0 + (geo & 7), tx = tx0 + (geo >> 3 & 7);
         const bool t_ok = ty < P.tiles_y && tx < P.tiles_x;
@@ -202,32 +229,42 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
         int cm = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) cm |= (r_ok && (unsigned)(c0 + c) < (unsigned)S_W) ? 1 << c : 0;
-        // a 16-byte piece (floats 0..3 / 2..5 of the row) with a valid column lies within 3 floats of the row's ends (slack >= 4);
-        // a piece without one is not read where it lies at all (below)
         m |= cm << 2;
       }
       r_mask = m;
     }
-    const unsigned o_vc = (r_edge && !(r_mask >> 4 & 15)) ? 0u : o_va + 8u;   // piece of floats 2..5
-    o_va = (r_edge && !(r_mask >> 2 & 15)) ? 0u : o_va;                        // piece of floats 0..3
     auto fill = [&](const char* base, unsigned off, float* dst) __attribute__((always_inline)) {
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + off), dst, 16, 0, 0);
     };
-    fill(dblk, o_y0, raw_w);
-    if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
+    if constexpr (WG2D_ABL & 128) o_y0 = o_y1 = 0u;
+    if constexpr (!(WG2D_ABL & 32)) {
+      fill(dblk, o_y0, raw_w);
+      if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
+    }
+    // window pieces: one with a column inside the segment lies within 3 floats of its row's ends (slack >= 4) and is read where it
+    // lies, partly outside or not (the transform masks by column); one without is not read where it lies (offset 0)
+    if constexpr (!(WG2D_ABL & 64)) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const char* const vb2 = vblk + (long long)(32 * i) * S_cs * 4;
-      constexpr int p0 = UROW ? 1 : 2;
-      fill(vb2, o_va, raw_w + (p0 + 2 * i) * 8 * 256);
-      fill(vb2, o_vc, raw_w + (p0 + 2 * i + 1) * 8 * 256);
+      for (int k = 0; k < KB; ++k)
+        if (wave + 8 * k < P.NI) {
+          unsigned off = (unsigned)v_org + x_off[k];
+          if (!inside) {
+            int mt = x_meta;
+            asm volatile("" : "+v"(mt));   // (unpacked HERE, in border k-steps only: hipcc would hoist the fields out of the loop into registers)
+            mt >>= 8 * k;
+            const int row = hs + (mt & 15), c0 = wsx + 4 * (mt >> 4 & 7);
+            const bool ok = !(mt & 128) && (unsigned)row < (unsigned)S_H && c0 + 3 >= 0 && c0 < S_W;
+            off = ok ? off : 0u;
+          }
+          if constexpr (WG2D_ABL & 128) off = 0u;
+          fill(vblk, off, smem + WIN + wb * (WINI * 256) + (wave + 8 * k) * 256);
+        }
     }
   };
 
   // transform this thread's raw pieces into LDS image `buf` (compile-time constant)
   auto transform = [&](auto buf_c) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_c)::value;
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this thread's fills of the k-step have landed (written out: gsd_common.h)
     // ---- U ----
     {
       f32x4 y0 = *reinterpret_cast<const f32x4*>(raw_r), y1 = y0;
@@ -276,13 +313,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     // ---- V rows ----
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      constexpr int p0 = UROW ? 1 : 2;
-      const f32x4 ra = *reinterpret_cast<const f32x4*>(raw_r + (p0 + 2 * i) * 8 * 256);
-      const f32x2d rb = *reinterpret_cast<const f32x2d*>(raw_r + (p0 + 2 * i + 1) * 8 * 256 + 2);
+      const float* const wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + v_rd) + buf * (WINI * 256) + i * 32 * (P.WR * P.NP * 4);
+      const f32x4 ra = *reinterpret_cast<const f32x4*>(wp);
+      const f32x2d rb = *reinterpret_cast<const f32x2d*>(wp + 4);
       float d[6] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1]};
       if constexpr (!PLAIN) {
+        const f32x2d ss = *reinterpret_cast<const f32x2d*>(smem + SCS + 2 * ((tid >> 4) + 32 * i));
 #pragma unroll
-        for (int c = 0; c < 6; ++c) d[c] = fmaxf(fmaf(d[c], sc[i], sh[i]), lo);
+        for (int c = 0; c < 6; ++c) d[c] = fmaxf(fmaf(d[c], ss[0], ss[1]), lo);
       }
       if (r_edge) {
 #pragma unroll
@@ -326,46 +364,65 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     const float* const Sb = smem + buf * BUF;
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 4 * g);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 16 * 24 + 4 * g);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(Sb + b_rd + 4 * g);
+      f32x4 a0, a1, b;
+      if constexpr (WG2D_ABL & 8) {
+        a0 = a1 = b = f32x4{1.f, 2.f, 3.f, (float)g};
+      } else {
+        a0 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 4 * g);
+        a1 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 16 * 24 + 4 * g);
+        b = *reinterpret_cast<const f32x4*>(Sb + b_rd + 4 * g);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc[0][4 * g + e] = mfma16(a0[e], b[e], acc[0][4 * g + e]);
-        acc[1][4 * g + e] = mfma16(a1[e], b[e], acc[1][4 * g + e]);
+        if constexpr (WG2D_ABL & 1) {
+          acc[0][4 * g + e][e] += a0[e] * b[e];
+          acc[1][4 * g + e][e] += a1[e] * b[e];
+        } else {
+          acc[0][4 * g + e] = mfma16(a0[e], b[e], acc[0][4 * g + e]);
+          acc[1][4 * g + e] = mfma16(a1[e], b[e], acc[1][4 * g + e]);
+        }
       }
     }
   };
 
   // ---- pipeline: image (it & 1) holds the transforms of k-step `it`; the raw registers hold k-step it + 1 ---------------------
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
   if (nst > 0) {
-    load();
-    transform(std::integral_constant<int, 0>{});
-    if (nst > 1) load();
-    __syncthreads();
+    load(I0{});
+    gsd_dma_barrier();   // vmcnt(0) + barrier: everyone's fills of the first k-step are in
+    transform(I0{});
+    if (nst > 1) load(I1{});
+    gsd_dma_barrier();
     auto step = [&](const int it, auto cur_c) __attribute__((always_inline)) {
       constexpr int cur = decltype(cur_c)::value;
-      if (it + 1 < nst) transform(std::integral_constant<int, cur ^ 1>{});
+      if (it + 1 < nst && !((WG2D_ABL & 4) && it > 1)) transform(std::integral_constant<int, cur ^ 1>{});
       __builtin_amdgcn_sched_barrier(0);   // (phases in program order: the register budget is 192 accumulators + one phase's values)
-      if (it + 2 < nst) load();
+      if (it + 2 < nst && !((WG2D_ABL & 2) && it > 1)) load(cur_c);   // k-step it + 2 has this one's parity
       __builtin_amdgcn_sched_barrier(0);
       multiply(cur_c);
-      __syncthreads();
+      // the fills of k-step it + 2 have the MFMA phase to land; published to the other waves (window pieces) by the barrier
+      if constexpr (!(WG2D_ABL & 16)) gsd_dma_barrier();
     };
     for (int it = 0; it < nst; it += 2) {
-      step(it, std::integral_constant<int, 0>{});
-      if (it + 1 < nst) step(it + 1, std::integral_constant<int, 1>{});
+      step(it, I0{});
+      if (it + 1 < nst) step(it + 1, I1{});
     }
   }
 
   // ---- epilogue: G4 along fc, G2^T along fr, per split (linear: the slab reduction only adds) ---------------------------------
   const size_t pl = (size_t)P.M * P.Ncols;
+  // (lane coordinates re-derived behind the loop from a laundered thread id: nothing of the epilogue's addressing is held in a
+  //  register -- or spilled -- across the loop)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int j_e = (tid_e & 63) >> 4, l16_e = tid_e & 15;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int mr = m0 + wm * 32 + m * 16 + j * 4 + reg;
-      const int col = n0 + wn * 16 + l16;
+      const int mr = m0 + wm * 32 + m * 16 + j_e * 4 + reg;
+      const int col = n0 + wn * 16 + l16_e;
       float E[4][3];
 #pragma unroll
       for (int fr = 0; fr < 4; ++fr) {
@@ -400,10 +457,12 @@ WgW2dPlan plan_wg2d(int N, int H, int W, int M, int Ncols) {
   p.tiles_x = ceil_div(W, 4);
   long best = -1;
   const int force_kx = gsd_env_int("GSD_WG2D_KX", 0);   // tuning
-  for (int kx = 4; kx >= 1; kx /= 2) {                  // ties go to the wider k-step (longer contiguous runs)
+  for (int kx = 4; kx >= 1; kx /= 2) {
     if (force_kx && kx != force_kx) continue;
     const int ky = 4 / kx;
-    const long steps = (long)ceil_div(p.tiles_y, ky) * ceil_div(p.tiles_x, kx);
+    // fewest k-steps, weighted by what a k-step of that shape costs: 2 x 2 and 4 x 1 tiles fetch shorter runs of more rows
+    // (measured per k-step against 1 x 4, batch 32: +2 ... +13 % and +13 ... +55 %, profiles/r06_wg2d_kstep_shapes.txt)
+    const long steps = (long)ceil_div(p.tiles_y, ky) * ceil_div(p.tiles_x, kx) * (kx == 4 ? 100 : kx == 2 ? 106 : 130);
     if (best < 0 || steps < best) {
       best = steps;
       p.KY = ky; p.KX = kx;
@@ -474,12 +533,16 @@ int gsd_wgrad_w2d_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   P.N = N; P.H = H; P.W = W;
   P.KY = pl.KY; P.KX = pl.KX; P.kx_log2 = pl.kx_log2;
   P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.sy_n = pl.sy_n; P.sx_n = pl.sx_n;
+  P.WR = 2 * pl.KY + 2; P.NP = pl.KX + 1;
+  P.NI = (pl.BN * P.WR * P.NP + 63) / 64;
   P.ksteps_total = pl.ksteps_total; P.splits = pl.splits; P.mblocks = pl.mblocks; P.nblocks = pl.nblocks;
   bool plain = true;
   for (int i = 0; i < nsrc; ++i) plain = plain && a[i].scale == nullptr && a[i].relu == 0;
   const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
-  const int npc = (pl.BM == 64 ? 1 : 2) + 2 * (pl.BN / 32);   // raw pieces per thread (kernel: NPC)
-  const size_t lds = ((size_t)2 * (4 * (pl.BM * 24 + 4) + 4 * (pl.BN * 24 + 4)) + (size_t)npc * 8 * 256) * sizeof(float);
+  // LDS (floats): dy slots [1 or 2 pieces][8 waves][256] | two window images of 10 / 20 KiB | two images of [4 tiles][BM | BN][24] (+4) | (scale, shift)[BN]
+  const size_t lds = ((size_t)(pl.BM == 64 ? 1 : 2) * 8 * 256 + (size_t)2 * (pl.BN == 32 ? 10 : 20) * 256 +
+                      (size_t)2 * (4 * (pl.BM * 24 + 4) + 4 * (pl.BN * 24 + 4)) + 2 * pl.BN) * sizeof(float);
+  GSD_REQUIRE(P.NI <= 8 * (pl.BN == 32 ? 2 : 3) && P.NI <= (pl.BN == 32 ? 10 : 20), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad (w2d): window image too large");
   if (gsd_env_set("GSD_WG43_TRACE"))   // tuning: one line per launch
     fprintf(stderr, "wg2d M%d N%d %dx%d B%d kstep %dx%d ksteps %d splits %d blocks %ld BM %d BN %d plain %d lds %zu\n", Cout, Cin, H, W,
             N, pl.KY, pl.KX, pl.ksteps_total, pl.splits, grid, pl.BM, pl.BN, (int)plain, lds);

@@ -1,7 +1,7 @@
 """fp32 conv3x3 dW on the U-Net's 17 Winograd layers in the form the ENGINE launches them: activation segments with deferred
 BatchNorm + ReLU and slack (16-byte window pieces), the two-segment decoder form, dy from the row-pitched buffer (aligned 16-byte
 pieces).  One line per layer: ms and algorithmic TFLOP/s.  GSD_WG43_TRACE=1 adds the planner's choice per launch (stderr).
-usage (GPU box): python profiles/bench_wgrad_engine_form.py [batch]"""
+usage (GPU box): python profiles/bench_wgrad_engine_form.py [batch [layer,layer,...]]"""
 import ctypes as C
 import sys
 import torch
@@ -16,6 +16,8 @@ for l in range(1, 5):
     layers += [(f"down{l-1}.c0", l, Cs[l - 1], 0, Cs[l], True), (f"down{l-1}.c1", l, Cs[l], 0, Cs[l], False)]
 for j, l in enumerate((3, 2, 1, 0)):
     layers += [(f"up{j}.c0", l, Cs[l], Cs[l], Cs[l], False), (f"up{j}.c1", l, Cs[l], 0, Cs[l], False)]
+if len(sys.argv) > 2:
+    layers = [l for l in layers if l[0] in sys.argv[2].split(",")]
 st = L.stream_ptr()
 tot = 0.0
 for name, lvl, c0, c1, co, pooled in layers:
