@@ -16,20 +16,27 @@
 // own operands (7 vector instructions per MFMA at a 16 x 16 wave tile, 264 registers at 32 x 16) is the
 // transform work, so here it is done ONCE PER BLOCK and shared through LDS:
 //
-//   * a block of 8 waves owns BM x BN = 128 co x 32 ci (or 64 x 64 for the 64-channel layers); a k-step is 4 tiles (32 pixels);
-//   * per k-step every thread takes one or two small transform TASKS on raw values it loaded from global memory into registers
-//     a k-step earlier -- "U" (one (co, tile): two aligned 16-byte pieces of the row-pitched dy -> 24 values, 30 instructions)
-//     and "V row" (one window row of a (ci, tile): 6 floats -> deferred BatchNorm+ReLU -> B4^T row transform; the B2^T column
-//     transform takes the other three rows from the lane's quad by DPP: 36 instructions for 6 values) -- and stores the results
-//     as [tile][channel][24 frequencies] images;
-//   * the MFMA phase of a wave (tile 32 co x 16 ci x 24 frequencies = 192 accumulator registers) reads its operands
-//     frequency-major: one ds_read_b128 is four frequencies of (channel l16, tile j), 18 reads per 48 MFMAs, no vector work;
-//   * two images: the transforms of k-step i+1 are written while k-step i is multiplied, one barrier per k-step.
+//   * a block of 4 waves owns 64 co x 32 ci; a k-step is 4 tiles (32 pixels); TWO blocks per CU;
+//   * per k-step every thread takes three small transform TASKS: "U" (one (co, tile): two aligned 16-byte pieces of the row-pitched
+//     dy -> 24 values) and two "V rows" (one window row of a (ci, tile): 6 floats -> deferred BatchNorm+ReLU -> B4^T row transform;
+//     the B2^T column transform takes the other rows from the lane's quad by DPP), all in packed fp32 math, and stores the results
+//     as a [tile][channel][24 frequencies] image;
+//   * barrier; the MFMA phase of a wave (tile 32 co x 16 ci x 24 frequencies = 192 accumulator registers) reads its operands
+//     frequency-major: one ds_read_b128 is four frequencies of (channel l16, tile j), 18 reads per 48 MFMAs, no vector work; barrier.
 //
-// Vector instructions per MFMA: ~1.4 (128 x 32) / ~2 (64 x 64) against 2.7-3.3 in the row form, on two thirds of its MFMAs.
+// Why 4-wave blocks, two per CU, with ONE image and two barriers per k-step: a vector phase and an MFMA phase of the SAME wave do
+// not overlap, and the first form of this kernel (8 waves, two images, one barrier) put all eight waves of a CU in the same phase:
+// stamps showed a wave in its MFMA phase for 36 % of a k-step, 16 % at the barrier, the matrix pipes 0.53 busy, and removing a
+// third of the vector instructions changed nothing.  Two independent blocks per CU fall into opposite phases by themselves (each
+// SIMD hosts one wave of each): one block's MFMAs run beside the other's transforms, with no code duplicated for a stagger.
+// (A stagger inside one 8-wave block -- the two arms in one loop or in two loops -- made hipcc spill 70-800 bytes per lane.)
+//
+// The raw operands of the NEXT k-step wait in LDS, moved by LDS-DMA while this k-step is transformed and multiplied: registers
+// hold 192 accumulators + one phase's values, nothing is held across the MFMA phase (tests/test_abi.py: no scratch).
 // Split-K over k-steps with ordered slab reduction (the row form's reducer and slab layout): bitwise reproducible.
 //
-// Conventions: U row 3 is +dY row 1 and V row 3 is d3 - d1 (both signs of the textbook F(2,3) flipped: same products).
+// Conventions: U row 3 is +dY row 1 and V row 3 is d3 - d1 (both signs of the textbook F(2,3) flipped: same products); the six
+// frequencies of a row are stored in the order [1, 2, 3, 4, 0, 5] (what the packed transforms produce as register pairs).
 #include "gsd_common.h"
 #include <type_traits>
 
@@ -39,8 +46,7 @@
 typedef float f32x2d __attribute__((ext_vector_type(2)));
 
 // Diagnostic builds only (-DWG2D_ABL=mask via profiles/build_diag_one.sh; never in the product library; results are then garbage):
-// 1 no MFMAs, 2 no LDS-DMA fills after the first two k-steps, 4 no transform after the first two, 8 no operand reads, 16 no barrier,
-// 32 no dy fills, 64 no window fills, 128 every fill reads offset 0 (issue cost without the memory system's)
+// 1 no MFMAs, 2 no LDS-DMA fills after the first two k-steps, 4 no transform after the first two, 8 no operand reads
 #ifndef WG2D_ABL
 #define WG2D_ABL 0
 #endif
@@ -57,33 +63,31 @@ struct WgW2dParams {
   int ksteps_total, splits, mblocks, nblocks;
 };
 
-__device__ __forceinline__ float w2d_dpp(float v, const int ctrl_is_pair) {
-  // quad_perm [2,2,1,1] (0x5A): V column transform partners; quad_perm [1,0,3,2] (0xB1): the other row of a dy pair
-  return ctrl_is_pair ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true))
-                      : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
+__device__ __forceinline__ float w2d_dpp(float v) {   // quad_perm [2,2,1,1]: the partner row of the B2^T column transform
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, true));
 }
 
-// NWM x NWN waves of 32 co x 16 ci.  (4,2): 128 co x 32 ci -- U tasks: one (co, tile) per thread, V row tasks: one per thread.
-// (2,4): 64 co x 64 ci -- U tasks split by dy row (the A2 column transform takes the other row by DPP), two V row tasks per thread.
+namespace {
+constexpr int WG2D_BM = 64, WG2D_BN = 32, WG2D_NT = 256;
+constexpr int WG2D_TSU = WG2D_BM * 24 + 4, WG2D_TSV = WG2D_BN * 24 + 4;   // tile strides: an odd number of 16-byte slots (conflict-free b128 reads)
+constexpr int WG2D_WINI = 10;                                              // window image: at most BN * 20 pieces = 10 fills of 1 KiB
+constexpr int WG2D_DY = 0, WG2D_WIN = 2 * 4 * 256;                         // floats: dy slots [2 pieces][4 waves][256] | two window images |
+constexpr int WG2D_IMG = WG2D_WIN + 2 * WG2D_WINI * 256;                   // ... the image [4 tiles][BM][24] + [4 tiles][BN][24] |
+constexpr int WG2D_SCS = WG2D_IMG + 4 * WG2D_TSU + 4 * WG2D_TSV;           // ... (scale, shift)[BN]
+constexpr int WG2D_LDS = WG2D_SCS + 2 * WG2D_BN;
+}
+
 // PLAIN: no activation segment carries a deferred BatchNorm / ReLU.
-template <int NWM, int NWN, bool PLAIN>
-__global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams P) {
-  static_assert(NWM * NWN == 8, "8-wave blocks");
-  constexpr int BM = 32 * NWM, BN = 16 * NWN;
-  constexpr bool UROW = BM == 64;
-  constexpr int NV = BN / 32;
-  constexpr int TSU = BM * 24 + 4, TSV = BN * 24 + 4;   // tile strides: an odd number of 16-byte slots (conflict-free b128 reads)
-  constexpr int BUF = 4 * TSU + 4 * TSV;
-  constexpr int NPD = UROW ? 1 : 2;               // dy pieces per thread and k-step (private slots: [piece][wave][64 lanes x 4 floats])
-  constexpr int WINI = BN == 32 ? 10 : 20;        // window image of the block's BN channels: at most BN * 20 pieces = WINI fills of 1 KiB
-  constexpr int KB = BN == 32 ? 2 : 3;            // window fills per wave at most
-  constexpr int WIN = NPD * 8 * 256;              // first float of the window image
-  constexpr int IMG = WIN + 2 * WINI * 256;       // first float of image 0 (two window images: k-step parity, like the images)
+template <bool PLAIN>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_w2d_kernel(const WgW2dParams P) {
+  constexpr int BM = WG2D_BM, BN = WG2D_BN, TSU = WG2D_TSU, TSV = WG2D_TSV, WINI = WG2D_WINI;
+  constexpr int WIN = WG2D_WIN, IMG = WG2D_IMG, SCS = WG2D_SCS;
+  constexpr int KB = 3;   // window fills per wave at most
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
+  const int wm = wave >> 1, wn = wave & 1;
   const int j = lane >> 4, l16 = lane & 15;
 
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -105,27 +109,24 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
   const int S_c0 = n0 - (seg1 ? P.a0.C : 0);   // first channel of the block inside the segment
 
   // ---- transform tasks of this thread -----------------------------------------------------------------------------------------
-  // (the tile coordinates inside the k-step are needed again in border k-steps only: packed into one register there)
   const int kxm = P.KX - 1;
-  // U: (co, tile[, dy row])
-  const int u_t = UROW ? (tid >> 1) & 3 : tid & 3;
-  const int u_r = UROW ? tid & 1 : 0;
-  const int u_co = UROW ? tid >> 3 : tid >> 2;
+  // U: (co, tile): tile fastest, so that a quad of lanes reads 64 contiguous bytes of a dy row
+  const int u_t = tid & 3, u_co = tid >> 2;
   const int u_tyl = u_t >> P.kx_log2, u_txl = u_t & kxm;
-  const unsigned u_voff = (unsigned)((long long)u_co * P.dy.cs + (long long)(2 * u_tyl + u_r) * P.dy.ws + 4 * u_txl) * 4u;
-  const unsigned u_wr = (unsigned)(IMG + u_t * TSU + u_co * 24) * 4u;                // byte offsets of the thread's results in image 0
-  // V rows: (ci, tile, window row kr); lane quad = the four rows of one (ci, tile)
+  const unsigned u_voff = (unsigned)((long long)u_co * P.dy.cs + (long long)(2 * u_tyl) * P.dy.ws + 4 * u_txl) * 4u;
+  const unsigned u_wr = (unsigned)(IMG + u_t * TSU + u_co * 24) * 4u;     // byte offset of the thread's 24 results in the image
+  // V rows: (ci, tile, window row kr) and the same with ci + 16; lane quad = the four rows of one (ci, tile)
   const int v_kr = tid & 3, v_t = (tid >> 2) & 3, v_ci = tid >> 4;
   const int v_tyl = v_t >> P.kx_log2, v_txl = v_t & kxm;
-  const unsigned v_rd = (unsigned)(WIN + ((v_ci * P.WR + 2 * v_tyl + v_kr) * P.NP + v_txl) * 4) * 4u;   // its 6 floats in the window image
+  const unsigned v_rd = (unsigned)(WIN + ((v_ci * P.WR + 2 * v_tyl + v_kr) * P.NP + v_txl) * 4) * 4u;   // its 6 floats in window image 0
   const unsigned v_wr = (unsigned)(IMG + 4 * TSU + v_t * TSV + v_ci * 24 + v_kr * 6) * 4u;
-  int geo_packed = u_tyl | u_txl << 3 | v_tyl << 6 | v_txl << 9 | v_kr << 12 | u_r << 15;
-  asm volatile("" : "+v"(geo_packed));   // opaque: otherwise hipcc keeps the six fields in six registers for the whole kernel
+  // (the tile coordinates inside the k-step are needed again in border k-steps only: one packed, opaque register -- hipcc would keep
+  //  the fields in separate registers for the whole kernel, and the kernel lives at the register limit)
+  int geo_packed = u_tyl | u_txl << 3 | v_tyl << 6 | v_txl << 9 | v_kr << 12;
+  asm volatile("" : "+v"(geo_packed));
   const float v_sgn = (tid & 3) == 1 ? 1.f : -1.f;   // kr0: r0 - r2, kr1: r1 + r2, kr2: r2 - r1, kr3: r3 - r1
-  const float u_sgn = (UROW && (tid & 1)) ? -1.f : 1.f;    // UROW: row 0 forms r0 + r1, row 1 forms r0 - r1
-  // deferred BatchNorm of the block's BN channels: (scale, shift) pairs in LDS behind the images, read per task and k-step (one
-  // ds_read_b64 instead of two registers per task held for the whole kernel; the kernel lives at the register limit)
-  constexpr int SCS = IMG + 2 * BUF;
+  // deferred BatchNorm of the block's BN channels: (scale, shift) pairs in LDS, read per task and k-step (one ds_read_b64 instead of
+  // two registers per task held for the whole kernel)
   float lo = -__builtin_inff();
   if constexpr (!PLAIN) {
     const SrcD& S = seg1 ? P.a1 : P.a0;
@@ -148,29 +149,29 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     st_sx = rs - st_sy * P.sx_n;
   }
 
-  // Raw operands of one k-step wait in LDS (by LDS-DMA), not in registers (14 of them held across the MFMA phase did not fit 256):
-  //   * dy: every thread moves ITS OWN pieces (one or two rows of 16 bytes) into a private slot -- piece p of wave w occupies 1 KiB
-  //     at (p * 8 + w) * 256 floats, lane l its bytes [16 l, 16 l + 16) -- and reads them back itself a k-step later: the only
-  //     ordering needed is the thread's own vmcnt(0) before the read, and program order read -> next fill;
+  // Raw operands of a k-step wait in LDS (by LDS-DMA), not in registers (14 of them held across the MFMA phase did not fit 256):
+  //   * dy: every thread moves ITS OWN two row pieces of 16 bytes into a private slot -- piece p of wave w occupies 1 KiB at
+  //     (p * 4 + w) * 256 floats, lane l its bytes [16 l, 16 l + 16) -- and reads them back itself a k-step later: the only
+  //     ordering needed is the thread's own vmcnt(0) before the read, and its reads having returned before the next fill;
   //   * activation windows: ONE image per block and k-step, [channel][window row][piece of 4 floats], the halo shared by the tiles
   //     of the k-step (80 instead of 128 bytes per row at 1 x 4 tiles) and moved as runs of consecutive pieces by consecutive lanes
-  //     (fill i = pieces 64 i .. 64 i + 63 of the image, wave w issues fills w, w + 8, ...).  Another wave's pieces are read, so
-  //     there are two window images (k-step parity) and the fills are published by the k-step's barrier (vmcnt(0) in front of it).
-  int r_mask = 0;            // edge k-steps: bit 0/1 dy row ok, bits 2..7: window columns of the V tasks ok
+  //     (fill i = pieces 64 i .. 64 i + 63 of the image, wave w issues fills w, w + 4, w + 8).  Another wave's pieces are read, so
+  //     there are two window images (k-step parity) and the fills are published by a barrier (vmcnt(0) in front of it).
+  int r_mask = 0;            // border k-steps: bit 0/1 dy row ok, bits 2..7: window columns of the V tasks ok
   bool r_edge = false;       // wave-uniform: the masks apply
-  float* const raw_w = smem + wave * 256;                       // this wave's slot of piece 0 (wave-uniform: the DMA's LDS base)
-  const float* const raw_r = smem + wave * 256 + lane * 4;  // this lane's 16 bytes of piece 0
-  // window fills of this wave: piece 64 (wave + 8 k) + lane = (channel, window row, piece) -> byte offset from the k-step's window
-  // origin in the first channel's plane; row and piece packed for border k-steps (-1: a dummy lane behind the image)
+  float* const raw_w = smem + WG2D_DY + wave * 256;                  // this wave's slot of piece 0 (wave-uniform: the DMA's LDS base)
+  const float* const raw_r = smem + WG2D_DY + wave * 256 + lane * 4;   // this lane's 16 bytes of piece 0
+  // window fills of this wave: piece 64 (wave + 4 k) + lane = (channel, window row, piece) -> byte offset from the k-step's window
+  // origin in the first channel's plane; row and piece packed (8 bits per fill: row | piece << 4 | dummy << 7) for border k-steps
   unsigned x_off[KB];
-  int x_meta = 0;   // 8 bits per fill: window row | piece << 4 | dummy << 7
+  int x_meta = 0;
   {
     const int per_ch = P.WR * P.NP;
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
-      const int pid = 64 * (wave + 8 * k) + lane;
-      const int ch = pid / per_ch, rem = pid - ch * per_ch;
-      const int wr = rem / P.NP, pp = rem - wr * P.NP;
+      const int pid = 64 * (wave + 4 * k) + lane;
+      const int ch = pid / per_ch, rm = pid - ch * per_ch;
+      const int wr = rm / P.NP, pp = rm - wr * P.NP;
       const bool dummy = ch >= BN;
       x_off[k] = dummy ? 0u : (unsigned)((long long)ch * S_cs + (long long)wr * S_ws + 4 * pp) * 4u;
       x_meta |= (dummy ? 128 : (wr | pp << 4)) << (8 * k);
@@ -180,10 +181,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
 
   // Addresses: a wave-uniform 64-bit base that depends on the IMAGE only (the block's first channel plane) plus an unsigned 32-bit
   // byte offset per lane = (k-step origin, scalar) + (task constant).  A lane whose piece must not be read where it lies takes
-  // offset 0 instead.  (The first form of this code selected between 64-bit pointers per lane and held 14 raw registers across
-  // the MFMA phase; at 256 registers hipcc then spilled the zero-extended offsets on some paths of the branchy prologue only and
-  // reloaded them on all -- wild addresses, a memory fault at the 160x213 level.  No 64-bit vector address selects here, the raw
-  // values wait in LDS, and tests/test_abi.py checks that these kernels use no scratch.)
+  // offset 0 instead.  (The first form of this code selected between 64-bit pointers per lane and held the raw values in registers;
+  // at 256 registers hipcc then spilled the zero-extended offsets on some paths of the branchy prologue only and reloaded them on
+  // all -- wild addresses, a memory fault at the 160x213 level.  No 64-bit vector address selects here.)
   auto load = [&](auto wb_c) __attribute__((always_inline)) {
     constexpr int wb = decltype(wb_c)::value;   // window image of the k-step (its parity inside the block's range)
     const int n = st_n, ty0 = st_sy * P.KY, tx0 = st_sx * P.KX;
@@ -210,11 +210,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     if (!inside) {
       int m = 0;
       int geo = geo_packed;
-      asm volatile("" : "+v"(geo));   // (as x_meta below)
+      asm volatile("" : "+v"(geo));   // (unpacked HERE, in border k-steps only: hipcc would hoist the fields out of the loop)
       {
         const int ty = ty0 + (geo & 7), tx = tx0 + (geo >> 3 & 7);
         const bool t_ok = ty < P.tiles_y && tx < P.tiles_x;
-        const int h = 2 * ty + (geo >> 15 & 1);
+        const int h = 2 * ty;
         const bool ok0 = t_ok && h < P.H, ok1 = t_ok && h + 1 < P.H;
         o_y0 = ok0 ? o_y0 : 0u;
         o_y1 = ok1 ? o_y1 : 0u;
@@ -236,38 +236,53 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     auto fill = [&](const char* base, unsigned off, float* dst) __attribute__((always_inline)) {
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + off), dst, 16, 0, 0);
     };
-    if constexpr (WG2D_ABL & 128) o_y0 = o_y1 = 0u;
-    if constexpr (!(WG2D_ABL & 32)) {
-      fill(dblk, o_y0, raw_w);
-      if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
-    }
     // window pieces: one with a column inside the segment lies within 3 floats of its row's ends (slack >= 4) and is read where it
     // lies, partly outside or not (the transform masks by column); one without is not read where it lies (offset 0)
-    if constexpr (!(WG2D_ABL & 64)) {
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
-        if (wave + 8 * k < P.NI) {
-          unsigned off = (unsigned)v_org + x_off[k];
-          if (!inside) {
-            int mt = x_meta;
-            asm volatile("" : "+v"(mt));   // (unpacked HERE, in border k-steps only: hipcc would hoist the fields out of the loop into registers)
-            mt >>= 8 * k;
-            const int row = hs + (mt & 15), c0 = wsx + 4 * (mt >> 4 & 7);
-            const bool ok = !(mt & 128) && (unsigned)row < (unsigned)S_H && c0 + 3 >= 0 && c0 < S_W;
-            off = ok ? off : 0u;
-          }
-          if constexpr (WG2D_ABL & 128) off = 0u;
-          fill(vblk, off, smem + WIN + wb * (WINI * 256) + (wave + 8 * k) * 256);
+    for (int k = 0; k < KB; ++k)
+      if (wave + 4 * k < P.NI) {
+        unsigned off = (unsigned)v_org + x_off[k];
+        if (!inside) {
+          int mt = x_meta;
+          asm volatile("" : "+v"(mt));
+          mt >>= 8 * k;
+          const int row = hs + (mt & 15), c0 = wsx + 4 * (mt >> 4 & 7);
+          const bool ok = !(mt & 128) && (unsigned)row < (unsigned)S_H && c0 + 3 >= 0 && c0 < S_W;
+          off = ok ? off : 0u;
         }
-    }
+        fill(vblk, off, smem + WIN + wb * (WINI * 256) + (wave + 4 * k) * 256);
+      }
+    // dy pieces go into the slots this thread has just read (read_raw): its reads have to have RETURNED before a fill can land
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    fill(dblk, o_y0, raw_w);
+    fill(dblk, o_y1, raw_w + 4 * 256);
   };
 
-  // transform this thread's raw pieces into LDS image `buf` (compile-time constant)
-  auto transform = [&](auto buf_c) __attribute__((always_inline)) {
-    constexpr int buf = decltype(buf_c)::value;
-    // Packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two floats for the issue slot of one; an fp32 MFMA stream does not hide vector
-    // instructions, profiles/r05_mfma_f32_issue_ubench.txt).  The six frequencies of a row are stored in the order
-    // [1, 2, 3, 4, 0, 5]: the transforms produce (1,2), (3,4) and (0,5) as register pairs, and U, V and the epilogue only have to agree.
+  // A k-step's iteration: (1) the thread's raw values of k-step `it` come from LDS into registers, (2) the fills of k-step it + 1
+  // are issued -- their destinations are free: the dy slots were just read, the other window image was last read an iteration ago --
+  // (3) the transforms are computed and stored, barrier, (4) the k-step is multiplied, (5) vmcnt(0) + barrier.  The fills have the
+  // transform AND the MFMA phase to land.
+  f32x4 t_y0, t_y1, t_ra[2];
+  f32x2d t_rb[2];
+  int t_mask = 0;
+  bool t_edge = false;
+  auto read_raw = [&](auto wb_c) __attribute__((always_inline)) {
+    constexpr int wb = decltype(wb_c)::value;
+    t_y0 = *reinterpret_cast<const f32x4*>(raw_r);
+    t_y1 = *reinterpret_cast<const f32x4*>(raw_r + 4 * 256);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* const wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + v_rd) + wb * (WINI * 256) + i * 16 * (P.WR * P.NP * 4);
+      t_ra[i] = *reinterpret_cast<const f32x4*>(wp);
+      t_rb[i] = *reinterpret_cast<const f32x2d*>(wp + 4);
+    }
+    t_mask = r_mask;   // (of the k-step whose raw values these are: the next load() overwrites r_mask / r_edge)
+    t_edge = r_edge;
+  };
+
+  // Packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two floats for the issue slot of one; an fp32 MFMA stream does not hide vector
+  // instructions, profiles/r05_mfma_f32_issue_ubench.txt).
+  auto transform = [&]() __attribute__((always_inline)) {
     const f32x2d p1m1 = {1.f, -1.f}, p2m2 = {2.f, -2.f}, c4 = {4.f, 4.f};
     // A4 of one dy row (y0..y3) -> (U1, U2), (U3, U4); U0 = y0, U5 = y3
     auto a4_row = [&](const f32x4& y, f32x2d& u12, f32x2d& u34) __attribute__((always_inline)) {
@@ -277,65 +292,40 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
       u12 = __builtin_elementwise_fma(f32x2d{pq[1], pq[1]}, p1m1, f32x2d{pq[0], pq[0]});
       u34 = __builtin_elementwise_fma(f32x2d{ab[1], ab[1]}, p2m2, f32x2d{ab[0], ab[0]});
     };
-    // ---- U ----
+    // ---- U: rows fr = [r0, r0 + r1, r0 - r1, r1] of A4-transformed dy rows, 24 consecutive floats as six 16-byte groups ----
     {
-      f32x4 y0 = *reinterpret_cast<const f32x4*>(raw_r), y1 = y0;
-      if constexpr (!UROW) y1 = *reinterpret_cast<const f32x4*>(raw_r + 8 * 256);
-      if (r_edge) {
-        if (!(r_mask & 1)) y0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (!UROW)
-          if (!(r_mask & 2)) y1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 y0 = t_y0, y1 = t_y1;
+      if (t_edge) {
+        if (!(t_mask & 1)) y0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(t_mask & 2)) y1 = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      f32x2d a12, a34;
+      f32x2d a12, a34, b12, b34;
       a4_row(y0, a12, a34);
-      if constexpr (UROW) {
-        // this lane holds A4 of ONE dy row; rows fr of U = [r0, r0 + r1, r0 - r1, r1]: lane r = 0 stores (own, own + x) as rows 0, 1,
-        // lane r = 1 stores (x - own, own) as rows 2, 3
-        const f32x2d sg = {u_sgn, u_sgn};
-        const f32x2d a05 = {y0[0], y0[3]};
-        const f32x2d x12 = {w2d_dpp(a12[0], 1), w2d_dpp(a12[1], 1)}, x34 = {w2d_dpp(a34[0], 1), w2d_dpp(a34[1], 1)};
-        const f32x2d x05 = {w2d_dpp(a05[0], 1), w2d_dpp(a05[1], 1)};
-        const f32x2d t12 = __builtin_elementwise_fma(a12, sg, x12), t34 = __builtin_elementwise_fma(a34, sg, x34);
-        const f32x2d t05 = __builtin_elementwise_fma(a05, sg, x05);
-        float* const o_own = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF + ((tid & 1) ? 18 : 0);
-        float* const o_t1 = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF + ((tid & 1) ? 12 : 6);
-        *reinterpret_cast<f32x2d*>(o_own) = a12;
-        *reinterpret_cast<f32x2d*>(o_own + 2) = a34;
-        *reinterpret_cast<f32x2d*>(o_own + 4) = a05;
-        *reinterpret_cast<f32x2d*>(o_t1) = t12;
-        *reinterpret_cast<f32x2d*>(o_t1 + 2) = t34;
-        *reinterpret_cast<f32x2d*>(o_t1 + 4) = t05;
-      } else {
-        f32x2d b12, b34;
-        a4_row(y1, b12, b34);
-        const f32x2d s12 = a12 + b12, s34 = a34 + b34, d12 = a12 - b12, d34 = a34 - b34;
-        const float s0 = y0[0] + y1[0], s5 = y0[3] + y1[3], d0 = y0[0] - y1[0], d5 = y0[3] - y1[3];
-        // rows fr of U = [r0, r0 + r1, r0 - r1, r1], 24 consecutive floats as six 16-byte groups
-        float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + buf * BUF;
-        *reinterpret_cast<f32x4*>(op) = f32x4{a12[0], a12[1], a34[0], a34[1]};
-        *reinterpret_cast<f32x4*>(op + 4) = f32x4{y0[0], y0[3], s12[0], s12[1]};
-        *reinterpret_cast<f32x4*>(op + 8) = f32x4{s34[0], s34[1], s0, s5};
-        *reinterpret_cast<f32x4*>(op + 12) = f32x4{d12[0], d12[1], d34[0], d34[1]};
-        *reinterpret_cast<f32x4*>(op + 16) = f32x4{d0, d5, b12[0], b12[1]};
-        *reinterpret_cast<f32x4*>(op + 20) = f32x4{b34[0], b34[1], y1[0], y1[3]};
-      }
+      a4_row(y1, b12, b34);
+      const f32x2d s12 = a12 + b12, s34 = a34 + b34, d12 = a12 - b12, d34 = a34 - b34;
+      const float s0 = y0[0] + y1[0], s5 = y0[3] + y1[3], d0 = y0[0] - y1[0], d5 = y0[3] - y1[3];
+      float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr);
+      *reinterpret_cast<f32x4*>(op) = f32x4{a12[0], a12[1], a34[0], a34[1]};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{y0[0], y0[3], s12[0], s12[1]};
+      *reinterpret_cast<f32x4*>(op + 8) = f32x4{s34[0], s34[1], s0, s5};
+      *reinterpret_cast<f32x4*>(op + 12) = f32x4{d12[0], d12[1], d34[0], d34[1]};
+      *reinterpret_cast<f32x4*>(op + 16) = f32x4{d0, d5, b12[0], b12[1]};
+      *reinterpret_cast<f32x4*>(op + 20) = f32x4{b34[0], b34[1], y1[0], y1[3]};
     }
     // ---- V rows ----
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float* const wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + v_rd) + buf * (WINI * 256) + i * 32 * (P.WR * P.NP * 4);
-      const f32x4 ra = *reinterpret_cast<const f32x4*>(wp);
-      const f32x2d rb = *reinterpret_cast<const f32x2d*>(wp + 4);
-      f32x2d t0 = {ra[0], ra[1]}, t1 = {ra[2], ra[3]}, t2 = rb;
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 ra = t_ra[i];
+      f32x2d t0 = {ra[0], ra[1]}, t1 = {ra[2], ra[3]}, t2 = t_rb[i];
       if constexpr (!PLAIN) {
-        const f32x2d ss = *reinterpret_cast<const f32x2d*>(smem + SCS + 2 * ((tid >> 4) + 32 * i));
+        const f32x2d ss = *reinterpret_cast<const f32x2d*>(smem + SCS + 2 * ((tid >> 4) + 16 * i));
         const f32x2d sc2 = {ss[0], ss[0]}, sh2 = {ss[1], ss[1]}, lo2 = {lo, lo};
         t0 = __builtin_elementwise_max(__builtin_elementwise_fma(t0, sc2, sh2), lo2);
         t1 = __builtin_elementwise_max(__builtin_elementwise_fma(t1, sc2, sh2), lo2);
         t2 = __builtin_elementwise_max(__builtin_elementwise_fma(t2, sc2, sh2), lo2);
       }
-      if (r_edge) {
-        const int m = r_mask;
+      if (t_edge) {
+        const int m = t_mask;
         if (!(m & 4)) t0[0] = 0.f;
         if (!(m & 8)) t0[1] = 0.f;
         if (!(m & 16)) t1[0] = 0.f;
@@ -352,9 +342,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
       const f32x2d v05 = __builtin_elementwise_fma(t0, c4, __builtin_elementwise_fma(t1, m5, t2));
       // B2^T down the window column: the partner row from the lane's quad
       const f32x2d sg = {v_sgn, v_sgn};
-      const f32x2d x12 = {w2d_dpp(v12[0], 0), w2d_dpp(v12[1], 0)}, x34 = {w2d_dpp(v34[0], 0), w2d_dpp(v34[1], 0)};
-      const f32x2d x05 = {w2d_dpp(v05[0], 0), w2d_dpp(v05[1], 0)};
-      float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + v_wr) + buf * BUF + i * (32 * 24);
+      const f32x2d x12 = {w2d_dpp(v12[0]), w2d_dpp(v12[1])}, x34 = {w2d_dpp(v34[0]), w2d_dpp(v34[1])};
+      const f32x2d x05 = {w2d_dpp(v05[0]), w2d_dpp(v05[1])};
+      float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + v_wr) + i * (16 * 24);
       *reinterpret_cast<f32x2d*>(op) = __builtin_elementwise_fma(sg, x12, v12);
       *reinterpret_cast<f32x2d*>(op + 2) = __builtin_elementwise_fma(sg, x34, v34);
       *reinterpret_cast<f32x2d*>(op + 4) = __builtin_elementwise_fma(sg, x05, v05);
@@ -370,21 +360,18 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
   const int a_rd = IMG + j * TSU + (wm * 32 + l16) * 24;
   const int b_rd = IMG + 4 * TSU + j * TSV + (wn * 16 + l16) * 24;
 
-  // One operand group = four frequencies of (channel l16, tile j) per ds_read_b128: 3 reads feed 8 MFMAs.  The groups are NOT
-  // double-buffered in the source: 12 operand registers instead of 24 keep the kernel inside 256 registers without scratch, and the
-  // SIMD's other wave multiplies while this one waits for its reads.
-  auto multiply = [&](auto buf_c) __attribute__((always_inline)) {
-    constexpr int buf = decltype(buf_c)::value;
-    const float* const Sb = smem + buf * BUF;
+  // One operand group = four frequencies of (channel l16, tile j) per ds_read_b128: 3 reads feed 8 MFMAs.  One register set: the
+  // SIMD's other wave (of the CU's other block) multiplies or transforms while this one waits for its reads.
+  auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
       f32x4 a0, a1, b;
       if constexpr (WG2D_ABL & 8) {
         a0 = a1 = b = f32x4{1.f, 2.f, 3.f, (float)g};
       } else {
-        a0 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 4 * g);
-        a1 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 16 * 24 + 4 * g);
-        b = *reinterpret_cast<const f32x4*>(Sb + b_rd + 4 * g);
+        a0 = *reinterpret_cast<const f32x4*>(smem + a_rd + 4 * g);
+        a1 = *reinterpret_cast<const f32x4*>(smem + a_rd + 16 * 24 + 4 * g);
+        b = *reinterpret_cast<const f32x4*>(smem + b_rd + 4 * g);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -399,24 +386,32 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     }
   };
 
-  // ---- pipeline: image (it & 1) holds the transforms of k-step `it`; the raw registers hold k-step it + 1 ---------------------
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   if (nst > 0) {
     load(I0{});
-    gsd_dma_barrier();   // vmcnt(0) + barrier: everyone's fills of the first k-step are in
-    transform(I0{});
-    if (nst > 1) load(I1{});
-    gsd_dma_barrier();
+    gsd_dma_barrier();   // vmcnt(0) + barrier: everyone's fills of the first k-step (and the BatchNorm pairs) are in
     auto step = [&](const int it, auto cur_c) __attribute__((always_inline)) {
       constexpr int cur = decltype(cur_c)::value;
-      if (it + 1 < nst && !((WG2D_ABL & 4) && it > 1)) transform(std::integral_constant<int, cur ^ 1>{});
+      using NXT = std::integral_constant<int, cur ^ 1>;
+      const bool tr = !((WG2D_ABL & 4) && it > 1);
+      // The vector phase runs at raised priority: beside another block's wave that issues MFMAs back to back, vector instructions
+      // of a wave of equal priority get one issue slot per MFMA (~40 cycles each, profiles/r05_mfma_f32_issue_ubench.txt)
+      __builtin_amdgcn_s_setprio(3);
+      if (tr) read_raw(cur_c);
       __builtin_amdgcn_sched_barrier(0);   // (phases in program order: the register budget is 192 accumulators + one phase's values)
-      if (it + 2 < nst && !((WG2D_ABL & 2) && it > 1)) load(cur_c);   // k-step it + 2 has this one's parity
+      if (it + 1 < nst && !((WG2D_ABL & 2) && it > 1)) load(NXT{});
       __builtin_amdgcn_sched_barrier(0);
-      multiply(cur_c);
-      // the fills of k-step it + 2 have the MFMA phase to land; published to the other waves (window pieces) by the barrier
-      if constexpr (!(WG2D_ABL & 16)) gsd_dma_barrier();
+      if (tr) transform();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      // the image is complete: a RAW barrier behind lgkmcnt(0) -- __syncthreads() would also wait for the fills in flight (vmcnt(0)) ...
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      multiply();
+      gsd_dma_barrier();      // ... which have until here to land: vmcnt(0) + barrier; everyone has left the image
     };
     for (int it = 0; it < nst; it += 2) {
       step(it, I0{});
@@ -486,13 +481,13 @@ WgW2dPlan plan_wg2d(int N, int H, int W, int M, int Ncols) {
   p.kx_log2 = p.KX == 4 ? 2 : p.KX == 2 ? 1 : 0;
   p.sy_n = ceil_div(p.tiles_y, p.KY);
   p.sx_n = ceil_div(p.tiles_x, p.KX);
-  p.BM = M >= 128 ? 128 : 64;
-  p.BN = p.BM == 128 ? 32 : 64;
+  p.BM = WG2D_BM;
+  p.BN = WG2D_BN;
   p.ok = M % p.BM == 0 && Ncols % p.BN == 0;
   p.mblocks = ceil_div(M, p.BM);
   p.nblocks = ceil_div(Ncols, p.BN);
   p.ksteps_total = N * p.sy_n * p.sx_n;
-  const int target = gsd_env_int("GSD_WG2D_BLOCKS", 256);   // one block per CU
+  const int target = gsd_env_int("GSD_WG2D_BLOCKS", 512);   // two blocks per CU
   int splits = ceil_div(target, p.mblocks * p.nblocks);
   if (splits > p.ksteps_total) splits = p.ksteps_total;
   if (splits > 2048) splits = 2048;
@@ -554,32 +549,25 @@ int gsd_wgrad_w2d_run(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   bool plain = true;
   for (int i = 0; i < nsrc; ++i) plain = plain && a[i].scale == nullptr && a[i].relu == 0;
   const long grid = (long)pl.splits * pl.mblocks * pl.nblocks;
-  // LDS (floats): dy slots [1 or 2 pieces][8 waves][256] | two window images of 10 / 20 KiB | two images of [4 tiles][BM | BN][24] (+4) | (scale, shift)[BN]
-  const size_t lds = ((size_t)(pl.BM == 64 ? 1 : 2) * 8 * 256 + (size_t)2 * (pl.BN == 32 ? 10 : 20) * 256 +
-                      (size_t)2 * (4 * (pl.BM * 24 + 4) + 4 * (pl.BN * 24 + 4)) + 2 * pl.BN) * sizeof(float);
-  GSD_REQUIRE(P.NI <= 8 * (pl.BN == 32 ? 2 : 3) && P.NI <= (pl.BN == 32 ? 10 : 20), GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad (w2d): window image too large");
+  const size_t lds = (size_t)WG2D_LDS * sizeof(float);   // 2 x 65.3 KiB per CU
+  GSD_REQUIRE(P.NI <= 4 * 3 && P.NI <= WG2D_WINI, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_wgrad (w2d): window image too large");
   if (gsd_env_set("GSD_WG43_TRACE"))   // tuning: one line per launch
     fprintf(stderr, "wg2d M%d N%d %dx%d B%d kstep %dx%d ksteps %d splits %d blocks %ld BM %d BN %d plain %d lds %zu\n", Cout, Cin, H, W,
             N, pl.KY, pl.KX, pl.ksteps_total, pl.splits, grid, pl.BM, pl.BN, (int)plain, lds);
   const dim3 g((int)grid);
   const hipStream_t st = (hipStream_t)stream;
-#define WG2D_LAUNCH(NWM_, NWN_, PL_)                                                                              \
+#define WG2D_LAUNCH(PL_)                                                                                          \
   do {                                                                                                            \
     static gsd_attr_once once;                                                                                    \
-    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w2d_kernel<NWM_, NWN_, PL_>);                        \
+    const void* fn = reinterpret_cast<const void*>(&wgrad3x3_w2d_kernel<PL_>);                                    \
     if (hipError_t e = gsd_allow_big_lds(once, fn); e != hipSuccess) {                                            \
       gsd_set_error("gsd_conv3x3_wgrad (w2d): hipFuncSetAttribute: %s", hipGetErrorString(e));                    \
       return GSD_ERR_HIP;                                                                                         \
     }                                                                                                             \
-    hipLaunchKernelGGL((wgrad3x3_w2d_kernel<NWM_, NWN_, PL_>), g, dim3(512), lds, st, P);                         \
+    hipLaunchKernelGGL((wgrad3x3_w2d_kernel<PL_>), g, dim3(WG2D_NT), lds, st, P);                                 \
   } while (0)
-  if (pl.BM == 128) {
-    if (plain) WG2D_LAUNCH(4, 2, true);
-    else WG2D_LAUNCH(4, 2, false);
-  } else {
-    if (plain) WG2D_LAUNCH(2, 4, true);
-    else WG2D_LAUNCH(2, 4, false);
-  }
+  if (plain) WG2D_LAUNCH(true);
+  else WG2D_LAUNCH(false);
 #undef WG2D_LAUNCH
   GSD_LAUNCH_CHECK("gsd_conv3x3_wgrad (w2d)");
   *splits_out = pl.splits;

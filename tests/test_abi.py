@@ -230,5 +230,5 @@ def test_wgrad_w2d_kernels_use_no_scratch():
     names = re.findall(r"Function Name: (\S+)", r.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
     kernels = {n: s for n, s in zip(names, scratch) if "wgrad3x3_w2d_kernel" in n}
-    assert len(kernels) >= 4, r.stderr[-2000:]
+    assert len(kernels) >= 2, r.stderr[-2000:]
     assert all(v == 0 for v in kernels.values()), kernels
