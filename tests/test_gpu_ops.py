@@ -770,10 +770,12 @@ def with_slack(t, poison=float("nan")):
                                                   (2, 64, 64, 64, 13, 26, 12, 26), (1, 32, 32, 32, 10, 106, 10, 105),
                                                   (3, 16, 0, 16, 5, 16, 0, 0), (2, 128, 0, 64, 8, 213, 0, 0),
                                                   (1, 64, 64, 128, 7, 427, 6, 426), (1, 48, 0, 80, 6, 19, 0, 0)])
-def test_conv3x3_wgrad_window_pieces(gsd, n, c0, c1, co, h, w, uh, uw):
+def test_conv3x3_wgrad_window_pieces(gsd, monkeypatch, n, c0, c1, co, h, w, uh, uw):
     """Activation windows as 16-byte pieces from unaligned rows (gsd_src.slack >= 4): image widths of every residue mod 4,
-    images narrower than a tile row, two segments with an F.pad offset -- the same bits as the dword-gather form (same
-    products in the same order) and the oracle's numbers; the slack floats are NaN and must not leak."""
+    images narrower than a tile row, two segments with an F.pad offset -- in the row form (GSD_WGRAD_W2D=0) the same bits as the
+    dword-gather form (same products in the same order) and the oracle's numbers; the slack floats are NaN and must not leak.
+    With slack the call may take the two-dimensional form (gsd_wgrad_w2d.hip, other products): there the oracle's numbers
+    and no leak."""
     from oracle import unet_numpy as on
     rng = np.random.default_rng(c0 * 3 + c1 + w)
     raw0 = rnd(rng, n, c0, h, w)
@@ -798,12 +800,16 @@ def test_conv3x3_wgrad_window_pieces(gsd, n, c0, c1, co, h, w, uh, uw):
     dy_src = gsd.make_src(dyp)
     need = gsd.lib.gsd_conv3x3_wgrad_workspace(n, h, w, ci, co)
     ws = torch.zeros(need, device="cuda")
-    outs = []
-    for ss in (segs, segs_s):
+    def run(ss):
         dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
         gsd.check(gsd.lib.gsd_conv3x3_wgrad(gsd.src_array(ss), len(ss), C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(),
                                             need, n, h, w, gsd.stream_ptr()))
-        outs.append(dw.cpu().numpy())
+        return dw.cpu().numpy()
+    got = run(segs_s)                     # whichever form the library takes for these operands
+    assert np.isfinite(got).all()
+    assert rel_l1(got, dwr) < 5e-5
+    monkeypatch.setenv("GSD_WGRAD_W2D", "0")
+    outs = [run(segs), run(segs_s)]
     assert np.isfinite(outs[1]).all()
     assert rel_l1(outs[1], dwr) < 5e-5
     assert np.array_equal(outs[0], outs[1])
