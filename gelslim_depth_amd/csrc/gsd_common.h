@@ -179,6 +179,20 @@ static inline int gsd_require_rows_contiguous(const gsd_src& s, const char* what
   return 0;
 }
 
+// Compute units of the current device (256 on MI355X), remembered per process: an idempotent cache like gsd_attr_once -- every
+// thread computes the same value.  The planners' run-time models deal blocks over this many CUs.
+static inline int gsd_cu_count() {
+  static std::atomic<int> n{0};
+  int v = n.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

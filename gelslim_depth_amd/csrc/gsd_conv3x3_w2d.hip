@@ -842,14 +842,19 @@ bool plan_w2d(int N, int H, int W, int M, W2DPlan* best) {
   // LDS row pitch and plane stride of the chosen tile: a search over 36 candidates of ~10^5 operations each, i.e. a fraction of a
   // millisecond of HOST time -- per (tile, block form) it is done once and remembered (an idempotent cache like cu_count(): every
   // thread computes the same value, the key is published last)
-  struct Memo { std::atomic<int> key{0}; int wcp = 0, ps = 0; };
-  static Memo memo[16];
+  // (key, WCp, PS) travel in ONE 64-bit atomic: a reader never sees the key of one entry with the payload of another (with the key
+  //  and the payload in separate words two writers of colliding keys could hand a reader a torn pair, and the LDS size would then
+  //  be computed from another PS than the kernel's)
+  static std::atomic<uint64_t> memo[16];
   const int th = best->TH, tw = best->TW, key = (th << 16) | (tw << 4) | nwp;
-  Memo& mm = memo[(th * 7 + tw + nwp) & 15];
-  if (mm.key.load(std::memory_order_acquire) == key) {
-    best->WCp = mm.wcp;
-    best->PS = mm.ps;
-    return true;
+  std::atomic<uint64_t>& mm = memo[(th * 7 + tw + nwp) & 15];
+  {
+    const uint64_t v = mm.load(std::memory_order_acquire);
+    if (v != 0 && (int)(v >> 40) == key) {
+      best->WCp = (int)(v >> 20) & 0xFFFFF;
+      best->PS = (int)v & 0xFFFFF;
+      return true;
+    }
   }
   const int wcp0 = round_up(tw + 2, 4);
   int bc = -1;
@@ -862,21 +867,20 @@ bool plan_w2d(int N, int H, int W, int M, W2DPlan* best) {
         best->PS = ps;
       }
     }
-  if (mm.key.exchange(0, std::memory_order_acq_rel) == 0) {   // (a concurrent writer of another key simply loses its slot)
-    mm.wcp = best->WCp;
-    mm.ps = best->PS;
-    mm.key.store(key, std::memory_order_release);
-  }
+  if (key < (1 << 24) && best->WCp < (1 << 20) && best->PS < (1 << 20))
+    mm.store(((uint64_t)key << 40) | ((uint64_t)best->WCp << 20) | (uint64_t)best->PS, std::memory_order_release);
   return true;
 }
 
 // X4: plane stride of the shifted planes (row pitch 4 NP floats) with the fewest bank conflicts of the consumers' reads
 int w2d_x4_plane_stride(int TWq, int WCp, int WR) {
-  struct Memo { std::atomic<int> key{0}; int ps = 0; };
-  static Memo memo[8];
+  static std::atomic<uint64_t> memo[8];   // (key, PS) in one 64-bit atomic, as in plan_w2d
   const int key = (TWq << 20) | (WCp << 8) | WR;
-  Memo& mm = memo[(TWq + WR) & 7];
-  if (mm.key.load(std::memory_order_acquire) == key) return mm.ps;
+  std::atomic<uint64_t>& mm = memo[(TWq + WR) & 7];
+  {
+    const uint64_t v = mm.load(std::memory_order_acquire);
+    if (v != 0 && (int)(v >> 32) == key) return (int)(v & 0xFFFFFFFFu);
+  }
   int best = -1, ps_best = WR * WCp + 4;
   for (int ps = WR * WCp + 4; ps < WR * WCp + 4 + 68; ps += 4) {
     const int c = w2d_read_cycles(TWq, WCp, ps, 2);
@@ -885,10 +889,7 @@ int w2d_x4_plane_stride(int TWq, int WCp, int WR) {
       ps_best = ps;
     }
   }
-  if (mm.key.exchange(0, std::memory_order_acq_rel) == 0) {
-    mm.ps = ps_best;
-    mm.key.store(key, std::memory_order_release);
-  }
+  mm.store(((uint64_t)(unsigned)key << 32) | (uint64_t)(unsigned)ps_best, std::memory_order_release);
   return ps_best;
 }
 
@@ -914,7 +915,8 @@ int launch_w2d(const W2DParams& P, int grid, size_t lds, hipStream_t st) {
 // k = ceil(blocks / 256) blocks runs pairs at 2.07 us per chunk and block (+ 5 us per block) and an odd last block at 0.66 of that;
 // the slab sums cost 12 us + the slabs' bytes at 6 TB/s (the constants of gsd_conv3x3_w43.hip's model, the kernel's own rate).
 double w2d_time_us(long base, int nchunks, int S, bool bw) {
-  const long k = (base * S + 255) / 256;
+  const long cus = gsd_cu_count();
+  const long k = (base * S + cus - 1) / cus;
   const double cu = (double)(k / 2) + (k & 1 ? 0.66 : 0.0);
   double t = cu * (2.07 * nchunks / S + 5.0);
   if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
@@ -966,7 +968,7 @@ extern "C" double gsd_conv3x3_w2d_estimate_us(int N, int H, int W, int Cin, int 
   W2DPlan p;
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !plan_w2d(N, H, W, Cout, &p)) return 0.0;
   const long blocks = (long)N * p.tiles_y * p.tiles_x * p.mblocks;
-  if (p.nwp != 2) return (double)((blocks + 255) / 256) * (4.6 * ceil_div(Cin, 4) + 5.0);   // (the eight-wave block: one per CU, twice the pixels)
+  if (p.nwp != 2) return (double)((blocks + gsd_cu_count() - 1) / gsd_cu_count()) * (4.6 * ceil_div(Cin, 4) + 5.0);   // (the eight-wave block: one per CU, twice the pixels)
   return w2d_time_us(blocks, ceil_div(Cin, 4), 1, false);
 }
 

@@ -1167,7 +1167,8 @@ int launch_w43(const W43Params& P, int grid, size_t lds, hipStream_t st, int wm,
 // and is within 0.5 % on the other two): 2.6 us per chunk of a block that shares its CU, 4 us per block, a lone block at 0.55 of a
 // pair's time, the reducer at 12 us + 6 TB/s.  GSD_W43_SPLIT: 0 / 1 never, S >= 2 that many wherever the shape admits it.
 double w43_time_us(long base, int nchunks, int S, bool bw) {
-  const long k = (base * S + 255) / 256;
+  const long cus = gsd_cu_count();
+  const long k = (base * S + cus - 1) / cus;
   const double cu = (double)(k / 2) + (k & 1 ? 0.55 : 0.0);
   double t = cu * (2.6 * nchunks / S + 4.0);
   if (S > 1) t += 12.0 + (double)(S + 1 + (bw ? 1 : 0)) * base * 65536.0 / 6.0e6;
@@ -1199,7 +1200,9 @@ extern "C" int64_t gsd_conv3x3_w43_workspace(int N, int H, int W, int Cin, int C
   W43Plan p;
   if (!plan_w43(N, H, W, Cout, &p)) return 0;
   const long base = (long)(p.fold ? 1 : N) * p.tiles_y * p.tiles_x * p.mblocks;
-  const int S = w43_pick_slabs(base, Cin / 4, true);
+  // (the launch picks its own S with bw as it is called, and never more than fits: size for the larger of the two)
+  const int Sa = w43_pick_slabs(base, Cin / 4, true), Sb = w43_pick_slabs(base, Cin / 4, false);
+  const int S = Sa > Sb ? Sa : Sb;
   return S > 1 ? (int64_t)S * base * W43_BM * 256 : 0;
 }
 

@@ -54,6 +54,15 @@ class _ConvForm:
     def choose(n: int, h: int, w: int, cin: int, c0: int, cout: int, train: bool) -> "_ConvForm":
         """The library's preference for a launch shape (include/gsd.h: gsd_conv3x3_algo, gsd_conv3x3_prefers_w2d).  c0: channels
         of the first source segment.  Eval mode gets the forms whose bits do not depend on the batch (no row folding, no K slabs)."""
+        if not train:
+            # decided from N-independent quantities only: the one-image plan says direct or Winograd; Winograd means the 2-D form (no
+            # row folding, no K slabs: image i of a batch gets the bits the image alone gets); where the 2-D form does not serve
+            # the channel counts the direct form does (its tiles never span images either) -- never the row form, which folds rows
+            # across images
+            algo = lib.gsd_conv3x3_algo(1, h, w, cin, cout)
+            if algo == 1:
+                algo = 2 if lib.gsd_conv3x3_w2d_supported(cin, c0) else 0
+            return _ConvForm(algo)
         algo = lib.gsd_conv3x3_algo(n, h, w, cin, cout)
         if algo == 1 and lib.gsd_conv3x3_w2d_supported(cin, c0) and lib.gsd_conv3x3_prefers_w2d(n, h, w, cin, cout, int(train)):
             algo = 2
@@ -156,12 +165,21 @@ class UNetEngine:
         self.side: Optional[torch.cuda.Stream] = None
         self.convt_dg_bn = os.environ.get("GSD_CONVT_DG_BN", "1") != "0"   # ConvT dX + pass 1 of the BatchNorm backward below it
         self.batch_wl = os.environ.get("GSD_WL_BATCH", "1") != "0"   # a pass's weight layouts through gsd_weight_layout_batch
+        self._handoff: Optional[torch.cuda.Stream] = None   # bucket hand-off to the all-reduce (see _announce)
         self.kernel_log: Optional[list] = None
+        self.wgrad_log: Optional[list] = None      # bench hook: conv3x3 dW launches (+ slab reducer), same rows as kernel_log
         self.region_log: Optional[list] = None     # bench hook: (region name, start event, end event)
 
     # ------------------------------------------------------------------ buffers
+    # Library switches that change launch plans (tile shapes, partial-row counts, slab counts, the form a launch takes): partials,
+    # conv_ws and the weight-gradient workspaces are sized from them, so they are part of the shape key -- a switch flipped
+    # between two steps (a test's monkeypatch, a sweep in one process) re-sizes the buffers instead of overrunning them
+    _SIZING_ENV = ("GSD_W2D_WAVES", "GSD_W2D_TW", "GSD_W2D_TW8_PCT", "GSD_W43_TW", "GSD_W43_FOLD", "GSD_CONV_W2D", "GSD_CONV_ALGO",
+                   "GSD_W43_SPLIT", "GSD_WGRAD_ALGO", "GSD_WGRAD_W2D", "GSD_WG2D_KX", "GSD_WG2D_BLOCKS", "GSD_WGRAD_BLOCKS",
+                   "GSD_WG43_TW", "GSD_WG43_SMALL")
+
     def _ensure(self, n: int, h: int, w: int, dev: torch.device, train: bool) -> None:
-        key = (n, h, w, str(dev))
+        key = (n, h, w, str(dev), tuple(os.environ.get(k) for k in self._SIZING_ENV))
         if self._shape == key and (not train or self.units[0].g is not None):
             return
         if self._shape != key:
@@ -468,9 +486,18 @@ class UNetEngine:
                                    u.invstd.data_ptr(), u.c1.data_ptr(), u.c2.data_ptr(), n, u.cout, lh, lw, out_ptr, p, st),
               "bn_bwd_apply")
         dy = L.make_src(u.dsrc)
+        ev0 = self._log_begin() if self.wgrad_log is not None else None
         on_side = self._on_side(lambda sst, ws: check(
             lib.gsd_conv3x3_wgrad(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, G[u.wname].data_ptr(), ws.data_ptr(), ws.numel(),
                                   n, lh, lw, sst), "conv3x3_wgrad"))
+        if ev0 is not None and not on_side:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            form = lib.gsd_conv3x3_wgrad_form(u.srcs, len(u.srcs), C.byref(dy), u.cin, u.cout, n, lh, lw)
+            name = ("wgrad3x3_kernel", "wgrad3x3_w43_kernel", "wgrad3x3_w2d_kernel")[form]
+            flops = 2.0 * u.cout * u.cin * 9 * n * lh * lw
+            executed = 2048.0 * lib.gsd_conv3x3_wgrad_mfma_count(form, n, lh, lw, u.cin, u.cout) if form else flops
+            self.wgrad_log.append((name, flops, ev0, ev1, (u.cout, u.cin, lh, lw), executed))
         if on_side and turn is not None:
             self.gp_free[turn] = self.side.record_event()
 
@@ -489,6 +516,24 @@ class UNetEngine:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
             self.gp_free = [None, None]
+
+    def _announce(self, tag: str) -> None:
+        """A block of gradients is final once BOTH streams have finished what was issued so far.  The callback (the bucket's
+        all-reduce: RCCL orders itself behind the stream that is current when it is called) therefore runs under a hand-off
+        stream that waits for the two -- the main stream does NOT: the dX chain of the next unit does not depend on this
+        block's weight gradients and used to stall behind them nine times per step."""
+        if self.block_done_cb is None:
+            return
+        if self.side is None or self.kernel_log is not None:
+            self.block_done_cb(tag)
+            return
+        if self._handoff is None:
+            self._handoff = torch.cuda.Stream(device=self.side.device)
+        h = self._handoff
+        h.wait_stream(torch.cuda.current_stream())
+        h.wait_stream(self.side)
+        with torch.cuda.stream(h):
+            self.block_done_cb(tag)
 
     def _reduce(self, mode: int, u: _Unit, st: int, dpool: Optional[torch.Tensor] = None,
                 dout: Optional[torch.Tensor] = None, wout: Optional[torch.Tensor] = None) -> None:
@@ -592,9 +637,7 @@ class UNetEngine:
                 check(lib.gsd_convT2x2_dgrad_as(up.mode_d, C.byref(dys), up.wt_d.data_ptr(), up.cin, up.cout, C.byref(d), n, hi, wi, st),
                       "convT2x2_dgrad")
                 self._reduce(0, prev, st)
-            if self.block_done_cb is not None:
-                self._join_side()
-                self.block_done_cb(f"dec{j}")      # up.{j}.* (and outc with the last decoder) are final
+            self._announce(f"dec{j}")      # up.{j}.* (and outc with the last decoder) are final
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
             if lvl < self.L:
@@ -604,9 +647,7 @@ class UNetEngine:
             dwout = None
             self._dgrad_fused(u1, u0, P, st)
             self._bn_bwd_tail(u0, P, G, st, fused=True)
-            if self.block_done_cb is not None:
-                self._join_side()
-                self.block_done_cb(f"enc{lvl}")
+            self._announce(f"enc{lvl}")
             if lvl > 0:
                 self._dgrad(u0, P, [L.make_dst(self.dpooled[lvl])], st)
         self._join_side()

@@ -610,6 +610,21 @@ class UNetEngineBF16:
         if self.side_dw:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def _announce(self, tag: str) -> None:
+        """As engine.UNetEngine._announce: the bucket's all-reduce is called under a hand-off stream that waits for the main and
+        the side stream; the main stream (the dX chain) does not wait for the weight gradients."""
+        if self.block_done_cb is None:
+            return
+        if not self.side_dw or self.kernel_log is not None:
+            self.block_done_cb(tag)
+            return
+        if getattr(self, "_handoff", None) is None:
+            self._handoff = torch.cuda.Stream(device=self.side.device)
+        self._handoff.wait_stream(torch.cuda.current_stream())
+        self._handoff.wait_stream(self.side)
+        with torch.cuda.stream(self._handoff):
+            self.block_done_cb(tag)
+
     def _bnbwd(self, tgt: _Unit):
         """gsd_bf16_bnbwd for fusing pass 1 of tgt's BatchNorm+ReLU backward into the dX launch that produces tgt.g."""
         yv = L.make_nhwc(tgt.y)
@@ -694,9 +709,7 @@ class UNetEngineBF16:
             done()
             prev.fused_rows = lib.gsd_bf16_conv_dense_partial_rows(n, hi, wi, up.cout, up.cin, 4, 2)
             prev_fused = prev
-            if self.block_done_cb is not None:
-                self._join_side()
-                self.block_done_cb(f"dec{j}")
+            self._announce(f"dec{j}")
         for lvl in reversed(range(self.L + 1)):
             u0, u1 = self.enc[lvl]
             if lvl < self.L:
@@ -714,9 +727,7 @@ class UNetEngineBF16:
             inc = lvl == 0 and self.fused_inc      # u0's raw output was never stored: no pass 1 in the dX epilogue
             self._dgrad(u1, P, u0.g, st, fuse=None if inc else u0)
             self._tail(u0, G, st, fused=True, recompute=inc)
-            if self.block_done_cb is not None:
-                self._join_side()
-                self.block_done_cb(f"enc{lvl}")
+            self._announce(f"enc{lvl}")
             if lvl > 0:
                 self._dgrad(u0, P, self.dpooled[lvl], st)
         self._join_side()

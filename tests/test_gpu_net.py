@@ -476,3 +476,20 @@ def test_backward_teacher_forced_unit_by_unit(dims, h, w):
             _, idx = on.maxpool2_fwd(act(skip))
             dpool = on.maxpool2_bwd(npy(eng.dpooled[lvl + 1]), idx, act(skip).shape)
             close(dz_of(skip), masked(skip, dcat[:, :skip.cout] + dpool), 1e-5, f"skip + pool gradient into {skip.gname}")
+
+
+@pytest.mark.parametrize("h,w,dims", [(20, 27, [18, 36]), (41, 53, [20, 40, 80]), (12, 9, [64, 128])])
+def test_eval_forward_is_batch_independent_for_any_dims(h, w, dims):
+    """Eval-mode batch independence (image i of a batch == the image alone, bitwise) where the two-dimensional Winograd form does
+    not serve the channel counts (18: not a multiple of 4) and on small images: the engine decides the conv form from
+    N-independent quantities in eval mode and never takes the row form there (it folds rows across images)."""
+    st = synth.make_state(3, 1, dims, h + w, "conditioned")
+    x, _ = synth.make_batch(5, h, w, 3)
+    xd = torch.from_numpy(x).cuda()
+    m = make_model(dims, st)
+    m.eval()
+    yb = m(x=xd).clone()
+    for i in (0, 3, 4):
+        assert torch.equal(yb[i:i + 1], m(x=xd[i:i + 1].contiguous())), i
+    from oracle import unet_numpy as on
+    assert rel_l1(yb.cpu().numpy(), on.UNetOracle(st).forward(x, train=False)) < 1e-4

@@ -278,3 +278,20 @@ def test_gaussian_blur_restatement(k):
                     want[:, :, h, w] += k2[i, j] * x[:, :, refl(h + i - r, 9), refl(w + j - r, 11)]
     got = dr.gaussian_blur(torch.from_numpy(x), k).numpy()
     assert np.abs(got - want).max() < 1e-6
+
+
+def test_l1_loss_matches_torch():
+    """oracle.l1_loss (the per-pixel L1 the north star names beside the reference's MSE, train_unet.py:51-52) against
+    torch.nn.functional.l1_loss: value and gradient (sign / N; torch's subgradient at 0 is 0)."""
+    import torch
+    from oracle import unet_numpy as on
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((3, 1, 17, 23)).astype(np.float32)
+    t = rng.standard_normal((3, 1, 17, 23)).astype(np.float32)
+    t[0, 0, 0, :5] = y[0, 0, 0, :5]            # exact ties: the subgradient convention
+    loss, dy = on.l1_loss(y, t)
+    yt = torch.from_numpy(y).requires_grad_(True)
+    lt = torch.nn.functional.l1_loss(yt, torch.from_numpy(t))
+    lt.backward()
+    assert abs(loss - lt.item()) < 1e-6 * max(abs(lt.item()), 1e-30)
+    np.testing.assert_allclose(dy, yt.grad.numpy(), rtol=1e-6, atol=0)
