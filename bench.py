@@ -643,8 +643,8 @@ def main():
                 roof["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes: %s)" % ", ".join(tj.get("sources", []))
                 roof["traffic_provenance"] = traffic_provenance(tj)
                 # algorithmic bytes of an average launch of the dominant kernel: the source segments and the
-                # destination once each + the weight image; forward 0.97 GB, dX with the fused BatchNorm-backward read 1.50 GB
-                roof["algorithmic_bytes_per_launch"] = int(tj.get("algorithmic_bytes_per_launch", 1.23e9))
+                # destination once each + the weight image (profiles/make_traffic.py): forward 0.98 GB, dX 1.23 GB, average 1.105 GB
+                roof["algorithmic_bytes_per_launch"] = int(tj.get("algorithmic_bytes_per_launch", 1.105e9))
                 roof["traffic_vs_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 3)
         except (OSError, ValueError, KeyError):
             pass

@@ -37,6 +37,24 @@ def pooled(path, counters):
     return {c: v / max(n, 1) for c, v in tot.items()}, n
 
 
+def algorithmic_bytes_per_launch(n=32):
+    """SURVEY 8(d)-style count for the dominant kernel's 34 launches of a step (17 forward + 17 dX, Cin >= 16): every source and
+    destination tensor once (4 bytes per element) + the 24-row weight image; a dX launch of a DoubleConv's second conv also reads
+    the producer's raw output (fused BatchNorm backward).  -> (average, forward average, dX average) in bytes."""
+    hs, ws, cs = [320, 160, 80, 40, 20], [427, 213, 106, 53, 26], [64, 128, 256, 512, 1024]
+    layers = [(0, 64, 64, True)]
+    for l in range(1, 5):
+        layers += [(l, cs[l - 1], cs[l], False), (l, cs[l], cs[l], True)]
+    for l in (3, 2, 1, 0):
+        layers += [(l, 2 * cs[l], cs[l], False), (l, cs[l], cs[l], True)]
+    fw = dx = 0
+    for l, ci, co, second in layers:
+        px = n * hs[l] * ws[l]
+        fw += 4 * px * (ci + co) + 96 * ci * co
+        dx += 4 * px * (ci + co) + 96 * ci * co + (4 * px * ci if second else 0)
+    return (fw + dx) / 34.0, fw / 17.0, dx / 17.0
+
+
 fetch, n1 = pooled(f"gpurun_out/{tag}_fetch_pmc.txt", ["FETCH_SIZE"])
 write, n2 = pooled(f"gpurun_out/{tag}_write_pmc.txt", ["WRITE_SIZE"])
 sq, n3 = pooled(f"gpurun_out/{tag}_sq_pmc.txt", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"])
@@ -49,6 +67,8 @@ out = {
     "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM)",
     "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0,
+    "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch()[0],
+    "algorithmic_bytes_forward_dX": list(algorithmic_bytes_per_launch()[1:]),
     "mfma_busy": busy,
     "cycles_per_launch": cycles,
     "sources": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt", f"profiles/{tag}_pmc_sq.txt"],
