@@ -237,10 +237,6 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + off), dst, 16, 0, 0);
     };
     if constexpr (WG2D_ABL & 128) o_y0 = o_y1 = 0u;
-    if constexpr (!(WG2D_ABL & 32)) {
-      fill(dblk, o_y0, raw_w);
-      if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
-    }
     // window pieces: one with a column inside the segment lies within 3 floats of its row's ends (slack >= 4) and is read where it
     // lies, partly outside or not (the transform masks by column); one without is not read where it lies (offset 0)
     if constexpr (!(WG2D_ABL & 64)) {
@@ -259,6 +255,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
           if constexpr (WG2D_ABL & 128) off = 0u;
           fill(vblk, off, smem + WIN + wb * (WINI * 256) + (wave + 8 * k) * 256);
         }
+    }
+    // dy pieces go into the slots this thread reads its raw dy rows from: those reads have to have RETURNED before a fill can land
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    if constexpr (!(WG2D_ABL & 32)) {
+      fill(dblk, o_y0, raw_w);
+      if constexpr (!UROW) fill(dblk, o_y1, raw_w + 8 * 256);
     }
   };
 
@@ -361,11 +363,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     }
   };
 
-  f32x4 acc[2][24];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int f = 0; f < 24; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][24];   // (zeroed behind the pipeline's prologue: 192 registers that the prologue's address work does not have to avoid)
 
   const int a_rd = IMG + j * TSU + (wm * 32 + l16) * 24;
   const int b_rd = IMG + 4 * TSU + j * TSV + (wn * 16 + l16) * 24;
@@ -408,6 +406,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     transform(I0{});
     if (nst > 1) load(I1{});
     gsd_dma_barrier();
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int f = 0; f < 24; ++f) acc[m][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nst > 0) {
     auto step = [&](const int it, auto cur_c) __attribute__((always_inline)) {
       constexpr int cur = decltype(cur_c)::value;
       if (it + 1 < nst && !((WG2D_ABL & 4) && it > 1)) transform(std::integral_constant<int, cur ^ 1>{});
@@ -418,9 +422,162 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
       // the fills of k-step it + 2 have the MFMA phase to land; published to the other waves (window pieces) by the barrier
       if constexpr (!(WG2D_ABL & 16)) gsd_dma_barrier();
     };
+#ifndef WG2D_PIPE   // 1: the transform of k-step it + 1 in pieces BETWEEN the MFMA groups of k-step it (software pipeline inside the wave)
+#define WG2D_PIPE 1
+#endif
+    // With separate phases a k-step was a chain of exposed latencies: raw reads -> transform -> stores | fills | operand reads ->
+    // MFMAs, every wave of the CU in the same phase (barrier): stamps showed a wave in its MFMA phase for 36 % of a k-step and
+    // removing a third of the vector instructions changed nothing.  Here the vector work rides between the MFMA groups: a piece
+    // of ~10-16 instructions works on values that were read a group earlier, clustered (the first vector instruction in an MFMA gap
+    // costs 12.6 cycles, each further one 4: profiles/r05_mfma_f32_issue_ubench.txt), and its LDS latencies lie behind MFMAs.
+    auto step_pipe = [&](const int it, auto cur_c) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_c)::value, nxt = cur ^ 1;
+      const bool tr = it + 1 < nst, ld = it + 2 < nst;
+      const float* const Sb = smem + cur * BUF;
+      const f32x2d p1m1 = {1.f, -1.f}, p2m2 = {2.f, -2.f}, c4 = {4.f, 4.f};
+      f32x4 a0, a1, b;
+      auto rd_ops = [&](const int g) __attribute__((always_inline)) {
+        a0 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 4 * g);
+        a1 = *reinterpret_cast<const f32x4*>(Sb + a_rd + 16 * 24 + 4 * g);
+        b = *reinterpret_cast<const f32x4*>(Sb + b_rd + 4 * g);
+      };
+      auto mm = [&](const int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][4 * g + e] = mfma16(a0[e], b[e], acc[0][4 * g + e]);
+          acc[1][4 * g + e] = mfma16(a1[e], b[e], acc[1][4 * g + e]);
+        }
+      };
+      auto a4_row = [&](const f32x4& y, f32x2d& u12, f32x2d& u34) __attribute__((always_inline)) {
+        const f32x2d lo2 = {y[0], y[1]}, hi2 = {y[2], y[3]};
+        const f32x2d pq = lo2 + hi2;
+        const f32x2d ab = __builtin_elementwise_fma(c4, hi2, lo2);
+        u12 = __builtin_elementwise_fma(f32x2d{pq[1], pq[1]}, p1m1, f32x2d{pq[0], pq[0]});
+        u34 = __builtin_elementwise_fma(f32x2d{ab[1], ab[1]}, p2m2, f32x2d{ab[0], ab[0]});
+      };
+      // masks of the k-step being transformed (load() below replaces r_mask / r_edge by the next one's)
+      const int t_mask = r_mask;
+      const bool t_edge = r_edge;
+      f32x4 y0, y1;
+      f32x2d a12, a34, b12, b34;
+      f32x4 ra;
+      f32x2d rb, v12, v34, v05;
+      float* const u_out = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + u_wr) + nxt * BUF;
+      auto rd_y = [&]() __attribute__((always_inline)) {
+        y0 = *reinterpret_cast<const f32x4*>(raw_r);
+        y1 = y0;
+        if constexpr (!UROW) y1 = *reinterpret_cast<const f32x4*>(raw_r + 8 * 256);
+      };
+      auto u_rows = [&]() __attribute__((always_inline)) {      // A4 along the dy rows
+        if (t_edge) {
+          if (!(t_mask & 1)) y0 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (!UROW)
+            if (!(t_mask & 2)) y1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        a4_row(y0, a12, a34);
+        if constexpr (!UROW) a4_row(y1, b12, b34);
+      };
+      auto u_cols = [&]() __attribute__((always_inline)) {      // A2 down the columns, stores
+        if constexpr (UROW) {
+          const f32x2d sg = {u_sgn, u_sgn};
+          const f32x2d a05 = {y0[0], y0[3]};
+          const f32x2d x12 = {w2d_dpp(a12[0], 1), w2d_dpp(a12[1], 1)}, x34 = {w2d_dpp(a34[0], 1), w2d_dpp(a34[1], 1)};
+          const f32x2d x05 = {w2d_dpp(a05[0], 1), w2d_dpp(a05[1], 1)};
+          float* const o_own = u_out + ((tid & 1) ? 18 : 0);
+          float* const o_t1 = u_out + ((tid & 1) ? 12 : 6);
+          *reinterpret_cast<f32x2d*>(o_own) = a12;
+          *reinterpret_cast<f32x2d*>(o_own + 2) = a34;
+          *reinterpret_cast<f32x2d*>(o_own + 4) = a05;
+          *reinterpret_cast<f32x2d*>(o_t1) = __builtin_elementwise_fma(a12, sg, x12);
+          *reinterpret_cast<f32x2d*>(o_t1 + 2) = __builtin_elementwise_fma(a34, sg, x34);
+          *reinterpret_cast<f32x2d*>(o_t1 + 4) = __builtin_elementwise_fma(a05, sg, x05);
+        } else {
+          const f32x2d s12 = a12 + b12, s34 = a34 + b34, d12 = a12 - b12, d34 = a34 - b34;
+          const float s0 = y0[0] + y1[0], s5 = y0[3] + y1[3], d0 = y0[0] - y1[0], d5 = y0[3] - y1[3];
+          *reinterpret_cast<f32x4*>(u_out) = f32x4{a12[0], a12[1], a34[0], a34[1]};
+          *reinterpret_cast<f32x4*>(u_out + 4) = f32x4{y0[0], y0[3], s12[0], s12[1]};
+          *reinterpret_cast<f32x4*>(u_out + 8) = f32x4{s34[0], s34[1], s0, s5};
+          *reinterpret_cast<f32x4*>(u_out + 12) = f32x4{d12[0], d12[1], d34[0], d34[1]};
+          *reinterpret_cast<f32x4*>(u_out + 16) = f32x4{d0, d5, b12[0], b12[1]};
+          *reinterpret_cast<f32x4*>(u_out + 20) = f32x4{b34[0], b34[1], y1[0], y1[3]};
+        }
+      };
+      auto rd_v = [&](const int i) __attribute__((always_inline)) {
+        const float* const wp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + v_rd) + nxt * (WINI * 256) + i * 32 * (P.WR * P.NP * 4);
+        ra = *reinterpret_cast<const f32x4*>(wp);
+        rb = *reinterpret_cast<const f32x2d*>(wp + 4);
+      };
+      auto v_rows = [&](const int i) __attribute__((always_inline)) {   // deferred BatchNorm + ReLU, masks, B4^T along the window row
+        f32x2d t0 = {ra[0], ra[1]}, t1 = {ra[2], ra[3]}, t2 = rb;
+        if constexpr (!PLAIN) {
+          const f32x2d ss = *reinterpret_cast<const f32x2d*>(smem + SCS + 2 * ((tid >> 4) + 32 * i));
+          const f32x2d sc2 = {ss[0], ss[0]}, sh2 = {ss[1], ss[1]}, lo2 = {lo, lo};
+          t0 = __builtin_elementwise_max(__builtin_elementwise_fma(t0, sc2, sh2), lo2);
+          t1 = __builtin_elementwise_max(__builtin_elementwise_fma(t1, sc2, sh2), lo2);
+          t2 = __builtin_elementwise_max(__builtin_elementwise_fma(t2, sc2, sh2), lo2);
+        }
+        if (t_edge) {
+          const int m = t_mask;
+          if (!(m & 4)) t0[0] = 0.f;
+          if (!(m & 8)) t0[1] = 0.f;
+          if (!(m & 16)) t1[0] = 0.f;
+          if (!(m & 32)) t1[1] = 0.f;
+          if (!(m & 64)) t2[0] = 0.f;
+          if (!(m & 128)) t2[1] = 0.f;
+        }
+        const f32x2d m41 = {-4.f, -1.f}, m5 = {-5.f, -5.f};
+        const f32x2d ac = __builtin_elementwise_fma(f32x2d{t1[0], t1[0]}, m41, f32x2d{t2[0], t2[0]});
+        const f32x2d be = __builtin_elementwise_fma(f32x2d{t0[1], t0[1]}, m41, f32x2d{t1[1], t1[1]});
+        v12 = __builtin_elementwise_fma(f32x2d{be[0], be[0]}, p1m1, f32x2d{ac[0], ac[0]});
+        v34 = __builtin_elementwise_fma(f32x2d{be[1], be[1]}, p2m2, f32x2d{ac[1], ac[1]});
+        v05 = __builtin_elementwise_fma(t0, c4, __builtin_elementwise_fma(t1, m5, t2));
+      };
+      auto v_cols = [&](const int i) __attribute__((always_inline)) {   // B2^T down the window column (quad partners by DPP), stores
+        int tq = threadIdx.x;
+        asm volatile("" : "+v"(tq));   // (the sign is re-derived here, three instructions, instead of living in a register: as geo_packed)
+        const float sgn = (tq & 3) == 1 ? 1.f : -1.f;
+        const f32x2d sg = {sgn, sgn};
+        const f32x2d x12 = {w2d_dpp(v12[0], 0), w2d_dpp(v12[1], 0)}, x34 = {w2d_dpp(v34[0], 0), w2d_dpp(v34[1], 0)};
+        const f32x2d x05 = {w2d_dpp(v05[0], 0), w2d_dpp(v05[1], 0)};
+        float* const op = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + v_wr) + nxt * BUF + i * (32 * 24);
+        *reinterpret_cast<f32x2d*>(op) = __builtin_elementwise_fma(sg, x12, v12);
+        *reinterpret_cast<f32x2d*>(op + 2) = __builtin_elementwise_fma(sg, x34, v34);
+        *reinterpret_cast<f32x2d*>(op + 4) = __builtin_elementwise_fma(sg, x05, v05);
+      };
+#define WG2D_SB __builtin_amdgcn_sched_barrier(0)
+      rd_ops(0);
+      if (tr) rd_y();
+      WG2D_SB;
+      mm(0); WG2D_SB; rd_ops(1);
+      if (ld) load(cur_c);                      // fills of k-step it + 2 (it has this one's parity); waits for the dy reads above
+      WG2D_SB;
+      mm(1); WG2D_SB; rd_ops(2);
+      if (tr) { u_rows(); if constexpr (UROW) u_cols(); }
+      WG2D_SB;
+      mm(2); WG2D_SB; rd_ops(3);
+      if (tr) { rd_v(0); if constexpr (!UROW) u_cols(); }
+      WG2D_SB;
+      mm(3); WG2D_SB; rd_ops(4);
+      if (tr) v_rows(0);
+      WG2D_SB;
+      mm(4); WG2D_SB; rd_ops(5);
+      if (tr) { v_cols(0); if constexpr (NV > 1) rd_v(1); }
+      WG2D_SB;
+      mm(5); WG2D_SB;
+      if constexpr (NV > 1) {
+        if (tr) { v_rows(1); v_cols(1); }
+      }
+#undef WG2D_SB
+      gsd_dma_barrier();
+    };
     for (int it = 0; it < nst; it += 2) {
-      step(it, I0{});
-      if (it + 1 < nst) step(it + 1, I1{});
+      if constexpr (WG2D_PIPE != 0 && WG2D_ABL == 0) {
+        step_pipe(it, I0{});
+        if (it + 1 < nst) step_pipe(it + 1, I1{});
+      } else {
+        step(it, I0{});
+        if (it + 1 < nst) step(it + 1, I1{});
+      }
     }
   }
 
