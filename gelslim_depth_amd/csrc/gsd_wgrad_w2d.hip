@@ -545,28 +545,52 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
         *reinterpret_cast<f32x2d*>(op + 4) = __builtin_elementwise_fma(sg, x05, v05);
       };
 #define WG2D_SB __builtin_amdgcn_sched_barrier(0)
+#ifndef WG2D_VPRIO     // diagnostic: wave priority during the vector pieces
+#define WG2D_VPRIO 0
+#endif
+#ifndef WG2D_SPLITMM   // diagnostic: a piece between the two halves of an MFMA group instead of behind it
+#define WG2D_SPLITMM 0
+#endif
+      auto mm_half = [&](const int g, const int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 2 * h; e < 2 * h + 2; ++e) {
+          acc[0][4 * g + e] = mfma16(a0[e], b[e], acc[0][4 * g + e]);
+          acc[1][4 * g + e] = mfma16(a1[e], b[e], acc[1][4 * g + e]);
+        }
+      };
+      // one MFMA group, the next group's operand reads behind it, and a vector piece
+      auto group = [&](const int g, auto piece) __attribute__((always_inline)) {
+        if constexpr (WG2D_SPLITMM) {
+          mm_half(g, 0); WG2D_SB;
+          if constexpr (WG2D_VPRIO) __builtin_amdgcn_s_setprio(WG2D_VPRIO);
+          piece();
+          if constexpr (WG2D_VPRIO) __builtin_amdgcn_s_setprio(0);
+          WG2D_SB;
+          mm_half(g, 1); WG2D_SB;
+          if (g + 1 < 6) rd_ops(g + 1);
+          WG2D_SB;
+        } else {
+          mm(g); WG2D_SB;
+          if (g + 1 < 6) rd_ops(g + 1);
+          if constexpr (WG2D_VPRIO) __builtin_amdgcn_s_setprio(WG2D_VPRIO);
+          piece();
+          if constexpr (WG2D_VPRIO) __builtin_amdgcn_s_setprio(0);
+          WG2D_SB;
+        }
+      };
       rd_ops(0);
       if (tr) rd_y();
       WG2D_SB;
-      mm(0); WG2D_SB; rd_ops(1);
-      if (ld) load(cur_c);                      // fills of k-step it + 2 (it has this one's parity); waits for the dy reads above
-      WG2D_SB;
-      mm(1); WG2D_SB; rd_ops(2);
-      if (tr) { u_rows(); if constexpr (UROW) u_cols(); }
-      WG2D_SB;
-      mm(2); WG2D_SB; rd_ops(3);
-      if (tr) { rd_v(0); if constexpr (!UROW) u_cols(); }
-      WG2D_SB;
-      mm(3); WG2D_SB; rd_ops(4);
-      if (tr) v_rows(0);
-      WG2D_SB;
-      mm(4); WG2D_SB; rd_ops(5);
-      if (tr) { v_cols(0); if constexpr (NV > 1) rd_v(1); }
-      WG2D_SB;
-      mm(5); WG2D_SB;
-      if constexpr (NV > 1) {
-        if (tr) { v_rows(1); v_cols(1); }
-      }
+      group(0, [&]() __attribute__((always_inline)) { if (ld) load(cur_c); });   // fills of k-step it + 2 (this one's parity); waits for rd_y
+      group(1, [&]() __attribute__((always_inline)) { if (tr) { u_rows(); if constexpr (UROW) u_cols(); } });
+      group(2, [&]() __attribute__((always_inline)) { if (tr) { rd_v(0); if constexpr (!UROW) u_cols(); } });
+      group(3, [&]() __attribute__((always_inline)) { if (tr) v_rows(0); });
+      group(4, [&]() __attribute__((always_inline)) { if (tr) { v_cols(0); if constexpr (NV > 1) rd_v(1); } });
+      group(5, [&]() __attribute__((always_inline)) {
+        if constexpr (NV > 1) {
+          if (tr) { v_rows(1); v_cols(1); }
+        }
+      });
 #undef WG2D_SB
       gsd_dma_barrier();
     };
@@ -632,9 +656,9 @@ WgW2dPlan plan_wg2d(int N, int H, int W, int M, int Ncols) {
   for (int kx = 4; kx >= 1; kx /= 2) {
     if (force_kx && kx != force_kx) continue;
     const int ky = 4 / kx;
-    // fewest k-steps, weighted by what a k-step of that shape costs: 2 x 2 and 4 x 1 tiles fetch shorter runs of more rows
-    // (measured per k-step against 1 x 4, batch 32: +2 ... +13 % and +13 ... +55 %, profiles/r06_wg2d_kstep_shapes.txt)
-    const long steps = (long)ceil_div(p.tiles_y, ky) * ceil_div(p.tiles_x, kx) * (kx == 4 ? 100 : kx == 2 ? 106 : 130);
+    // fewest k-steps, weighted by what a k-step of that shape costs (profiles/r06_wg2d_kstep_shapes.txt, batch 32): 2 x 2 tiles cost
+    // what 1 x 4 tiles cost within 2 % either way (a 6 x 12 window instead of 4 x 20) and get the ties, 4 x 1 tiles 7-16 % more
+    const long steps = (long)ceil_div(p.tiles_y, ky) * ceil_div(p.tiles_x, kx) * (kx == 4 ? 100 : kx == 2 ? 99 : 112);
     if (best < 0 || steps < best) {
       best = steps;
       p.KY = ky; p.KX = kx;
