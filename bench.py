@@ -651,6 +651,17 @@ def main():
         if args.dtype == "f32" and args.workload == "train":
             sec = second_roofline(main_wlog, logged_steps, ms_per_step)
             if sec is not None:
+                try:
+                    tw = json.load(open(os.path.join(REPO, "profiles", "traffic_wgrad.json")))
+                    if tw.get("kernel", "?") in sec["kernel"] and B == 32:
+                        sec["traffic"] = round(float(tw["hbm_bytes_per_launch"]))
+                        sec["algorithmic_bytes_per_launch"] = int(tw["algorithmic_bytes_per_launch"])
+                        sec["traffic_vs_algorithmic"] = round(sec["traffic"] / sec["algorithmic_bytes_per_launch"], 3)
+                        sec["mfma_busy_pmc"] = round(float(tw["mfma_busy"]), 3) if tw.get("mfma_busy") else None
+                        sec["traffic_source"] = "profiles/traffic_wgrad.json (committed rocprofv3 --pmc passes: %s)" % ", ".join(tw.get("sources", []))
+                        sec["traffic_provenance"] = traffic_provenance(tw)
+                except (OSError, ValueError, KeyError):
+                    pass
                 roof["second"] = sec
         if hbm is not None:
             roof["hbm"] = hbm

@@ -10,6 +10,7 @@ import sys
 
 tag = sys.argv[1]
 KERNEL = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_w2d_kernel"
+OUT = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
 
 
 def lib_digest():
@@ -55,6 +56,17 @@ def algorithmic_bytes_per_launch(n=32):
     return (fw + dx) / 34.0, fw / 17.0, dx / 17.0
 
 
+def wgrad_algorithmic_bytes_per_launch(n=32):
+    """conv3x3 dW, 17 launches: the activation and the gradient once each + the (Cout, Cin, 3, 3) result."""
+    hs, ws, cs = [320, 160, 80, 40, 20], [427, 213, 106, 53, 26], [64, 128, 256, 512, 1024]
+    layers = [(0, 64, 64)]
+    for l in range(1, 5):
+        layers += [(l, cs[l - 1], cs[l]), (l, cs[l], cs[l])]
+    for l in (3, 2, 1, 0):
+        layers += [(l, 2 * cs[l], cs[l]), (l, cs[l], cs[l])]
+    return sum(4 * n * hs[l] * ws[l] * (ci + co) + 36 * ci * co for l, ci, co in layers) / 17.0
+
+
 fetch, n1 = pooled(f"gpurun_out/{tag}_fetch_pmc.txt", ["FETCH_SIZE"])
 write, n2 = pooled(f"gpurun_out/{tag}_write_pmc.txt", ["WRITE_SIZE"])
 sq, n3 = pooled(f"gpurun_out/{tag}_sq_pmc.txt", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"])
@@ -67,12 +79,12 @@ out = {
     "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM)",
     "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024.0,
-    "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch()[0],
-    "algorithmic_bytes_forward_dX": list(algorithmic_bytes_per_launch()[1:]),
+    "algorithmic_bytes_per_launch": algorithmic_bytes_per_launch()[0] if "conv3x3" in KERNEL else wgrad_algorithmic_bytes_per_launch(),
+    "algorithmic_bytes_forward_dX": list(algorithmic_bytes_per_launch()[1:]) if "conv3x3" in KERNEL else None,
     "mfma_busy": busy,
     "cycles_per_launch": cycles,
     "sources": [f"profiles/{tag}_pmc_fetch_size.txt", f"profiles/{tag}_pmc_write_size.txt", f"profiles/{tag}_pmc_sq.txt"],
     "library_source_digest": lib_digest(),
 }
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+json.dump(out, open(OUT, "w"), indent=1)
 print(json.dumps(out, indent=1))
