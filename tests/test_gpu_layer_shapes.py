@@ -86,7 +86,7 @@ FORM_CASES = [(u, n, f) for u, n in CASES for f in ("w43", "w2d")]
 @pytest.mark.parametrize("unit,n,form", FORM_CASES, ids=[f"{u[0]}-N{n}-{f}" for u, n, f in FORM_CASES])
 def test_conv3x3_unit_at_network_shape(gsd, unit, n, form):
     """form: the Winograd F(4,3)-rows kernels (gsd_conv3x3_w43*) or the two-dimensional F(2x4,3x3) kernels (gsd_conv3x3_w2d*) for
-    the forward and dX launches; dW is the same kernel in both."""
+    the forward and dX launches; dW is the same kernel in both (the two-dimensional Winograd form, checked in the w43 case)."""
     from oracle import unet_numpy as on
     name, lvl, c0, c1, co, pooled = unit
     h, w = HS[lvl], WS[lvl]
@@ -206,6 +206,8 @@ def test_conv3x3_unit_at_network_shape(gsd, unit, n, form):
     dw = torch.full((co, ci, 3, 3), float("nan"), device="cuda")
     assert L.gsd_conv3x3_wgrad_takes_pitched_dy(n, h, w, ci, co) == 1
     dy_src = gsd.make_src(dyp)
+    # every Winograd layer of the network takes the two-dimensional F(2x4,3x3) dW kernel (gsd_wgrad_w2d.hip) in the engine's form
+    assert L.gsd_conv3x3_wgrad_form(src, len(segs), C.byref(dy_src), ci, co, n, h, w) == 2
     gsd.check(L.gsd_conv3x3_wgrad(src, len(segs), C.byref(dy_src), ci, co, dw.data_ptr(), ws.data_ptr(), need, n, h, w,
                                   gsd.stream_ptr()))
     got = dw.cpu().numpy()
