@@ -78,8 +78,9 @@ typedef struct {
                            the last element of the stored tensor (0: none).  With slack >= 4 the Winograd
                            dW kernel moves activation windows as 16-byte pieces straight from unaligned
                            rows -- a piece that straddles an image edge reads up to 3 floats of the
-                           neighbouring row, at the tensor's two ends of the slack -- a quarter of the
-                           fill instructions.  (Keeps the 64-bit members aligned.)                  */
+                           neighbouring row, at the tensor's two ends of the slack; the two-dimensional
+                           dW form also parks masked lanes on the 4 floats in front of a plane -- a quarter
+                           of the fill instructions.  (Keeps the 64-bit members aligned.)           */
   int64_t n_stride;     /* elements between images                                              */
   int64_t c_stride;     /* elements between channels                                            */
 } gsd_src;
