@@ -704,11 +704,12 @@ int gsd_wgrad_w2d_use(const gsd_src* a, int nsrc, const gsd_src* dy, int Cin, in
   if (!p.ok) return 0;
   if (dy->w_stride % 4 != 0 || ((uintptr_t)dy->ptr & 15) != 0 || dy->c_stride % 4 != 0 || dy->n_stride % 4 != 0) return 0;
   if (dy->w_stride < 4 * p.tiles_x) return 0;
-  if ((int64_t)p.BM * dy->c_stride * 4 >= (1LL << 31)) return 0;
+  if ((int64_t)p.BM * dy->c_stride * 4 >= (1LL << 31)) return 0;   // lane offsets are 32-bit byte offsets inside a block's planes
   if (nsrc == 2 && a[0].C % p.BN != 0) return 0;
   for (int i = 0; i < nsrc; ++i) {
     if (a[i].slack < 4) return 0;
     if ((int64_t)p.BN * a[i].c_stride * 4 >= (1LL << 31)) return 0;
+    if ((int64_t)(a[i].H + 4) * a[i].w_stride * 4 >= (1LL << 31)) return 0;   // (k-step origins inside a plane are 32-bit too)
   }
   return 1;
 }
