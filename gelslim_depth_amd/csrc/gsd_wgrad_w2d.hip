@@ -198,7 +198,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
     // (the activation base is 4 floats IN FRONT of the plane, inside the slack the caller vouches for: the piece that starts at
     //  column -1 of row 0 of the block's first channel has offset -4 bytes from the plane, and the offsets are UNSIGNED 32-bit --
     //  a zero-extended -4 is 4 GiB away: the memory fault of this kernel's first LDS-DMA builds)
-    const char* const vblk = reinterpret_cast<const char*>(S_p + (long long)n * S_ns + (long long)S_c0 * S_cs) - 16;
+    const char* vblk = reinterpret_cast<const char*>(S_p + (long long)n * S_ns + (long long)S_c0 * S_cs) - 16;
+    asm volatile("" : "+s"(vblk));   // (a scalar: otherwise hipcc adds the -16 per lane and fill, a 64-bit vector addition each)
     const int hs = 2 * ty0 - 1 - S_oh, wsx = 4 * tx0 - 1 - S_ow;
     const unsigned d_org = (unsigned)(2 * ty0 * P.dy.ws + 4 * tx0) * 4u;   // k-step origin inside a dy plane, bytes
     const int v_org = (hs * S_ws + wsx) * 4 + 16;                          // ... from vblk (< 0 only where every lane is masked)
@@ -226,9 +227,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_w2d_kernel(const WgW2dParams 
         const bool t_ok = ty < P.tiles_y && tx < P.tiles_x;
         const int row = hs + 2 * vy + (geo >> 12 & 3), c0 = wsx + 4 * vx;
         const bool r_ok = t_ok && (unsigned)row < (unsigned)S_H;
-        int cm = 0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) cm |= (r_ok && (unsigned)(c0 + c) < (unsigned)S_W) ? 1 << c : 0;
+        // the valid columns of the 6-float row piece are the range [max(0, -c0), min(6, S_W - c0)): a mask from two shifts
+        const int lo_ = c0 < 0 ? -c0 : 0, hi_ = S_W - c0;
+        const int lo = lo_ < 6 ? lo_ : 6, hi = hi_ < 0 ? 0 : (hi_ < 6 ? hi_ : 6);   // shift counts in [0, 6]
+        const int cm = (r_ok && hi > lo) ? ((1 << hi) - 1) & ~((1 << lo) - 1) : 0;
         m |= cm << 2;
       }
       r_mask = m;
