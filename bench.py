@@ -691,6 +691,10 @@ def main():
                                             "fp32: two-dimensional winograd F(2x4,3x3) or winograd F(4,3) rows with K slabs, per launch by "
                                             "the library's run-time models (Cin>=16) / direct taps (first layer)"))},
             "roofline": roof,
+            # which machine measured this line: the pool's boxes differ by 2-3 %; the dominant kernel's average
+            # launch time in `roofline` (1.43-1.44 ms on the fast group, ~1.48 on the slow one) tells the group
+            "box": {"hostname": __import__("socket").gethostname(), "device": torch.cuda.get_device_name(dev_index),
+                    "compute_units": torch.cuda.get_device_properties(dev_index).multi_processor_count},
         }
         if comm is not None:
             comm["share_of_step"] = round(comm["allreduce_ms_per_step"] / ms_per_step, 4) if ms_per_step > 0 else None
