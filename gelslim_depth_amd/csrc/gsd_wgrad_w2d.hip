@@ -16,20 +16,28 @@
 // own operands (7 vector instructions per MFMA at a 16 x 16 wave tile, 264 registers at 32 x 16) is the
 // transform work, so here it is done ONCE PER BLOCK and shared through LDS:
 //
-//   * a block of 8 waves owns BM x BN = 128 co x 32 ci (or 64 x 64 for the 64-channel layers); a k-step is 4 tiles (32 pixels);
-//   * per k-step every thread takes one or two small transform TASKS on raw values it loaded from global memory into registers
-//     a k-step earlier -- "U" (one (co, tile): two aligned 16-byte pieces of the row-pitched dy -> 24 values, 30 instructions)
-//     and "V row" (one window row of a (ci, tile): 6 floats -> deferred BatchNorm+ReLU -> B4^T row transform; the B2^T column
-//     transform takes the other three rows from the lane's quad by DPP: 36 instructions for 6 values) -- and stores the results
-//     as [tile][channel][24 frequencies] images;
-//   * the MFMA phase of a wave (tile 32 co x 16 ci x 24 frequencies = 192 accumulator registers) reads its operands
-//     frequency-major: one ds_read_b128 is four frequencies of (channel l16, tile j), 18 reads per 48 MFMAs, no vector work;
-//   * two images: the transforms of k-step i+1 are written while k-step i is multiplied, one barrier per k-step.
+//   * a block of 8 waves owns BM x BN = 128 co x 32 ci (or 64 x 64 for the 64-channel layers); a k-step is 4 tiles (32 pixels:
+//     1 x 4, 2 x 2 or 4 x 1 tiles, chosen per shape); one block per CU, split-K over k-steps;
+//   * per k-step every thread takes one or two small transform TASKS -- "U" (one (co, tile): two aligned 16-byte pieces of the
+//     row-pitched dy -> A4 along the rows, A2 down the columns -> 24 values) and "V row" (one window row of a (ci, tile): 6 floats ->
+//     deferred BatchNorm+ReLU -> B4^T; the B2^T column transform takes the partner row from the lane's quad by DPP) -- in packed
+//     fp32 math, and stores the results as [tile][channel][24 frequencies] images;
+//   * the raw values of the NEXT k-step wait in LDS, moved by LDS-DMA: dy pieces in per-thread private slots, the activation windows
+//     as one image per block and k-step (the halo shared by its tiles, filled as runs of consecutive 16-byte pieces); nothing raw is
+//     held in registers across MFMAs (192 accumulators + one piece's values is all that fits);
+//   * a wave's 48 MFMAs of k-step i (tile 32 co x 16 ci x 24 frequencies = 192 accumulator registers; operands frequency-major: one
+//     ds_read_b128 is four frequencies of (channel l16, tile j), 18 reads per 48 MFMAs, no vector work) run in six groups with the
+//     transform of k-step i+1 in PIECES between them -- a software pipeline inside the wave: with separate phases all eight waves of
+//     the CU sat in the same phase and the matrix pipes were 0.53 busy (docs/LOG_r06.md);
+//   * two transform images and two window images (k-step parity), one barrier per k-step.
 //
-// Vector instructions per MFMA: ~1.4 (128 x 32) / ~2 (64 x 64) against 2.7-3.3 in the row form, on two thirds of its MFMAs.
+// ~1.9 vector instructions per MFMA including addressing (row form: 2.7-3.3), on two thirds of the row form's MFMAs; 23.6 ms for
+// the network's 17 layers at batch 32 against 29.5.  The kernel lives at the register limit and must compile to ZERO scratch
+// (tests/test_abi.py): with spills hipcc stored two slots on some paths of a branchy prologue only and reloaded them on all.
 // Split-K over k-steps with ordered slab reduction (the row form's reducer and slab layout): bitwise reproducible.
 //
-// Conventions: U row 3 is +dY row 1 and V row 3 is d3 - d1 (both signs of the textbook F(2,3) flipped: same products).
+// Conventions: U row 3 is +dY row 1 and V row 3 is d3 - d1 (both signs of the textbook F(2,3) flipped: same products); the six
+// frequencies of a row are stored in the order [1, 2, 3, 4, 0, 5] (what the packed transforms produce as register pairs).
 #include "gsd_common.h"
 #include <type_traits>
 
@@ -40,7 +48,8 @@ typedef float f32x2d __attribute__((ext_vector_type(2)));
 
 // Diagnostic builds only (-DWG2D_ABL=mask via profiles/build_diag_one.sh; never in the product library; results are then garbage):
 // 1 no MFMAs, 2 no LDS-DMA fills after the first two k-steps, 4 no transform after the first two, 8 no operand reads, 16 no barrier,
-// 32 no dy fills, 64 no window fills, 128 every fill reads offset 0 (issue cost without the memory system's)
+// 32 no dy fills, 64 no window fills, 128 every fill reads offset 0 (issue cost without the memory system's).  Any non-zero mask
+// also runs the phase-separated loop (transform, fills, MFMAs one after the other) instead of the pipelined one.
 #ifndef WG2D_ABL
 #define WG2D_ABL 0
 #endif
