@@ -1,6 +1,6 @@
 """fp32 conv3x3 on the U-Net's layer shapes: Winograd F(4,3) rows (gsd_conv3x3_w43) against the two-dimensional F(2x4,3x3)
 (gsd_conv3x3_w2d), forward with a deferred-BatchNorm source + statistics, and the relative L1 of both against the direct-tap kernel.
-usage (GPU box): python profiles/bench_conv_w2d.py [batch] [max level]"""
+usage (GPU box): python profiles/bench_conv_w2d.py [batch] [max level] [min level]"""
 import sys
 import torch
 from gelslim_depth_amd import _lib as L
@@ -8,10 +8,11 @@ from gelslim_depth_amd import _lib as L
 lib, check = L.lib, L.check
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 LMAX = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+LMIN = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 HS, WS = [320, 160, 80, 40, 20], [427, 213, 106, 53, 26]
 C = [64, 128, 256, 512, 1024]
 shapes = []
-for lvl in range(0, LMAX + 1):
+for lvl in range(LMIN, LMAX + 1):
     if lvl:
         shapes += [(lvl, C[lvl], C[lvl - 1]), (lvl, C[lvl - 1], C[lvl])]
     shapes += [(lvl, C[lvl], C[lvl])]
