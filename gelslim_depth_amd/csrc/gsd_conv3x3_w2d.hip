@@ -52,6 +52,7 @@ struct W2DParams {
   int N, H, W;
   int TH, TW, TWq, tiles_y, tiles_x, WR, WC, WCp, PS, NPV;
   int NP, NI;   // X4: 16-byte pieces per window row (TW / 4 + 2), DMA instructions per channel plane
+  int mgrp, pgrp, ptiles;   // block order of the deep levels: passes of mgrp m-blocks over groups of pgrp of the ptiles pixel tiles
   int nslab;    // K slabs (SPLIT): block (tile, slab k, m-block) runs chunks [k n / S, (k + 1) n / S) and stores its un-reduced
   float* slabs; // 2 x 4 outputs per channel and Winograd tile to [tile][slab][m-block][64 channels][16 NWP tiles][8] floats
 };
@@ -257,9 +258,29 @@ __global__ __launch_bounds__(128 * NWP, 2) void conv3x3_w2d_kernel(const W2DPara
 
   // the m-blocks of one pixel tile read the same halo: every XCD gets a contiguous range of logical ids (pixel tile major)
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int mbb = lid % P.mblocks;
+  int mbb = lid % P.mblocks;
   const int slab = SPLIT ? (lid / P.mblocks) % P.nslab : 0;
-  const int pt = SPLIT ? lid / P.mblocks / P.nslab : lid / P.mblocks;
+  int pt = SPLIT ? lid / P.mblocks / P.nslab : lid / P.mblocks;
+  if (!SPLIT && P.mgrp < P.mblocks) {
+    // Deep levels: an m-block's weight image (24 KiB per chunk) is megabytes, and the blocks in flight on an XCD are at arbitrary
+    // phases of their chunk loops once the first round is over -- with every m-block of a pixel tile in flight at once, the eight or
+    // sixteen weight streams evict each other from the 4-MiB L2 and nearly every weight fill misses it (measured: 7.0 GB of L2 misses
+    // per 40 x 53 512 -> 512 launch, the weight fills are 7.9 GB).  So the ids walk groups of `pgrp` pixel tiles, and inside a group
+    // the m-blocks in passes of `mgrp` (as many as fit the L2): the blocks in flight share mgrp weight images; the tile windows
+    // (a quarter of the weights' bytes) are what a later pass reads again.
+    const int gsz = P.pgrp * P.mblocks;
+    const int g = lid / gsz;
+    int r = lid - g * gsz;
+    const int p0 = g * P.pgrp;
+    const int pn = min(P.pgrp, P.ptiles - p0);          // (the last pixel group may be short)
+    const int per = pn * P.mgrp;
+    const int mg = r / per;
+    r -= mg * per;
+    const int gn = min(P.mgrp, P.mblocks - mg * P.mgrp);   // (and the last pass)
+    const int pl = r / gn;
+    pt = p0 + pl;
+    mbb = mg * P.mgrp + (r - pl * gn);
+  }
   const int c_lo = SPLIT ? (int)((long)slab * P.nchunks / P.nslab) : 0;
   const int c_hi = SPLIT ? (int)((long)(slab + 1) * P.nchunks / P.nslab) : P.nchunks;
   const int m0 = mbb * BM;
@@ -1052,6 +1073,18 @@ static int w2d_impl(const gsd_src* src, int nsrc, const float* wt, int Cin, int 
   P.WR = pl.WR; P.WC = pl.WC; P.WCp = pl.WCp; P.PS = pl.PS;
   P.NPV = ceil_div(P.WR * P.WCp, 64);
   GSD_REQUIRE(P.NPV <= 4 * pl.nwp, GSD_ERR_UNSUPPORTED, "gsd_conv3x3_w2d: halo window too large");
+  // block order: as many m-blocks per pass as have their weight images (24 KiB per chunk) in 3 MiB of the XCD's 4-MiB L2, over
+  // groups of as many pixel tiles as make 64 blocks (what an XCD of the four-wave form holds).  GSD_W2D_MGROUP: 0 all m-blocks of a
+  // pixel tile together (the order of the shallow levels), n that many; GSD_W2D_PGROUP the pixel tiles per group.  (tuning / A-B runs)
+  {
+    int g = (gsd_env_int("GSD_W2D_L2KB", 3072) << 10) / (P.nchunks * W2D_WTILE * 4);
+    const int forced = gsd_env_int("GSD_W2D_MGROUP", -1);
+    if (forced == 0) g = P.mblocks;
+    if (forced > 0) g = forced;
+    P.mgrp = std::min(std::max(g, 1), P.mblocks);
+    P.pgrp = std::max(gsd_env_int("GSD_W2D_PGROUP", 64 / P.mgrp), 1);
+    P.ptiles = N * pl.tiles_y * pl.tiles_x;
+  }
   const long base = (long)N * pl.tiles_y * pl.tiles_x * P.mblocks;
   // K slabs: only with a workspace (the engine lends one in train mode), only in the four-wave form, and never more than fit
   int S = (ws != nullptr && pl.nwp == 2) ? w2d_pick_slabs(base, P.nchunks, bw_raw != nullptr) : 1;

@@ -903,3 +903,35 @@ def test_winograd_instantiation_switches_are_bit_identical(gsd, monkeypatch, n, 
         monkeypatch.delenv(var)
         for a_, b_ in zip(ref, got):
             assert bool(torch.isfinite(a_).all()) and torch.equal(a_, b_), var
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,mg,pg", [(2, 512, 256, 13, 53, None, None), (3, 64, 320, 20, 37, 3, 5), (2, 32, 448, 9, 70, 2, 1),
+                                               (1, 128, 192, 17, 33, 1, 64)])
+def test_w2d_block_order_is_bit_identical(gsd, monkeypatch, n, ci, co, h, w, mg, pg):
+    """The deep levels walk their blocks in passes of a few m-blocks over groups of pixel tiles (so that the weight images in flight
+    fit the L2; gsd_conv3x3_w2d.hip, GSD_W2D_MGROUP / GSD_W2D_PGROUP): a permutation of the block ids -- every output element and
+    every BatchNorm partial row is written exactly once (NaN-prefilled), with the bits of the plain order.  Forced group sizes that
+    leave a short last pixel group and a short last pass; the default rule at K = 512."""
+    rng = np.random.default_rng(ci + co)
+    x = with_slack(dev(rnd(rng, n, ci, h, w)))
+    sc, sh = dev(rng.uniform(0.5, 1.5, ci).astype(np.float32)), dev(rnd(rng, ci, scale=0.3))
+    wl = layout(gsd, 8, dev(rnd(rng, co, ci, 3, 3, scale=0.1)), co, ci)
+    rows = gsd.lib.gsd_conv3x3_w2d_partial_rows(n, h, w, co)
+    mpad = (co + 63) // 64 * 64
+    res = []
+    for order in ("plain", "grouped"):
+        if order == "plain":
+            monkeypatch.setenv("GSD_W2D_MGROUP", "0")
+        elif mg is None:
+            monkeypatch.delenv("GSD_W2D_MGROUP")
+        else:
+            monkeypatch.setenv("GSD_W2D_MGROUP", str(mg))
+            monkeypatch.setenv("GSD_W2D_PGROUP", str(pg))
+        y = torch.full((n, co, h, w), float("nan"), device="cuda")
+        part = torch.full((rows * 2 * mpad,), float("nan"), device="cuda")
+        gsd.check(gsd.lib.gsd_conv3x3_w2d(gsd.src_array([gsd.make_src(x, sc, sh, relu=True, slack=4)]), 1, wl.data_ptr(), ci, co,
+                                          gsd.dst_array([gsd.make_dst(y)]), 1, part.data_ptr(), n, h, w, gsd.stream_ptr()))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(part).all()), order
+        res.append((y, part))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
